@@ -1,0 +1,92 @@
+"""ctypes loader of libdebwt_hip.so (include/debwt_hip.h).  There is no CPU fallback: if the HIP
+library is missing or cannot be loaded, every entry point raises."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdebwt_hip.so")
+_lib = None
+
+
+class DebwtConfig(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int), ("device", ctypes.c_int), ("sort_algo", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
+class DebwtStats(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_uint64) for n in (
+        "n", "nrec", "red_capacity", "blue_capacity", "blue_bound_num", "case3num", "sp_len",
+        "special_branch_num", "n_main", "distinct_keys", "blue_large_blocks", "blue_max_block")] +
+        [(n, ctypes.c_float) for n in (
+            "ms_extract", "ms_sort", "ms_classify", "ms_sp", "ms_blue", "ms_assemble", "ms_total",
+            "ms_host_special")] +
+        [("radix_pass_launches", ctypes.c_uint32), ("radix_pass_ms", ctypes.c_float),
+         ("radix_pass_keys", ctypes.c_uint64)])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/debwt_hip.h declares
+SYMBOLS = [
+    "debwt_create", "debwt_destroy", "debwt_strerror", "debwt_last_error", "debwt_load_text",
+    "debwt_load_ascii", "debwt_kmer_sort_rle", "debwt_classify", "debwt_sp_generate", "debwt_blue_sort",
+    "debwt_bwt_assemble", "debwt_build", "debwt_fetch_bwt", "debwt_bwt_device_ptr", "debwt_get_stats",
+    "debwt_fetch_array", "debwt_kmer_count_sorted", "debwt_radix_sort_u64", "debwt_verify_inverse",
+]
+
+
+def build(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", src_dir]
+    if force:
+        subprocess.check_call(args + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C debwt_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)
+    L.debwt_create.restype = ctypes.c_int
+    L.debwt_create.argtypes = [ctypes.POINTER(DebwtConfig), ctypes.POINTER(vp)]
+    L.debwt_destroy.restype = None
+    L.debwt_destroy.argtypes = [vp]
+    L.debwt_strerror.restype = ctypes.c_char_p
+    L.debwt_strerror.argtypes = [ctypes.c_int]
+    L.debwt_last_error.restype = ctypes.c_char_p
+    L.debwt_last_error.argtypes = [vp]
+    L.debwt_load_text.restype = ctypes.c_int
+    L.debwt_load_text.argtypes = [vp, u64p, ctypes.c_uint64, u64p, ctypes.c_uint64]
+    L.debwt_load_ascii.restype = ctypes.c_int
+    L.debwt_load_ascii.argtypes = [vp, ctypes.c_char_p, u64p, ctypes.c_uint64]
+    for name in ("debwt_kmer_sort_rle", "debwt_classify", "debwt_sp_generate", "debwt_blue_sort",
+                 "debwt_bwt_assemble", "debwt_build"):
+        fn = getattr(L, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp]
+    L.debwt_fetch_bwt.restype = ctypes.c_int
+    L.debwt_fetch_bwt.argtypes = [vp, u64p, u64p, u64p]
+    L.debwt_bwt_device_ptr.restype = ctypes.c_int
+    L.debwt_bwt_device_ptr.argtypes = [vp, ctypes.POINTER(vp)]
+    L.debwt_get_stats.restype = ctypes.c_int
+    L.debwt_get_stats.argtypes = [vp, ctypes.POINTER(DebwtStats)]
+    L.debwt_fetch_array.restype = ctypes.c_int
+    L.debwt_fetch_array.argtypes = [vp, ctypes.c_int, vp, ctypes.c_uint64, u64p]
+    L.debwt_kmer_count_sorted.restype = ctypes.c_int
+    L.debwt_kmer_count_sorted.argtypes = [vp, u64p, u64p, ctypes.c_uint64, u64p]
+    L.debwt_radix_sort_u64.restype = ctypes.c_int
+    L.debwt_radix_sort_u64.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    L.debwt_verify_inverse.restype = ctypes.c_int
+    L.debwt_verify_inverse.argtypes = [u64p, ctypes.c_uint64, u64p, ctypes.c_uint64, ctypes.c_uint64,
+                                       ctypes.POINTER(ctypes.c_uint8)]
+    _lib = L
+    return L

@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference's stage interface (src/main.h:1-8, call order src/main.c:83-149)
+over the C ABI of libdebwt_hip.so.  Same stage names and order; state lives in a context object instead
+of globals and temp files; errors raise DebwtError instead of exit(1)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+ARR_SORTED_KEYS, ARR_DISTINCT_KEYS, ARR_RED, ARR_SP_SYMBOLS, ARR_BLUE, ARR_BLUE_BOUND, ARR_CASE3_BOUND, \
+    ARR_ROW_SYMBOLS = range(1, 9)
+_ARR_DTYPE = {ARR_SP_SYMBOLS: np.uint8, ARR_ROW_SYMBOLS: np.uint8}
+
+
+class DebwtError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = _lib.lib().debwt_strerror(code).decode()
+        super().__init__(f"{msg} ({code})" + (f": {detail}" if detail else ""))
+
+
+def _p64(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+def pack_records(records):
+    """2-bit packed text in the reference layout (src/collect#$.c:61-90): base j at bit
+    2*(31-(j&31)) of word j>>5, 'T' at every separator, 32 'T' of padding.  records: list of uint8
+    code arrays (A0 C1 G2 T3).  Returns (words, n, sep)."""
+    lens = np.array([len(r) for r in records], dtype=np.uint64)
+    if (lens <= 32).any():
+        raise ValueError("every record must be longer than 32 bases (src/collect#$.c:41-45)")
+    n = int(lens.sum()) + len(records)
+    total = n + 32
+    nwords = (total + 31) // 32 + 1
+    sym = np.full(nwords * 32, 3, dtype=np.uint8)
+    sym[total:] = 0
+    sep = np.empty(len(records), dtype=np.uint64)
+    o = 0
+    for i, r in enumerate(records):
+        r = np.asarray(r, dtype=np.uint8)
+        if r.size and r.max() > 3:
+            raise ValueError("codes must be 0..3")
+        sym[o:o + len(r)] = r
+        o += len(r)
+        sep[i] = o
+        o += 1
+    q = sym.reshape(-1, 4)
+    b = (q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]
+    words = np.ascontiguousarray(b).view(">u8").astype(np.uint64)
+    return words, n, sep
+
+
+class DeBWT:
+    """One context = one GPU.  Typical use:
+        d = DeBWT(k=32); d.load_records(records); d.build(); words, hash_rows, dollar_row = d.fetch()
+    or stage by stage: kmer_sort_rle(), classify(), sp_generate(), blue_sort(), bwt_assemble()."""
+
+    def __init__(self, k=32, device=0, sort_algo=0):
+        self._L = _lib.lib()
+        cfg = _lib.DebwtConfig(k=k, device=device, sort_algo=sort_algo, reserved=0)
+        h = ctypes.c_void_p()
+        rc = self._L.debwt_create(ctypes.byref(cfg), ctypes.byref(h))
+        if rc:
+            raise DebwtError(rc)
+        self._h = h
+        self.k = k
+        self.n = 0
+        self.nrec = 0
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.debwt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc:
+            raise DebwtError(rc, self._L.debwt_last_error(self._h).decode())
+
+    # -- loading ------------------------------------------------------------------------------------
+    def load_packed(self, words, n, sep):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        sep = np.ascontiguousarray(sep, dtype=np.uint64)
+        self._keep = (words, sep)       # the library reads the host text during a run
+        self._chk(self._L.debwt_load_text(self._h, _p64(words), n, _p64(sep), len(sep)))
+        self.n, self.nrec = n, len(sep)
+
+    def load_records(self, records):
+        words, n, sep = pack_records(records)
+        self.load_packed(words, n, sep)
+
+    def load_ascii(self, records):
+        recs = [r.encode() if isinstance(r, str) else bytes(r) for r in records]
+        lens = np.array([len(r) for r in recs], dtype=np.uint64)
+        self._chk(self._L.debwt_load_ascii(self._h, b"".join(recs), _p64(lens), len(recs)))
+        self.n, self.nrec = int(lens.sum()) + len(recs), len(recs)
+
+    # -- stages (src/main.c:83-149) -------------------------------------------------------------------
+    def kmer_sort_rle(self):
+        self._chk(self._L.debwt_kmer_sort_rle(self._h))
+
+    def classify(self):
+        self._chk(self._L.debwt_classify(self._h))
+
+    def sp_generate(self):
+        self._chk(self._L.debwt_sp_generate(self._h))
+
+    def blue_sort(self):
+        self._chk(self._L.debwt_blue_sort(self._h))
+
+    def bwt_assemble(self):
+        self._chk(self._L.debwt_bwt_assemble(self._h))
+
+    def build(self):
+        self._chk(self._L.debwt_build(self._h))
+
+    # -- results --------------------------------------------------------------------------------------
+    def fetch(self):
+        words = np.empty((self.n + 31) // 32, dtype=np.uint64)
+        hrows = np.empty(max(self.nrec - 1, 1), dtype=np.uint64)
+        drow = np.empty(1, dtype=np.uint64)
+        self._chk(self._L.debwt_fetch_bwt(self._h, _p64(words), _p64(hrows), _p64(drow)))
+        return words, hrows[:self.nrec - 1], int(drow[0])
+
+    def stats(self):
+        st = _lib.DebwtStats()
+        self._chk(self._L.debwt_get_stats(self._h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def fetch_array(self, which):
+        cnt = ctypes.c_uint64()
+        self._chk(self._L.debwt_fetch_array(self._h, which, None, 0, ctypes.byref(cnt)))
+        out = np.empty(max(cnt.value, 1), dtype=_ARR_DTYPE.get(which, np.uint64))
+        self._chk(self._L.debwt_fetch_array(self._h, which, out.ctypes.data_as(ctypes.c_void_p), cnt.value,
+                                            ctypes.byref(cnt)))
+        return out[:cnt.value]
+
+    def kmer_count_sorted(self):
+        """(kmers left-aligned, counts): the contents of the reference's kmerInfo (src/mySort.c:193-195)."""
+        d = ctypes.c_uint64()
+        self._chk(self._L.debwt_kmer_count_sorted(self._h, None, None, 0, ctypes.byref(d)))
+        km = np.empty(max(d.value, 1), dtype=np.uint64)
+        ct = np.empty(max(d.value, 1), dtype=np.uint64)
+        self._chk(self._L.debwt_kmer_count_sorted(self._h, _p64(km), _p64(ct), d.value, ctypes.byref(d)))
+        return km[:d.value], ct[:d.value]
+
+    def radix_sort_device(self, keys_ptr, tmp_ptr, count, key_bits=64, want_ms=False):
+        """Sort `count` u64 keys resident in HBM (raw device pointers, e.g. torch tensor .data_ptr())."""
+        ms = ctypes.c_float()
+        self._chk(self._L.debwt_radix_sort_u64(self._h, ctypes.c_void_p(keys_ptr), ctypes.c_void_p(tmp_ptr), count,
+                                               key_bits, ctypes.byref(ms) if want_ms else None))
+        return ms.value
+
+    def bwt_device_ptr(self):
+        p = ctypes.c_void_p()
+        self._chk(self._L.debwt_bwt_device_ptr(self._h, ctypes.byref(p)))
+        return p.value
+
+
+def verify_inverse(words, n, hash_rows, dollar_row):
+    """Inverse BWT by LF walk on the host (the job of the reference's dead LFsearch path)."""
+    L = _lib.lib()
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    hr = np.ascontiguousarray(hash_rows, dtype=np.uint64)
+    nrec = len(hr) + 1
+    if len(hr) == 0:
+        hr = np.zeros(1, dtype=np.uint64)
+    out = np.empty(n, dtype=np.uint8)
+    rc = L.debwt_verify_inverse(_p64(words), n, _p64(hr), nrec, int(dollar_row),
+                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    return rc, out
+
+
+def write_outputs(path, words, hash_rows, dollar_row):
+    """OUT, OUT.#, OUT.$ exactly as src/insertCase3.c:115-131 writes them."""
+    np.ascontiguousarray(words, dtype=np.uint64).tofile(path)
+    np.ascontiguousarray(hash_rows, dtype=np.uint64).tofile(path + ".#")
+    np.array([dollar_row], dtype=np.uint64).tofile(path + ".$")

@@ -1,0 +1,96 @@
+// common.h -- shared device helpers for the gfx950 deBWT kernels (wave64 throughout).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned char u8;
+
+#define DEBWT_WAVE 64
+#define DEBWT_BLOCK 256
+#define DEBWT_WAVES (DEBWT_BLOCK / DEBWT_WAVE)
+
+// ---- 2-bit packed text (reference layout: base j at bit 2*(31-(j&31)) of word j>>5) ---------------
+
+// 64-bit window = 32 symbols starting at symbol i (reference `convert`, src/collect#$.c:243-251)
+__device__ __forceinline__ u64 text_window(const u64 *__restrict__ words, u64 i) {
+    u64 w = i >> 5;
+    u32 sh = (u32)(i & 31) << 1;
+    u64 a = words[w];
+    if (sh == 0) return a;
+    u64 b = words[w + 1];
+    return (a << sh) | (b >> (64 - sh));
+}
+__device__ __forceinline__ u32 text_symbol(const u64 *__restrict__ words, u64 i) {
+    return (u32)(words[i >> 5] >> (((u32)(31 - (i & 31))) << 1)) & 3u;
+}
+
+// separator bitmap: bit (i & 63) of word i >> 6 set when position i holds '#' or '$'.
+// 64-bit window of bits [i, i+64), bit 0 = position i.
+__device__ __forceinline__ u64 sep_window(const u64 *__restrict__ bits, u64 i) {
+    u64 w = i >> 6;
+    u32 sh = (u32)(i & 63);
+    u64 a = bits[w];
+    if (sh == 0) return a;
+    u64 b = bits[w + 1];
+    return (a >> sh) | (b << (64 - sh));
+}
+__device__ __forceinline__ bool sep_at(const u64 *__restrict__ bits, u64 i) {
+    return (bits[i >> 6] >> (i & 63)) & 1ull;
+}
+
+// ---- searches ---------------------------------------------------------------------------------------
+
+// first index in [lo, hi) with a[idx] >= key
+template <typename T>
+__device__ __forceinline__ u64 lower_bound_dev(const T *__restrict__ a, u64 lo, u64 hi, T key) {
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// first index in [lo, hi) with a[idx] > key
+template <typename T>
+__device__ __forceinline__ u64 upper_bound_dev(const T *__restrict__ a, u64 lo, u64 hi, T key) {
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (a[mid] <= key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- wave / block scans ----------------------------------------------------------------------------
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ u32 wave_scan_incl(u32 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over a 256-thread block; *total = block sum.  smem: >= DEBWT_WAVES+1 u32.
+// Ends with a barrier, so smem may be reused right after.
+__device__ __forceinline__ u32 block_scan_excl(u32 v, u32 *smem, u32 *total) {
+    u32 incl = wave_scan_incl(v);
+    u32 w = threadIdx.x >> 6;
+    if (lane_id() == 63) smem[w] = incl;
+    __syncthreads();
+    u32 base = 0, sum = 0;
+#pragma unroll
+    for (u32 i = 0; i < DEBWT_WAVES; i++) {
+        u32 t = smem[i];
+        if (i < w) base += t;
+        sum += t;
+    }
+    __syncthreads();
+    *total = sum;
+    return base + incl - v;
+}

@@ -1,0 +1,697 @@
+// debwt_hip.hip -- C ABI (include/debwt_hip.h) and stage orchestration of the gfx950 deBWT path.
+//
+// One context = one GPU = one HIP stream.  Device buffers grow on demand and are kept between runs,
+// so a steady-state run performs no allocation.  The only host work inside a run is the
+// special-region module (special_host.cpp), which overlaps the GPU's key sort.
+#include "../../include/debwt_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <new>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "radix_sort.h"
+#include "special_host.h"
+#include "stage_kernels.h"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+enum Stage { ST_EMPTY = 0, ST_LOADED, ST_SORTED, ST_CLASSIFIED, ST_SP, ST_BLUE, ST_ASSEMBLED };
+
+}  // namespace
+
+struct debwt_ctx {
+    debwt_config cfg{};
+    int K = 31;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Stage stage = ST_EMPTY;
+    debwt_stats st{};
+
+    // host side of the loaded text
+    const uint64_t *h_text = nullptr;
+    std::vector<uint64_t> own_text;
+    std::vector<uint64_t> h_sep;
+    uint64_t n = 0, nrec = 0, M = 0, NS = 0;
+    SpecialTables special;
+
+    // device buffers
+    DevBuf text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
+        red, red_q, pidx, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
+        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym;
+    u64 *sk = nullptr;          // sorted keys (keysA or keysB)
+    u32 *h_scalars = nullptr;   // pinned read-back area
+    int pbits = 8;
+    u64 D = 0, Q = 0, Rmo = 0, R = 0, B = 0, S = 0, nlarge = 0, nfacts = 0;
+
+    hipEvent_t ev[8]{};         // stage boundaries
+    hipEvent_t ev_pass[16][2]{};
+    int n_pass_events = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return e_ == hipErrorOutOfMemory ? DEBWT_ENOMEM : DEBWT_EDEVICE;                   \
+        }                                                                                      \
+    } while (0)
+
+int ensure(debwt_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return DEBWT_OK;
+    if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 16 + 256;
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return DEBWT_OK;
+}
+#define ENSURE(c, b, bytes) do { int r_ = ensure((c), (b), (bytes)); if (r_) return r_; } while (0)
+
+void plan_chunks(u64 n, u32 *nchunks, u64 *chunk) {
+    u64 tiles = (n + DEBWT_BLOCK - 1) / DEBWT_BLOCK;
+    u64 c = tiles < CP_MAXCHUNKS ? tiles : CP_MAXCHUNKS;
+    if (c == 0) c = 1;
+    u64 per = (tiles + c - 1) / c;
+    *chunk = per * DEBWT_BLOCK;
+    *nchunks = (u32)((n + *chunk - 1) / *chunk);
+    if (*nchunks == 0) *nchunks = 1;
+}
+
+// count + scan of a functor; the total lands in h_scalars[slot] once the stream is synchronised
+template <class F> int cp_count(debwt_ctx *c, const F &f, u64 n, u32 *counts, int slot) {
+    u32 nchunks; u64 chunk;
+    plan_chunks(n, &nchunks, &chunk);
+    if (n) cp_count_kernel<F><<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(f, n, chunk, counts);
+    else HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(u32), c->stream));
+    u32 *total = counts + CP_MAXCHUNKS;
+    cp_scan_kernel<<<1, 1024, 0, c->stream>>>(counts, n ? nchunks : 1, total);
+    HIPCHK(c, hipMemcpyAsync(&c->h_scalars[slot], total, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    return DEBWT_OK;
+}
+template <class F> int cp_emit(debwt_ctx *c, const F &f, u64 n, const u32 *counts) {
+    if (!n) return DEBWT_OK;
+    u32 nchunks; u64 chunk;
+    plan_chunks(n, &nchunks, &chunk);
+    cp_emit_kernel<F><<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(f, n, chunk, counts);
+    return DEBWT_OK;
+}
+// each in-flight compaction needs its own counts area: CP_MAXCHUNKS + 1 words per slot
+u32 *cp_area(debwt_ctx *c, int slot) { return c->cp_counts.as<u32>() + (size_t)slot * (CP_MAXCHUNKS + 16); }
+
+int sync_check(debwt_ctx *c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return DEBWT_OK;
+}
+
+inline u32 grid_for(u64 n, u32 block) { return (u32)((n + block - 1) / block); }
+
+RadixWorkspace radix_ws(debwt_ctx *c) {
+    RadixWorkspace ws{};
+    ws.counts = c->rs_counts.as<u32>();
+    return ws;
+}
+
+int sort_keys(debwt_ctx *c, u64 *a, u64 *b, u64 count, int key_bits, u64 **result, bool record_passes) {
+    RadixWorkspace ws = radix_ws(c);
+    hipError_t e = hipSuccess;
+    if (record_passes) {
+        *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo, &c->ev_pass[0][0], 16,
+                                 &c->n_pass_events, &e);
+        c->st.radix_pass_keys = count;
+    } else {
+        *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo, nullptr, 0, nullptr, &e);
+    }
+    if (e != hipSuccess) { c->err = std::string("radix sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
+    return DEBWT_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+
+extern "C" const char *debwt_strerror(int code) {
+    switch (code) {
+        case DEBWT_OK: return "ok";
+        case DEBWT_EINVAL: return "invalid argument";
+        case DEBWT_ENOMEM: return "out of memory";
+        case DEBWT_EDEVICE: return "HIP runtime error";
+        case DEBWT_ESTATE: return "stage called out of order";
+        case DEBWT_ERANGE: return "input exceeds a capacity of this build";
+        case DEBWT_EINTERNAL: return "internal consistency check failed";
+        default: return "unknown error";
+    }
+}
+
+extern "C" const char *debwt_last_error(const debwt_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+extern "C" int debwt_create(const debwt_config *cfg, debwt_ctx **out) {
+    if (!cfg || !out || cfg->k < 12 || cfg->k > 32) return DEBWT_EINVAL;   // src/main.c:41-47
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return DEBWT_EDEVICE;
+    debwt_ctx *c = new (std::nothrow) debwt_ctx();
+    if (!c) return DEBWT_ENOMEM;
+    c->cfg = *cfg;
+    if (c->cfg.sort_algo == 0) c->cfg.sort_algo = 1;
+    c->K = cfg->k - 1;
+    int rc = DEBWT_OK;
+    auto fail = [&](int code) { debwt_destroy(c); return code; };
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(DEBWT_EDEVICE);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(DEBWT_EDEVICE);
+    if (hipHostMalloc((void **)&c->h_scalars, 64 * sizeof(u32), hipHostMallocDefault) != hipSuccess)
+        return fail(DEBWT_ENOMEM);
+    for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) return fail(DEBWT_EDEVICE);
+    for (auto &p : c->ev_pass) for (auto &e : p) if (hipEventCreate(&e) != hipSuccess) return fail(DEBWT_EDEVICE);
+    if ((rc = ensure(c, c->rs_counts, radix_workspace_bytes(0))) != DEBWT_OK) return fail(rc);
+    if ((rc = ensure(c, c->cp_counts, 8 * (CP_MAXCHUNKS + 16) * sizeof(u32))) != DEBWT_OK) return fail(rc);
+    if ((rc = ensure(c, c->dollar, 64)) != DEBWT_OK) return fail(rc);
+    *out = c;
+    return DEBWT_OK;
+}
+
+extern "C" void debwt_destroy(debwt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->text, &c->sepbits, &c->sep, &c->keysA, &c->keysB, &c->rs_counts, &c->cp_counts, &c->dk,
+                     &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q, &c->pidx,
+                     &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
+                     &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
+                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym};
+    for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &p : c->ev_pass) for (auto &e : p) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n, const uint64_t *sep, uint64_t nrec) {
+    if (!c || !packed || !sep || nrec == 0 || n < 34) return DEBWT_EINVAL;
+    if (sep[nrec - 1] != n - 1) return DEBWT_EINVAL;
+    uint64_t prev = 0;
+    for (uint64_t r = 0; r < nrec; r++) {
+        uint64_t start = r ? sep[r - 1] + 1 : 0;
+        if (sep[r] < start + 33 || sep[r] >= n) return DEBWT_EINVAL;        // records > 32 bases
+        prev = sep[r];
+    }
+    (void)prev;
+    const int K = c->K;
+    if (n <= nrec * (uint64_t)K) return DEBWT_EINVAL;
+    uint64_t M = n - nrec * (uint64_t)K;
+    if (M >= 0xFFFFFFF0ull) return DEBWT_ERANGE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->h_text = packed;
+    c->h_sep.assign(sep, sep + nrec);
+    c->n = n; c->nrec = nrec; c->M = M; c->NS = nrec * (uint64_t)K;
+    size_t tw = (size_t)((n + 63) >> 5) + 2, bw = (size_t)(n >> 6) + 3;
+    ENSURE(c, c->text, tw * 8);
+    ENSURE(c, c->sepbits, bw * 8);
+    ENSURE(c, c->sep, nrec * 8);
+    HIPCHK(c, hipMemsetAsync(c->text.p, 0, tw * 8, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->text.p, packed, (size_t)((n + 63) >> 5) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sep.p, sep, nrec * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->sepbits.p, 0, bw * 8, c->stream));
+    k_set_sepbits<<<grid_for(nrec, 256), 256, 0, c->stream>>>(c->sep.as<u64>(), nrec, c->sepbits.as<u64>());
+    // workspace that depends only on n
+    ENSURE(c, c->keysA, M * 8 + 64);
+    ENSURE(c, c->keysB, M * 8 + 64);
+    ENSURE(c, c->dk, M * 8 + 64);
+    ENSURE(c, c->dstart, M * 4 + 64);
+    ENSURE(c, c->mchar, M + 64);
+    ENSURE(c, c->pflag, n + 64);
+    ENSURE(c, c->head_keys, nrec * 8);
+    ENSURE(c, c->spkey, c->NS * 8);
+    ENSURE(c, c->sprow, c->NS * 8);
+    ENSURE(c, c->spchr, c->NS + 64);
+    ENSURE(c, c->bwt, (size_t)((n + 31) >> 5) * 8 + 64);
+    ENSURE(c, c->hmask, (size_t)((n + 31) >> 5) * 4 + 64);
+    ENSURE(c, c->hash_rows, nrec * 8 + 64);
+    int rc = sync_check(c);
+    if (rc) return rc;
+    c->stage = ST_LOADED;
+    memset(&c->st, 0, sizeof c->st);
+    c->st.n = n; c->st.nrec = nrec; c->st.n_main = M;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_load_ascii(debwt_ctx *c, const char *seq, const uint64_t *reclen, uint64_t nrec) {
+    if (!c || !seq || !reclen || !nrec) return DEBWT_EINVAL;
+    uint64_t n = nrec;
+    for (uint64_t r = 0; r < nrec; r++) {
+        if (reclen[r] <= 32) return DEBWT_EINVAL;                              // src/collect#$.c:41-45
+        n += reclen[r];
+    }
+    std::vector<uint64_t> words(((n + 63) >> 5) + 2, 0), sep(nrec);
+    uint64_t o = 0, s = 0;
+    auto put = [&](uint64_t j, uint64_t code) { words[j >> 5] |= code << ((31 - (j & 31)) << 1); };
+    for (uint64_t r = 0; r < nrec; r++) {
+        for (uint64_t j = 0; j < reclen[r]; j++, s++, o++) {
+            uint64_t code;
+            switch (seq[s]) {                                                  // src/main.c:18-23
+                case 'A': case 'a': code = 0; break;
+                case 'C': case 'c': code = 1; break;
+                case 'G': case 'g': code = 2; break;
+                case 'T': case 't': code = 3; break;
+                default: return DEBWT_EINVAL;
+            }
+            put(o, code);
+        }
+        put(o, 3); sep[r] = o; o++;                                            // 'T' at the separator
+    }
+    for (uint64_t j = 0; j < 32; j++) put(o + j, 3);                           // src/collect#$.c:87-90
+    c->own_text.swap(words);
+    return debwt_load_text(c, c->own_text.data(), n, sep.data(), nrec);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 1: keys, sort, RLE                                                            (a-1, a-2, a-3)
+
+extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const u64 n = c->n, M = c->M;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    k_extract_keys<<<grid_for(n, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+        c->text.as<u64>(), c->sepbits.as<u64>(), c->sep.as<u64>(), c->nrec, n, c->K, 0, c->keysA.as<u64>());
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    int rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), M, 2 * c->cfg.k, &c->sk, true);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    RleF f{c->sk, c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>()};
+    if ((rc = cp_count(c, f, M, cp_area(c, 0), 0))) return rc;
+    if ((rc = cp_emit(c, f, M, cp_area(c, 0)))) return rc;
+
+    // host special-region module while the GPU sorts (src/collect#$.c:118-157,348-602)
+    auto t0 = std::chrono::steady_clock::now();
+    build_special_tables(c->h_text, n, c->h_sep.data(), c->nrec, c->K, &c->special);
+    c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const SpecialTables &sp = c->special;
+    ENSURE(c, c->branch, sp.branch.size() * 8 + 64);
+    ENSURE(c, c->facts_tmp, c->nrec * 8 + 64);
+    HIPCHK(c, hipMemcpyAsync(c->head_keys.p, sp.head_keys.data(), c->nrec * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->spkey.p, sp.key.data(), c->NS * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->spchr.p, sp.chr.data(), c->NS, hipMemcpyHostToDevice, c->stream));
+    if (!sp.branch.empty())
+        HIPCHK(c, hipMemcpyAsync(c->branch.p, sp.branch.data(), sp.branch.size() * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = sync_check(c))) return rc;
+    c->D = c->h_scalars[0];
+    c->st.distinct_keys = c->D;
+    c->st.special_branch_num = sp.branch.size();
+    c->stage = ST_SORTED;
+    return DEBWT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 2: classification                                                                      (a-8)
+
+extern "C" int debwt_classify(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_SORTED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const u64 M = c->M, D = c->D, nrec = c->nrec;
+    int rc;
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    ClassifyCommon cc{c->dk.as<u64>(), c->dstart.as<u32>(), D, M, c->head_keys.as<u64>(), nrec};
+    MultiInF fin{cc, nullptr, nullptr, nullptr};
+    MultiOutF fout{cc, c->K, nullptr};
+    if ((rc = cp_count(c, fin, D, cp_area(c, 1), 1))) return rc;
+    if ((rc = cp_count(c, fout, D, cp_area(c, 2), 2))) return rc;
+    if ((rc = sync_check(c))) return rc;
+    c->Q = c->h_scalars[1];
+    c->Rmo = c->h_scalars[2];
+    const u64 Q = c->Q, Rmo = c->Rmo;
+    const u64 nf = Rmo + nrec + Q;
+    c->nfacts = nf;
+    ENSURE(c, c->facts, nf * 8 + 64);
+    ENSURE(c, c->facts_tmp, nf * 8 + 64);
+    ENSURE(c, c->red, nf * 8 + 64);
+    ENSURE(c, c->red_q, nf * 4 + 64);
+    ENSURE(c, c->mi_j0, Q * 4 + 64);
+    ENSURE(c, c->mi_freq, Q * 4 + 64);
+    ENSURE(c, c->bstart, Q * 4 + 64);
+    ENSURE(c, c->cursor, Q * 4 + 64);
+    ENSURE(c, c->large_q, Q * 4 + 64);
+    // fact list = [multi-out facts | tail# facts | multi-in facts]
+    u64 *facts = c->facts.as<u64>();
+    fout.mo_fact = facts;
+    fin.mi_fact = facts + Rmo + nrec; fin.mi_j0 = c->mi_j0.as<u32>(); fin.mi_freq = c->mi_freq.as<u32>();
+    if ((rc = cp_emit(c, fout, D, cp_area(c, 2)))) return rc;
+    if ((rc = cp_emit(c, fin, D, cp_area(c, 1)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(facts + Rmo, c->special.tail_facts.data(), nrec * 8, hipMemcpyHostToDevice, c->stream));
+    u64 *sorted_facts = nullptr;
+    if ((rc = sort_keys(c, facts, c->facts_tmp.as<u64>(), nf, 2 * c->cfg.k, &sorted_facts, false))) return rc;
+    RedUniqueF fr{sorted_facts, nf, c->red.as<u64>()};
+    if ((rc = cp_count(c, fr, nf, cp_area(c, 3), 3))) return rc;
+    if ((rc = cp_emit(c, fr, nf, cp_area(c, 3)))) return rc;
+    BlockStartF fb{c->mi_freq.as<u32>(), c->bstart.as<u32>()};
+    if ((rc = cp_count(c, fb, Q, cp_area(c, 4), 4))) return rc;
+    if ((rc = cp_emit(c, fb, Q, cp_area(c, 4)))) return rc;
+    LargeBlockF fl{c->mi_freq.as<u32>(), BLUE_LDS_CAP, c->large_q.as<u32>()};
+    if ((rc = cp_count(c, fl, Q, cp_area(c, 5), 5))) return rc;
+    if ((rc = cp_emit(c, fl, Q, cp_area(c, 5)))) return rc;
+    if ((rc = sync_check(c))) return rc;
+    c->R = c->h_scalars[3];
+    c->B = c->h_scalars[4];
+    c->nlarge = c->h_scalars[5];
+    const u64 R = c->R;
+    RedBlockF fq{c->red.as<u64>(), c->red_q.as<u32>()};
+    if ((rc = cp_count(c, fq, R, cp_area(c, 6), 6))) return rc;
+    if ((rc = cp_emit(c, fq, R, cp_area(c, 6)))) return rc;
+    // prefix index: about two bins per red node, never finer than the node itself
+    int p = 8;
+    while (p < 26 && (1ull << p) < 2 * R) p++;
+    if (p > 2 * c->K) p = 2 * c->K;
+    c->pbits = p;
+    ENSURE(c, c->pidx, ((size_t)(1ull << p) + 2) * 4);
+    k_build_pidx<<<grid_for((1ull << p) + 1, 256), 256, 0, c->stream>>>(c->red.as<u64>(), R, c->K, p, c->pidx.as<u32>());
+    k_special_rows<<<grid_for(c->NS, 256), 256, 0, c->stream>>>(c->sk, M, c->spkey.as<u64>(), c->NS, c->sprow.as<u64>());
+    HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, Q * 4 + 4, c->stream));
+    ENSURE(c, c->blue, c->B * 8 + 64);
+    if ((rc = sync_check(c))) return rc;
+    if (c->h_scalars[6] != Q) { c->err = "multi-in count mismatch between fact list and red table"; return DEBWT_EINTERNAL; }
+    c->st.red_capacity = R; c->st.blue_capacity = c->B; c->st.blue_bound_num = Q; c->st.case3num = 2 * Q;
+    c->st.blue_large_blocks = c->nlarge;
+    c->stage = ST_CLASSIFIED;
+    return DEBWT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 3: SP code and blue entries                                                            (a-4)
+
+extern "C" int debwt_sp_generate(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_CLASSIFIED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc;
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    // S <= n; the SP symbol buffer is sized for the worst case once
+    ENSURE(c, c->spsym, c->n + 64);
+    SpF f{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->red.as<u64>(), c->pidx.as<u32>(), c->pbits,
+          c->red_q.as<u32>(), c->branch.as<u64>(), (u64)c->special.branch.size(), c->pflag.as<u8>(),
+          c->spsym.as<u8>(), c->bstart.as<u32>(), c->cursor.as<u32>(), c->blue.as<u64>()};
+    if ((rc = cp_count(c, f, c->n, cp_area(c, 0), 8))) return rc;
+    if ((rc = cp_emit(c, f, c->n, cp_area(c, 0)))) return rc;
+    if ((rc = sync_check(c))) return rc;
+    c->S = c->h_scalars[8];
+    u64 nwords = (c->S >> 4) + 3;
+    ENSURE(c, c->spn, nwords * 8);
+    k_pack_sp<<<grid_for(nwords, 256), 256, 0, c->stream>>>(c->spsym.as<u8>(), c->S, nwords, c->spn.as<u64>());
+    c->st.sp_len = c->S;
+    c->stage = ST_SP;
+    return DEBWT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 4: blue-block sort                                                                     (a-5)
+
+extern "C" int debwt_blue_sort(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_SP) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc;
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    const u64 Q = c->Q;
+    if (Q) {
+        u32 grid = Q < (1u << 20) ? (u32)Q : (1u << 20);
+        k_blue_sort_lds<<<grid, DEBWT_BLOCK, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
+                                                             c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q,
+                                                             c->spn.as<u64>(), c->S, c->mchar.as<u8>());
+    }
+    c->st.blue_max_block = 0;
+    if (c->nlarge) {
+        // heavy-tail blocks (satellite / poly-A nodes): bitonic network in HBM, one block at a time
+        std::vector<u32> lq(c->nlarge), fr(c->nlarge), bs(c->nlarge), j0(c->nlarge);
+        HIPCHK(c, hipMemcpyAsync(lq.data(), c->large_q.p, c->nlarge * 4, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = sync_check(c))) return rc;
+        for (u64 t = 0; t < c->nlarge; t++) {
+            HIPCHK(c, hipMemcpyAsync(&fr[t], c->mi_freq.as<u32>() + lq[t], 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&bs[t], c->bstart.as<u32>() + lq[t], 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&j0[t], c->mi_j0.as<u32>() + lq[t], 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        if ((rc = sync_check(c))) return rc;
+        u32 maxm = 0;
+        for (u64 t = 0; t < c->nlarge; t++) maxm = std::max(maxm, fr[t]);
+        c->st.blue_max_block = maxm;
+        u64 Pmax = 2;
+        while (Pmax < maxm) Pmax <<= 1;
+        ENSURE(c, c->large_k0, Pmax * 8);
+        ENSURE(c, c->large_en, Pmax * 8);
+        for (u64 t = 0; t < c->nlarge; t++) {
+            u64 P = 2;
+            while (P < fr[t]) P <<= 1;
+            k_large_load<<<grid_for(P, 256), 256, 0, c->stream>>>(c->blue.as<u64>(), bs[t], fr[t], P, c->spn.as<u64>(),
+                                                                  c->large_k0.as<u64>(), c->large_en.as<u64>());
+            for (u64 kk = 2; kk <= P; kk <<= 1)
+                for (u64 jj = kk >> 1; jj > 0; jj >>= 1)
+                    k_large_step<<<grid_for(P >> 1, 256), 256, 0, c->stream>>>(
+                        c->large_k0.as<u64>(), c->large_en.as<u64>(), P, kk, jj, c->spn.as<u64>(), c->S);
+            k_large_store<<<grid_for(fr[t], 256), 256, 0, c->stream>>>(c->blue.as<u64>(), bs[t], fr[t], j0[t],
+                                                                       c->large_en.as<u64>(), c->mchar.as<u8>());
+        }
+    }
+    c->stage = ST_BLUE;
+    return DEBWT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 5: assembly                                                                            (a-6)
+
+static int run_assemble(debwt_ctx *c, u8 *rowsym) {
+    u64 nw = (c->n + 31) >> 5;
+    k_assemble<<<grid_for(nw, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+        c->mchar.as<u8>(), c->M, c->sprow.as<u64>(), c->spchr.as<u8>(), c->NS, c->n, c->bwt.as<u64>(),
+        c->hmask.as<u32>(), c->dollar.as<u64>(), rowsym);
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_bwt_assemble(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_BLUE) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc;
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dollar.p, 0xFF, 8, c->stream));
+    run_assemble(c, nullptr);
+    u64 nw = (c->n + 31) >> 5;
+    HashRowsF fh{c->hmask.as<u32>(), c->hash_rows.as<u64>()};
+    if ((rc = cp_count(c, fh, nw, cp_area(c, 0), 9))) return rc;
+    if ((rc = cp_emit(c, fh, nw, cp_area(c, 0)))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    if ((rc = sync_check(c))) return rc;
+    if (c->h_scalars[9] != c->nrec - 1) {
+        c->err = "number of '#' rows differs from records-1";
+        return DEBWT_EINTERNAL;
+    }
+    // stage timings
+    float ms[7] = {0};
+    for (int i = 0; i < 7; i++) (void)hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]);
+    c->st.ms_extract = ms[0]; c->st.ms_sort = ms[1]; c->st.ms_classify = ms[2] + ms[3];
+    c->st.ms_sp = ms[4]; c->st.ms_blue = ms[5]; c->st.ms_assemble = ms[6];
+    (void)hipEventElapsedTime(&c->st.ms_total, c->ev[0], c->ev[7]);
+    c->st.radix_pass_launches = (uint32_t)c->n_pass_events;
+    c->st.radix_pass_ms = 0.f;
+    for (int i = 0; i < c->n_pass_events; i++) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, c->ev_pass[i][0], c->ev_pass[i][1]);
+        c->st.radix_pass_ms += t;
+    }
+    c->stage = ST_ASSEMBLED;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_build(debwt_ctx *c) {
+    int rc;
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    c->stage = ST_LOADED;
+    if ((rc = debwt_kmer_sort_rle(c))) return rc;
+    if ((rc = debwt_classify(c))) return rc;
+    if ((rc = debwt_sp_generate(c))) return rc;
+    if ((rc = debwt_blue_sort(c))) return rc;
+    return debwt_bwt_assemble(c);
+}
+
+extern "C" int debwt_fetch_bwt(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row) {
+    if (!c || !bwt || !dollar_row || (c->nrec > 1 && !hash_rows)) return DEBWT_EINVAL;
+    if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemcpyAsync(bwt, c->bwt.p, (size_t)((c->n + 31) >> 5) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (c->nrec > 1)
+        HIPCHK(c, hipMemcpyAsync(hash_rows, c->hash_rows.p, (c->nrec - 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dollar_row, c->dollar.p, 8, hipMemcpyDeviceToHost, c->stream));
+    return sync_check(c);
+}
+
+extern "C" int debwt_bwt_device_ptr(debwt_ctx *c, const uint64_t **d_words) {
+    if (!c || !d_words) return DEBWT_EINVAL;
+    if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
+    *d_words = c->bwt.as<uint64_t>();
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_get_stats(const debwt_ctx *c, debwt_stats *out) {
+    if (!c || !out) return DEBWT_EINVAL;
+    *out = c->st;
+    return DEBWT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+
+extern "C" int debwt_fetch_array(debwt_ctx *c, debwt_array which, void *dst, uint64_t capacity, uint64_t *count) {
+    if (!c || !count) return DEBWT_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const void *src = nullptr;
+    uint64_t cnt = 0, esz = 8;
+    Stage need = ST_SORTED;
+    std::vector<uint64_t> host;
+    switch (which) {
+        case DEBWT_ARR_SORTED_KEYS: src = c->sk; cnt = c->M; break;
+        case DEBWT_ARR_DISTINCT_KEYS: src = c->dk.p; cnt = c->D; break;
+        case DEBWT_ARR_RED: src = c->red.p; cnt = c->R; need = ST_CLASSIFIED; break;
+        case DEBWT_ARR_SP_SYMBOLS: src = c->spsym.p; cnt = c->S; esz = 1; need = ST_SP; break;
+        case DEBWT_ARR_BLUE: src = c->blue.p; cnt = c->B; need = ST_SP; break;
+        case DEBWT_ARR_BLUE_BOUND:
+        case DEBWT_ARR_CASE3_BOUND: {
+            need = ST_CLASSIFIED;
+            if (c->stage < need) return DEBWT_ESTATE;
+            std::vector<u32> fr(c->Q), bs(c->Q), j0(c->Q);
+            std::vector<uint64_t> sprow(c->NS);
+            if (c->Q) {
+                HIPCHK(c, hipMemcpy(fr.data(), c->mi_freq.p, c->Q * 4, hipMemcpyDeviceToHost));
+                HIPCHK(c, hipMemcpy(bs.data(), c->bstart.p, c->Q * 4, hipMemcpyDeviceToHost));
+                HIPCHK(c, hipMemcpy(j0.data(), c->mi_j0.p, c->Q * 4, hipMemcpyDeviceToHost));
+            }
+            HIPCHK(c, hipMemcpy(sprow.data(), c->sprow.p, c->NS * 8, hipMemcpyDeviceToHost));
+            if (which == DEBWT_ARR_BLUE_BOUND) {
+                host.resize(c->Q);
+                for (u64 q = 0; q < c->Q; q++) host[q] = (uint64_t)bs[q] + fr[q] - 1;   // src/INandOut.c:359-361
+            } else {
+                // rows: instance j sits below every special suffix whose rank among the instances is <= j
+                std::vector<uint64_t> mrank(c->NS);
+                for (u64 s = 0; s < c->NS; s++) mrank[s] = sprow[s] - s;
+                host.resize(2 * c->Q);
+                for (u64 q = 0; q < c->Q; q++) {
+                    uint64_t before = std::upper_bound(mrank.begin(), mrank.end(), (uint64_t)j0[q]) - mrank.begin();
+                    host[2 * q] = j0[q] + before;                                        // src/INandOut.c:349-352
+                    host[2 * q + 1] = host[2 * q] + fr[q] - 1;
+                }
+            }
+            cnt = host.size();
+            *count = cnt;
+            if (dst) memcpy(dst, host.data(), (size_t)std::min(cnt, capacity) * 8);
+            return DEBWT_OK;
+        }
+        case DEBWT_ARR_ROW_SYMBOLS: {
+            if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
+            ENSURE(c, c->rowsym, c->n + 64);
+            run_assemble(c, c->rowsym.as<u8>());
+            int rc = sync_check(c);
+            if (rc) return rc;
+            src = c->rowsym.p; cnt = c->n; esz = 1; need = ST_ASSEMBLED;
+            break;
+        }
+        default: return DEBWT_EINVAL;
+    }
+    if (c->stage < need) return DEBWT_ESTATE;
+    *count = cnt;
+    uint64_t ncopy = std::min(cnt, capacity);
+    if (dst && ncopy) {
+        HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)ncopy * esz, hipMemcpyDeviceToHost, c->stream));
+        return sync_check(c);
+    }
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_kmer_count_sorted(debwt_ctx *c, uint64_t *kmers, uint64_t *counts, uint64_t capacity,
+                                       uint64_t *distinct) {
+    if (!c || !distinct) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int k = c->cfg.k;
+    if (c->n <= c->nrec * (u64)k) return DEBWT_EINVAL;
+    const u64 Mk = c->n - c->nrec * (u64)k;
+    c->stage = ST_LOADED;   // the pipeline buffers are reused
+    int rc;
+    k_extract_keys<<<grid_for(c->n, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+        c->text.as<u64>(), c->sepbits.as<u64>(), c->sep.as<u64>(), c->nrec, c->n, k, 1, c->keysA.as<u64>());
+    u64 *sorted = nullptr;
+    if ((rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), Mk, 2 * k, &sorted, false))) return rc;
+    KmerInfoF f{sorted, Mk, k, c->dk.as<u64>(), c->dstart.as<u32>()};
+    if ((rc = cp_count(c, f, Mk, cp_area(c, 0), 0))) return rc;
+    if ((rc = cp_emit(c, f, Mk, cp_area(c, 0)))) return rc;
+    if ((rc = sync_check(c))) return rc;
+    u64 D = c->h_scalars[0];
+    *distinct = D;
+    u64 ncopy = std::min<u64>(D, capacity);
+    if (kmers && ncopy) HIPCHK(c, hipMemcpy(kmers, c->dk.p, ncopy * 8, hipMemcpyDeviceToHost));
+    if (counts && ncopy) {
+        std::vector<u32> first(D);
+        HIPCHK(c, hipMemcpy(first.data(), c->dstart.p, D * 4, hipMemcpyDeviceToHost));
+        for (u64 i = 0; i < ncopy; i++) counts[i] = (i + 1 < D ? first[i + 1] : (u32)Mk) - first[i];
+    }
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_radix_sort_u64(debwt_ctx *c, uint64_t *d_keys, uint64_t *d_tmp, uint64_t count, int key_bits,
+                                    float *ms_per_pass) {
+    if (!c || !d_keys || !d_tmp || key_bits < 1 || key_bits > 64) return DEBWT_EINVAL;
+    if (count >= 0xFFFFFFF0ull) return DEBWT_ERANGE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    RadixWorkspace ws = radix_ws(c);
+    hipError_t e = hipSuccess;
+    int np = 0;
+    u64 *res = radix_sort_u64(c->stream, (u64 *)d_keys, (u64 *)d_tmp, count, key_bits, ws, c->cfg.sort_algo,
+                              ms_per_pass ? &c->ev_pass[0][0] : nullptr, 16, &np, &e);
+    if (e != hipSuccess) { c->err = hipGetErrorString(e); return DEBWT_EDEVICE; }
+    if (res != (u64 *)d_keys)
+        HIPCHK(c, hipMemcpyAsync(d_keys, res, count * 8, hipMemcpyDeviceToDevice, c->stream));
+    int rc = sync_check(c);
+    if (rc) return rc;
+    if (ms_per_pass) {
+        float sum = 0.f;
+        for (int i = 0; i < np; i++) { float t = 0.f; (void)hipEventElapsedTime(&t, c->ev_pass[i][0], c->ev_pass[i][1]); sum += t; }
+        *ms_per_pass = np ? sum / np : 0.f;
+    }
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_verify_inverse(const uint64_t *bwt, uint64_t n, const uint64_t *hash_rows, uint64_t nrec,
+                                    uint64_t dollar_row, uint8_t *sym_out) {
+    // LF(i) = C[c] + occ(c, i); '#' rows map in order to rows n-nrec.., '$' row to row n-1
+    // (src/LFsearch.c:49-166, src/insertCase3.c:141-194)
+    if (!bwt || !sym_out || n < 2 || nrec < 1 || dollar_row >= n) return DEBWT_EINVAL;
+    std::vector<uint8_t> L(n);
+    for (uint64_t j = 0; j < n; j++) L[j] = (uint8_t)((bwt[j >> 5] >> ((31 - (j & 31)) << 1)) & 3);
+    for (uint64_t h = 0; h + 1 < nrec; h++) { if (hash_rows[h] >= n) return DEBWT_EINVAL; L[hash_rows[h]] = 4; }
+    L[dollar_row] = 5;
+    uint64_t C[7] = {0}, cnt[6] = {0}, seen[6] = {0};
+    for (uint64_t i = 0; i < n; i++) cnt[L[i]]++;
+    for (int s = 0; s < 6; s++) C[s + 1] = C[s] + cnt[s];
+    std::vector<uint64_t> lf(n);
+    for (uint64_t i = 0; i < n; i++) lf[i] = C[L[i]] + seen[L[i]]++;
+    uint64_t row = n - 1;
+    sym_out[n - 1] = 5;
+    for (uint64_t p = n - 1; p > 0; p--) {
+        uint8_t s = L[row];
+        if (s == 5) return DEBWT_EINTERNAL;
+        sym_out[p - 1] = s;
+        row = lf[row];
+    }
+    return L[row] == 5 ? DEBWT_OK : DEBWT_EINTERNAL;
+}

@@ -1,0 +1,497 @@
+// stage_kernels.h -- device kernels of the deBWT path other than the radix sort (single TU: included
+// by debwt_hip.hip only).  Notation follows SURVEY 8: K = k-1 node length, key = node<<2 | pred.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// chunked two-pass scan/compaction: every functor F has
+//     u32  count(u64 i)                 items produced at index i (may write side outputs)
+//     u32  recount(u64 i)               the same value again in the emit pass (may read what count stored)
+//     void emit(u64 i, u32 off, u32 c)  called for EVERY index with its exclusive prefix
+// Chunks are contiguous so output order = input order (deterministic, no atomics).
+
+#define CP_MAXCHUNKS 2048
+
+template <class F>
+__global__ __launch_bounds__(DEBWT_BLOCK) void cp_count_kernel(F f, u64 n, u64 chunk, u32 *__restrict__ counts) {
+    __shared__ u32 red[DEBWT_WAVES];
+    u64 beg = (u64)blockIdx.x * chunk;
+    u64 end = beg + chunk < n ? beg + chunk : n;
+    u32 local = 0;
+    for (u64 i = beg + threadIdx.x; i < end; i += DEBWT_BLOCK) local += f.count(i);
+    u32 incl = wave_scan_incl(local);
+    if (lane_id() == 63) red[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 s = 0;
+        for (int w = 0; w < DEBWT_WAVES; w++) s += red[w];
+        counts[blockIdx.x] = s;
+    }
+}
+
+// exclusive scan of counts[0..m) in place (m <= CP_MAXCHUNKS), total to *total; one workgroup
+__global__ __launch_bounds__(1024) void cp_scan_kernel(u32 *__restrict__ counts, u32 m, u32 *__restrict__ total) {
+    __shared__ u32 wsum[16];
+    u32 per = (m + 1023u) / 1024u;
+    u32 beg = threadIdx.x * per, end = beg + per < m ? beg + per : m;
+    u32 s = 0;
+    for (u32 i = beg; i < end; i++) s += counts[i];
+    u32 incl = wave_scan_incl(s);
+    u32 w = threadIdx.x >> 6;
+    if (lane_id() == 63) wsum[w] = incl;
+    __syncthreads();
+    u32 base = 0, all = 0;
+    for (u32 i = 0; i < 16; i++) { if (i < w) base += wsum[i]; all += wsum[i]; }
+    u32 run = base + incl - s;
+    for (u32 i = beg; i < end; i++) { u32 c = counts[i]; counts[i] = run; run += c; }
+    if (threadIdx.x == 0) *total = all;
+}
+
+template <class F>
+__global__ __launch_bounds__(DEBWT_BLOCK) void cp_emit_kernel(F f, u64 n, u64 chunk, const u32 *__restrict__ offsets) {
+    __shared__ u32 tmp[8];
+    u64 beg = (u64)blockIdx.x * chunk;
+    u64 end = beg + chunk < n ? beg + chunk : n;
+    u32 base = offsets[blockIdx.x];
+    for (u64 tile = beg; tile < end; tile += DEBWT_BLOCK) {
+        u64 i = tile + threadIdx.x;
+        u32 c = i < end ? f.recount(i) : 0;
+        u32 tot;
+        u32 off = block_scan_excl(c, tmp, &tot);
+        if (i < end) f.emit(i, base + off, c);
+        base += tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// text preparation
+
+__global__ void k_set_sepbits(const u64 *__restrict__ sep, u64 nrec, u64 *__restrict__ bits) {
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrec) atomicOr(&bits[sep[r] >> 6], 1ull << (sep[r] & 63));
+}
+
+// One key per position whose L-symbol window holds no separator, compacted by record:
+//   mode 0 (L = K):  key = node << 2 | pred     node instances (pipeline)
+//   mode 1 (L = k):  key = k-mer                edge instances (stand-alone k-mer count)
+// Replaces the Jellyfish enumeration (src/kmercounting.sh:8) -- k-mers never span records.
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_extract_keys(const u64 *__restrict__ text,
+                                                               const u64 *__restrict__ sepbits,
+                                                               const u64 *__restrict__ sep, u64 nrec, u64 n, int L,
+                                                               int mode, u64 *__restrict__ keys) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 sw = sep_window(sepbits, i);
+    if (sw & ((1ull << L) - 1ull)) return;
+    u64 rho = lower_bound_dev<u64>(sep, 0, nrec, i);          // separators before i
+    u64 win = text_window(text, i) >> (64 - 2 * L);
+    u64 key = win;
+    if (mode == 0) {
+        u32 pred = i ? text_symbol(text, i - 1) : 3u;          // 'T' stands at separators: fake pred 3
+        key = (win << 2) | pred;
+    }
+    keys[i - rho * (u64)L] = key;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// run-length encoding of the sorted keys (kmerInfo analogue, src/mySort.c:193-195) + case-2 symbols
+
+struct RleF {
+    const u64 *sk; u64 *dk; u32 *dstart; u8 *mchar;
+    __device__ u32 count(u64 j) const {
+        u64 k = sk[j];
+        if (mchar) mchar[j] = (u8)(k & 3);                     // bwtSingle by row (src/INandOut.c:367-395)
+        return (j == 0 || sk[j - 1] != k) ? 1u : 0u;
+    }
+    __device__ u32 recount(u64 j) const { return (j == 0 || sk[j - 1] != sk[j]) ? 1u : 0u; }
+    __device__ void emit(u64 j, u32 off, u32 c) const {
+        if (c) { dk[off] = sk[j]; dstart[off] = (u32)j; }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// node classification over the distinct keys (mergeKmer, src/INandOut.c:258-346)
+
+struct ClassifyCommon {
+    const u64 *dk; const u32 *dstart; u64 D; u64 M;
+    const u64 *head_keys; u64 nrec;
+    // instances of distinct key e that are real edges (record-start instances carry the fake pred 3)
+    __device__ u32 real_count(u64 e) const {
+        u64 k = dk[e];
+        u32 cnt = (e + 1 < D ? dstart[e + 1] : (u32)M) - dstart[e];
+        if ((k & 3) == 3) {
+            u64 lo = lower_bound_dev<u64>(head_keys, 0, nrec, k);
+            u64 hi = upper_bound_dev<u64>(head_keys, lo, nrec, k);
+            cnt -= (u32)(hi - lo);
+        }
+        return cnt;
+    }
+    __device__ bool is_head(u64 node) const {
+        u64 k = (node << 2) | 3ull;
+        u64 lo = lower_bound_dev<u64>(head_keys, 0, nrec, k);
+        return lo < nrec && head_keys[lo] == k;
+    }
+};
+
+// multi-in nodes: >= 2 distinct real predecessors or a record-start occurrence (src/INandOut.c:282-343)
+struct MultiInF {
+    ClassifyCommon c;
+    u64 *mi_fact; u32 *mi_j0; u32 *mi_freq;
+    __device__ bool eval(u64 e, u32 *freq) const {
+        u64 node = c.dk[e] >> 2;
+        if (e && (c.dk[e - 1] >> 2) == node) return false;
+        u32 preds = 0;
+        u64 f = e;
+        for (; f < c.D && f < e + 4 && (c.dk[f] >> 2) == node; f++)
+            if (c.real_count(f)) preds |= 1u << (c.dk[f] & 3);
+        *freq = (f < c.D ? c.dstart[f] : (u32)c.M) - c.dstart[e];
+        return __popc(preds) >= 2 || c.is_head(node);
+    }
+    __device__ u32 count(u64 e) const { u32 fr; return eval(e, &fr) ? 1u : 0u; }
+    __device__ u32 recount(u64 e) const { return count(e); }
+    __device__ void emit(u64 e, u32 off, u32 cnt) const {
+        if (!cnt) return;
+        u32 fr; eval(e, &fr);
+        mi_fact[off] = ((c.dk[e] >> 2) << 2) | 2ull;
+        mi_j0[off] = c.dstart[e];
+        mi_freq[off] = fr;
+    }
+};
+
+// multi-out facts: within the group of keys sharing the (K-1)-symbol node prefix W, every pred c with
+// >= 2 distinct last symbols d among real keys (W.d, c) makes node c.W multi-out
+// (out-degree > 1, src/INandOut.c:271-281, read off the same sorted edge list)
+struct MultiOutF {
+    ClassifyCommon c;
+    int K;
+    u64 *mo_fact;
+    __device__ u32 eval(u64 e, u64 *facts) const {
+        u64 W = c.dk[e] >> 4;
+        if (e && (c.dk[e - 1] >> 4) == W) return 0;
+        u32 succ[4] = {0, 0, 0, 0};
+        for (u64 f = e; f < c.D && f < e + 16 && (c.dk[f] >> 4) == W; f++) {
+            if (!c.real_count(f)) continue;
+            u64 k = c.dk[f];
+            succ[k & 3] |= 1u << ((k >> 2) & 3);
+        }
+        u32 m = 0;
+        for (u32 p = 0; p < 4; p++)
+            if (__popc(succ[p]) >= 2) {
+                if (facts) facts[m] = ((((u64)p << (2 * (K - 1))) | W) << 2) | 1ull;
+                m++;
+            }
+        return m;
+    }
+    __device__ u32 count(u64 e) const { return eval(e, nullptr); }
+    __device__ u32 recount(u64 e) const { return count(e); }
+    __device__ void emit(u64 e, u32 off, u32 cnt) const {
+        if (!cnt) return;
+        u64 facts[4];
+        eval(e, facts);
+        for (u32 m = 0; m < cnt; m++) mo_fact[off + m] = facts[m];
+    }
+};
+
+// red table: sorted fact list -> one entry per node, node<<2 | multiin<<1 | multiout
+// (redSeq analogue, src/INandOut.c:396-412).  Facts of one node sort as (X|1)...(X|1)(X|2).
+struct RedUniqueF {
+    const u64 *facts; u64 nf; u64 *red;
+    __device__ u32 count(u64 e) const { return (e + 1 == nf || (facts[e + 1] >> 2) != (facts[e] >> 2)) ? 1u : 0u; }
+    __device__ u32 recount(u64 e) const { return count(e); }
+    __device__ void emit(u64 e, u32 off, u32 c) const {
+        if (!c) return;
+        u64 f = facts[e];
+        u32 fl = (u32)(f & 3);
+        if (fl == 2 && e && (facts[e - 1] >> 2) == (f >> 2)) fl = 3;
+        red[off] = ((f >> 2) << 2) | fl;
+    }
+};
+// rank of every multi-in red entry among the multi-in entries = its block id
+struct RedBlockF {
+    const u64 *red; u32 *red_q;
+    __device__ u32 count(u64 r) const { return (u32)(red[r] >> 1) & 1u; }
+    __device__ u32 recount(u64 r) const { return count(r); }
+    __device__ void emit(u64 r, u32 off, u32 c) const { red_q[r] = c ? off : 0xFFFFFFFFu; }
+};
+// exclusive scan of block sizes -> first blue slot of each block (blueBound analogue)
+struct BlockStartF {
+    const u32 *mi_freq; u32 *bstart;
+    __device__ u32 count(u64 q) const { return mi_freq[q]; }
+    __device__ u32 recount(u64 q) const { return count(q); }
+    __device__ void emit(u64 q, u32 off, u32) const { bstart[q] = off; }
+};
+struct LargeBlockF {
+    const u32 *mi_freq; u32 cap; u32 *large_q;
+    __device__ u32 count(u64 q) const { return mi_freq[q] > cap ? 1u : 0u; }
+    __device__ u32 recount(u64 q) const { return count(q); }
+    __device__ void emit(u64 q, u32 off, u32 c) const { if (c) large_q[off] = (u32)q; }
+};
+
+// prefix index over the red table (blackTable analogue, src/generateSP.c:53-59, 2^p bins instead of 4^10)
+__global__ void k_build_pidx(const u64 *__restrict__ red, u64 R, int K, int p, u32 *__restrict__ pidx) {
+    u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > (1ull << p)) return;
+    u64 key = (h << (2 * K - p)) << 2;
+    pidx[h] = (h == (1ull << p)) ? (u32)R : (u32)lower_bound_dev<u64>(red, 0, R, key);
+}
+
+__device__ __forceinline__ u32 red_lookup(const u64 *__restrict__ red, const u32 *__restrict__ pidx, int K, int p,
+                                          u64 node, u32 *flags) {
+    u64 h = node >> (2 * K - p);
+    u32 lo = pidx[h], hi = pidx[h + 1];
+    while (lo < hi) {
+        u32 mid = (lo + hi) >> 1;
+        u64 v = red[mid] >> 2;
+        if (v < node) lo = mid + 1; else hi = mid;
+    }
+    if (lo < pidx[h + 1]) {
+        u64 v = red[lo];
+        if ((v >> 2) == node) { *flags = (u32)(v & 3); return lo; }
+    }
+    *flags = 0;
+    return 0xFFFFFFFFu;
+}
+
+// rows of the special suffixes: rank among the node instances + own rank (src/INandOut.c:419-439)
+__global__ void k_special_rows(const u64 *__restrict__ sk, u64 M, const u64 *__restrict__ spkey, u64 NS,
+                               u64 *__restrict__ sprow) {
+    u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= NS) return;
+    sprow[s] = s + upper_bound_dev<u64>(sk, 0, M, (spkey[s] << 2) | 3ull);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SP code + blue entries (multiGenerateSP, src/generateSP.c:534-683)
+
+struct SpF {
+    const u64 *text; const u64 *sepbits; u64 n; int K;
+    const u64 *red; const u32 *pidx; int p; const u32 *red_q;
+    const u64 *branch; u64 nbranch;
+    u8 *pflag;                 // bit0 multi-out, bit1 multi-in, per position
+    u8 *spsym;                 // SP symbols 0..5
+    const u32 *bstart; u32 *cursor; u64 *blue;
+
+    __device__ u32 count(u64 i) const {
+        u64 sw = sep_window(sepbits, i);
+        u32 fl = 0;
+        if (sw & ((1ull << K) - 1ull)) {
+            // special module: multi-out iff listed in specialBranch (src/generateSP.c:612-624)
+            u64 lo = lower_bound_dev<u64>(branch, 0, nbranch, i);
+            if (lo < nbranch && branch[lo] == i) fl = 1;
+        } else {
+            u64 node = text_window(text, i) >> (64 - 2 * K);
+            red_lookup(red, pidx, K, p, node, &fl);
+        }
+        pflag[i] = (u8)fl;
+        return fl & 1u;
+    }
+    __device__ u32 recount(u64 i) const { return pflag[i] & 1u; }
+    __device__ void emit(u64 i, u32 off, u32 c) const {
+        u32 fl = pflag[i];
+        if (c) {
+            // the symbol K ahead; the separator itself when it follows the window (:626-660)
+            u64 j = i + (u64)K;
+            u8 s;
+            if (sep_at(sepbits, j)) s = (j == n - 1) ? 5 : 4; else s = (u8)text_symbol(text, j);
+            spsym[off] = s;
+        }
+        if (fl & 2u) {
+            u64 node = text_window(text, i) >> (64 - 2 * K);
+            u32 f2;
+            u32 r = red_lookup(red, pidx, K, p, node, &f2);
+            u32 q = red_q[r];
+            u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
+            u32 slot = atomicAdd(&cursor[q], 1u);
+            blue[(u64)bstart[q] + slot] = pred | ((u64)off << 4);          // src/generateSP.c:666-672
+        }
+    }
+};
+
+// SP symbols -> 4 bits per symbol, 16 per word, symbol s at bits 60-4*(s&15): integer order of a
+// window = order of the symbol string under A<C<G<T<#<$
+__global__ void k_pack_sp(const u8 *__restrict__ spsym, u64 S, u64 nwords, u64 *__restrict__ spn) {
+    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    u64 v = 0;
+    u64 base = w << 4;
+    for (u32 t = 0; t < 16; t++) {
+        u64 s = base + t;
+        u64 c = s < S ? (u64)spsym[s] : 0ull;
+        v |= c << (60 - 4 * t);
+    }
+    spn[w] = v;
+}
+
+__device__ __forceinline__ u64 sp_window(const u64 *__restrict__ spn, u64 s) {
+    u64 w = s >> 4;
+    u32 sh = (u32)(s & 15) << 2;
+    u64 a = spn[w];
+    if (sh == 0) return a;
+    return (a << sh) | (spn[w + 1] >> (64 - sh));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// blue-block sort (sortBlue/myQsort/cmpSP, src/sortBlue.c:109-280)
+
+// a < b by SP suffix beyond the first window (entries are distinct SP positions of one node: the
+// suffixes differ before the unique '$' that ends the SP code)
+__device__ __forceinline__ bool sp_less_deep(const u64 *__restrict__ spn, u64 S, u64 ea, u64 eb) {
+    u64 a = (ea >> 4) + 16, b = (eb >> 4) + 16;
+    while (a < S && b < S) {
+        u64 wa = sp_window(spn, a), wb = sp_window(spn, b);
+        if (wa != wb) return wa < wb;
+        a += 16; b += 16;
+    }
+    return a > b;   // not reached on consistent input
+}
+
+#define BLUE_LDS_CAP 2048
+
+// one workgroup per block of <= BLUE_LDS_CAP entries: bitonic sort in LDS on (first window, entry),
+// deeper windows fetched only on ties; writes the block's BWT symbols to their rows in mchar
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_sort_lds(u64 *__restrict__ blue, const u32 *__restrict__ bstart,
+                                                                const u32 *__restrict__ mi_freq,
+                                                                const u32 *__restrict__ mi_j0, u32 Q,
+                                                                const u64 *__restrict__ spn, u64 S,
+                                                                u8 *__restrict__ mchar) {
+    __shared__ u64 k0[BLUE_LDS_CAP];
+    __shared__ u64 en[BLUE_LDS_CAP];
+    __shared__ u32 seen;
+    for (u32 q = blockIdx.x; q < Q; q += gridDim.x) {
+        u32 m = mi_freq[q];
+        if (m > BLUE_LDS_CAP) continue;
+        u64 b0 = bstart[q];
+        u32 j0 = mi_j0[q];
+        if (m == 1) {
+            if (threadIdx.x == 0) mchar[j0] = (u8)(blue[b0] & 15);
+            continue;
+        }
+        if (threadIdx.x == 0) seen = 0;
+        __syncthreads();
+        u32 P = 2;
+        while (P < m) P <<= 1;
+        u32 mask = 0;
+        for (u32 t = threadIdx.x; t < P; t += DEBWT_BLOCK) {
+            if (t < m) {
+                u64 e = blue[b0 + t];
+                en[t] = e;
+                k0[t] = sp_window(spn, e >> 4);
+                mask |= 1u << (e & 15);
+            } else {
+                en[t] = ~0ull; k0[t] = ~0ull;
+            }
+        }
+        if (mask) atomicOr(&seen, mask);
+        __syncthreads();
+        u32 sm = seen;
+        if (sm & (sm - 1)) {                                  // >= 2 distinct symbols: sort (src/sortBlue.c:192-219)
+            for (u32 kk = 2; kk <= P; kk <<= 1) {
+                for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+                    for (u32 t = threadIdx.x; t < (P >> 1); t += DEBWT_BLOCK) {
+                        u32 i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+                        u32 l = i | jj;
+                        bool up = (i & kk) == 0;
+                        u64 ka = k0[i], kb = k0[l], ea = en[i], eb = en[l];
+                        bool lt;   // element l sorts before element i
+                        if (ka != kb) lt = kb < ka;
+                        else if (ea == ~0ull || eb == ~0ull) lt = eb < ea;
+                        else lt = sp_less_deep(spn, S, eb, ea);
+                        if (lt == up) { k0[i] = kb; k0[l] = ka; en[i] = eb; en[l] = ea; }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        for (u32 t = threadIdx.x; t < m; t += DEBWT_BLOCK) {
+            u64 e = en[t];
+            blue[b0 + t] = e;
+            mchar[j0 + t] = (u8)(e & 15);
+        }
+        __syncthreads();
+    }
+}
+
+// large blocks: bitonic network in global memory, one launch per compare-exchange distance
+__global__ void k_large_load(const u64 *__restrict__ blue, u64 b0, u32 m, u64 P, const u64 *__restrict__ spn,
+                             u64 *__restrict__ k0, u64 *__restrict__ en) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P) return;
+    if (t < m) { u64 e = blue[b0 + t]; en[t] = e; k0[t] = sp_window(spn, e >> 4); }
+    else { en[t] = ~0ull; k0[t] = ~0ull; }
+}
+__global__ void k_large_step(u64 *__restrict__ k0, u64 *__restrict__ en, u64 P, u64 kk, u64 jj,
+                             const u64 *__restrict__ spn, u64 S) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (P >> 1)) return;
+    u64 i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+    u64 l = i | jj;
+    bool up = (i & kk) == 0;
+    u64 ka = k0[i], kb = k0[l], ea = en[i], eb = en[l];
+    bool lt;
+    if (ka != kb) lt = kb < ka;
+    else if (ea == ~0ull || eb == ~0ull) lt = eb < ea;
+    else lt = sp_less_deep(spn, S, eb, ea);
+    if (lt == up) { k0[i] = kb; k0[l] = ka; en[i] = eb; en[l] = ea; }
+}
+__global__ void k_large_store(u64 *__restrict__ blue, u64 b0, u32 m, u32 j0, const u64 *__restrict__ en,
+                              u8 *__restrict__ mchar) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    u64 e = en[t];
+    blue[b0 + t] = e;
+    mchar[(u64)j0 + t] = (u8)(e & 15);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// assembly (insertCase3, src/insertCase3.c:56-104): rows = node-instance symbols in key order with the
+// special suffixes merged in at their rows; 2 bits per row, '#'/'$' rows stored as 3 and recorded
+
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_assemble(const u8 *__restrict__ mchar, u64 M,
+                                                           const u64 *__restrict__ sprow,
+                                                           const u8 *__restrict__ spchr, u64 NS, u64 n,
+                                                           u64 *__restrict__ bwt, u32 *__restrict__ hmask,
+                                                           u64 *__restrict__ dollar_row, u8 *__restrict__ rowsym) {
+    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 nw = (n + 31) >> 5;
+    if (w >= nw) return;
+    u64 r0 = w << 5;
+    u64 s = lower_bound_dev<u64>(sprow, 0, NS, r0);            // special rows before r0
+    u64 j = r0 - s;
+    u64 next_special = s < NS ? sprow[s] : ~0ull;
+    u64 word = 0;
+    u32 hm = 0;
+    u32 lim = (n - r0) < 32 ? (u32)(n - r0) : 32u;
+    for (u32 t = 0; t < lim; t++) {
+        u64 r = r0 + t;
+        u32 c;
+        if (r == next_special) { c = spchr[s]; s++; next_special = s < NS ? sprow[s] : ~0ull; }
+        else c = mchar[j++];
+        if (rowsym) rowsym[r] = (u8)c;
+        if (c == 4) { hm |= 1u << t; c = 3; }
+        else if (c == 5) { *dollar_row = r; c = 3; }
+        word |= (u64)c << ((31 - t) << 1);
+    }
+    (void)M;
+    bwt[w] = word;
+    hmask[w] = hm;
+}
+struct HashRowsF {
+    const u32 *hmask; u64 *hash_rows;
+    __device__ u32 count(u64 w) const { return (u32)__popc(hmask[w]); }
+    __device__ u32 recount(u64 w) const { return count(w); }
+    __device__ void emit(u64 w, u32 off, u32 c) const {
+        if (!c) return;
+        u32 m = hmask[w];
+        while (m) { u32 t = __ffs(m) - 1; m &= m - 1; hash_rows[off++] = (w << 5) + t; }
+    }
+};
+
+// counts of equal adjacent keys -> (kmer left-aligned, count) pairs for debwt_kmer_count_sorted
+struct KmerInfoF {
+    const u64 *sk; u64 M; int k; u64 *kmers; u32 *first;
+    __device__ u32 count(u64 j) const { return (j == 0 || sk[j - 1] != sk[j]) ? 1u : 0u; }
+    __device__ u32 recount(u64 j) const { return count(j); }
+    __device__ void emit(u64 j, u32 off, u32 c) const {
+        if (c) { kmers[off] = sk[j] << (64 - 2 * k); first[off] = (u32)j; }
+    }
+};

@@ -1,0 +1,150 @@
+/*
+ * debwt_hip.h -- C ABI of libdebwt_hip.so, the MI355X (gfx950) implementation of deBWT's
+ * de Bruijn branch-encode suffix sort and BWT assembly path.
+ *
+ * The reference has no plugin/FFI interface: its stages are C functions that pass state through
+ * ~30 globals and temp files and exit(1) on error (/root/reference/src/main.h:1-8,
+ * src/main.c:79-160).  Each entry point below replaces one of those stage calls; the comment on
+ * each names the call it replaces.  Conventions that differ from the reference on purpose:
+ *   - an opaque context instead of globals; explicit caller-owned buffers with sizes;
+ *   - every function returns int: 0 = ok, negative = DEBWT_E* (never exits, never prints);
+ *   - no temp files, no Jellyfish: k-mers are enumerated from the packed text on the GPU;
+ *   - functions are not re-entrant on one context; one host thread drives one context/GPU.
+ *
+ * Data formats are the reference's: text 2 bits/base A0 C1 G2 T3, 32 bases per
+ * uint64_t, base j at bit 2*(31-(j&31)) of word j>>5, 'T' stored at every separator and 32 'T'
+ * of padding after the end (src/collect#$.c:61-90); BWT output in the same packing with '#'/'$'
+ * rows stored as 3 and listed separately (src/insertCase3.c:75-97,115-131).
+ */
+#ifndef DEBWT_HIP_H
+#define DEBWT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEBWT_OK 0
+#define DEBWT_EINVAL (-1)   /* bad argument (k outside 12..32, n too small, NULL pointer, ...) */
+#define DEBWT_ENOMEM (-2)   /* device or host allocation failed */
+#define DEBWT_EDEVICE (-3)  /* HIP runtime error (see debwt_last_error) */
+#define DEBWT_ESTATE (-4)   /* stage called out of order */
+#define DEBWT_ERANGE (-5)   /* input exceeds a capacity of this build (n_main or S >= 2^32) */
+#define DEBWT_EINTERNAL (-6)/* consistency check failed */
+
+typedef struct debwt_ctx debwt_ctx;
+
+typedef struct {
+    int k;          /* edge length, KMER_LENGTH_PlusOne, 12..32 (src/main.c:41-47); node = k-1 */
+    int device;     /* HIP device ordinal */
+    int sort_algo;  /* 0 = default; 1 = histogram+scatter LSD passes; 2 = single-sweep look-back passes */
+    int reserved;
+} debwt_config;
+
+/* counters of one run; the first block mirrors the reference's globals so that runs can be
+ * compared stage by stage (src/generateSP.c:28-31, src/collect#$.c:59) */
+typedef struct {
+    uint64_t n;                 /* BWTLEN */
+    uint64_t nrec;              /* countRead */
+    uint64_t red_capacity;      /* redCapacity */
+    uint64_t blue_capacity;     /* blueCapacity */
+    uint64_t blue_bound_num;    /* blueBoundNum */
+    uint64_t case3num;          /* case3num */
+    uint64_t sp_len;            /* SP symbols (spCodeLen - 32) */
+    uint64_t special_branch_num;/* specialBranchNum */
+    uint64_t n_main;            /* node instances sorted (n - nrec*(k-1)) */
+    uint64_t distinct_keys;     /* distinct (node,pred) keys incl. record-start instances */
+    uint64_t blue_large_blocks; /* blocks sorted by the global-memory path */
+    uint64_t blue_max_block;
+    /* device time of the last run, milliseconds (hipEvents on the context's stream) */
+    float ms_extract, ms_sort, ms_classify, ms_sp, ms_blue, ms_assemble, ms_total, ms_host_special;
+    /* dominant kernel (one radix scatter pass): launches and total ms in the last run */
+    uint32_t radix_pass_launches;
+    float radix_pass_ms;
+    uint64_t radix_pass_keys;   /* keys moved per launch */
+} debwt_stats;
+
+int debwt_create(const debwt_config *cfg, debwt_ctx **out);
+void debwt_destroy(debwt_ctx *ctx);
+const char *debwt_strerror(int code);
+const char *debwt_last_error(const debwt_ctx *ctx);   /* text of the last HIP/internal failure */
+
+/* Replaces `collect`'s text hand-over (src/collect#$.c:61-90,100-113: files `reference`,
+ * `specialSA`).  packed: ceil((n+32)/32) words in the format above (host memory, must stay valid
+ * until the context is destroyed or the next load); sep: the nrec separator positions ascending,
+ * sep[nrec-1] == n-1 ('$').  Copies the text to HBM and sizes the workspace. */
+int debwt_load_text(debwt_ctx *ctx, const uint64_t *packed, uint64_t n, const uint64_t *sep, uint64_t nrec);
+
+/* Convenience for hosts that hold ASCII: records concatenated without separators, upper or
+ * lower case ACGT only (src/main.c:18-23), every record > 32 bases (src/collect#$.c:41-45).
+ * Packs on the host, then behaves like debwt_load_text (the packed copy is owned by ctx). */
+int debwt_load_ascii(debwt_ctx *ctx, const char *seq, const uint64_t *reclen, uint64_t nrec);
+
+/* ---- stage entry points, to be called in this order after a load ------------------------------ */
+
+/* Replaces kmercounting.sh + mySort (src/main.c:70,83; src/mySort.c:26-201) and getKmer
+ * (src/getKmer.c:12-49): enumerates every node instance of the text as a key
+ * (node << 2 | predecessor base) -- the edge list grouped by its (k-1)-suffix, i.e. getKmer's
+ * multiIn{A,C,G,T} view -- radix-sorts the keys and run-length encodes them. */
+int debwt_kmer_sort_rle(debwt_ctx *ctx);
+/* Replaces generateBlocks/mergeKmer (src/INandOut.c:13-89,159-943) plus the special-region
+ * tables of collect (src/collect#$.c:118-157,348-602): node flags, red table, block bounds,
+ * case-2 characters, rows of the special suffixes. */
+int debwt_classify(debwt_ctx *ctx);
+/* Replaces generateSP (src/generateSP.c:19-272): SP code and blue entries. */
+int debwt_sp_generate(debwt_ctx *ctx);
+/* Replaces sortBlue (src/sortBlue.c:10-57). */
+int debwt_blue_sort(debwt_ctx *ctx);
+/* Replaces insertCase3 up to the file writes (src/insertCase3.c:13-104). */
+int debwt_bwt_assemble(debwt_ctx *ctx);
+
+/* All five stages back to back (src/main.c:83-149). */
+int debwt_build(debwt_ctx *ctx);
+
+/* Copies the result to host memory: bwt ceil(n/32) words, hash_rows nrec-1 rows ascending,
+ * dollar_row 1 row -- the contents of OUT, OUT.#, OUT.$ (src/insertCase3.c:115-131). */
+int debwt_fetch_bwt(debwt_ctx *ctx, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row);
+/* Device address of the packed BWT words of the last run (for callers that keep it in HBM). */
+int debwt_bwt_device_ptr(debwt_ctx *ctx, const uint64_t **d_words);
+
+int debwt_get_stats(const debwt_ctx *ctx, debwt_stats *out);
+
+/* ---- intermediates, for stage-by-stage parity ---------------------------------- */
+typedef enum {
+    DEBWT_ARR_SORTED_KEYS = 1, /* u64 x n_main: (node<<2|pred) ascending                              */
+    DEBWT_ARR_DISTINCT_KEYS,   /* u64 x distinct_keys                                                 */
+    DEBWT_ARR_RED,             /* u64 x red_capacity: node<<2 | multiin<<1 | multiout, ascending      */
+    DEBWT_ARR_SP_SYMBOLS,      /* u8  x sp_len: SP symbols 0..5                                       */
+    DEBWT_ARR_BLUE,            /* u64 x blue_capacity: pred | spIndex<<4 (src/generateSP.c:666-672)   */
+    DEBWT_ARR_BLUE_BOUND,      /* u64 x blue_bound_num: inclusive end of each block (blueBound)       */
+    DEBWT_ARR_CASE3_BOUND,     /* u64 x case3num: [first row,last row] per block (case3bound)         */
+    DEBWT_ARR_ROW_SYMBOLS      /* u8  x n: BWT symbols 0..5 by row (after assemble)                   */
+} debwt_array;
+/* Copies up to `capacity` elements; *count receives the element count of the array. */
+int debwt_fetch_array(debwt_ctx *ctx, debwt_array which, void *dst, uint64_t capacity, uint64_t *count);
+
+/* ---- primitives exposed for measurement and parity ------------------------------------------- */
+
+/* Stand-alone a-1+a-2 in the reference's own output format: every k-mer inside a record,
+ * sorted ascending, left-aligned, with its count -- the contents of `kmerInfo`
+ * (src/mySort.c:193-195).  Needs a loaded text.  kmers/counts: host arrays of `capacity`
+ * entries; *distinct receives D. */
+int debwt_kmer_count_sorted(debwt_ctx *ctx, uint64_t *kmers, uint64_t *counts, uint64_t capacity,
+                            uint64_t *distinct);
+
+/* LSD radix sort of `count` 64-bit keys resident in HBM (d_keys, d_tmp: device pointers, both
+ * `count` words; result in d_keys).  key_bits: significant low bits (1..64).
+ * ms_per_pass (optional) receives the mean device time of one scatter pass. */
+int debwt_radix_sort_u64(debwt_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t count, int key_bits,
+                         float *ms_per_pass);
+
+/* Verification tool standing in for the dead LFsearch path (src/LFsearch.c:14-48): inverse BWT
+ * by LF walk on the host from a fetched result; writes the n symbols (0..5).  Returns 0 when the
+ * walk closes. */
+int debwt_verify_inverse(const uint64_t *bwt, uint64_t n, const uint64_t *hash_rows, uint64_t nrec,
+                         uint64_t dollar_row, uint8_t *sym_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,208 @@
+"""GPU parity: the HIP path (through the C ABI of libdebwt_hip.so) against the CPU oracle, the
+committed reference golden vectors and size-independent properties.  Bit-exact everywhere: the path is
+64-bit integer arithmetic only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import golden_id, golden_manifest, golden_outputs, golden_records
+
+pytestmark = pytest.mark.gpu
+MANIFEST = golden_manifest()
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from debwt_amd import api as A
+    return A
+
+
+def _run(api, recs, k, algo=0):
+    d = api.DeBWT(k=k, sort_algo=algo)
+    d.load_records(recs)
+    d.build()
+    out = d.fetch()
+    st = d.stats()
+    return d, out, st
+
+
+@pytest.mark.parametrize("entry", MANIFEST, ids=golden_id)
+def test_hip_matches_reference_golden(api, entry):
+    recs = golden_records(entry)
+    d, (words, hrows, drow), st = _run(api, recs, entry["k"])
+    sha = entry["sha256"]
+    assert _sha(words) == sha["bwt"]
+    assert _sha(hrows) == sha["hash"]
+    assert _sha(np.array([drow], dtype=np.uint64)) == sha["dollar"]
+    files = golden_outputs(entry)
+    if files:
+        assert np.array_equal(words, files[0]) and np.array_equal(hrows, files[1]) and drow == files[2]
+    c = entry["counters"]
+    assert (st["n"], st["nrec"]) == (c["BWTLEN"], c["countRead"])
+    assert st["case3num"] == c["case3num"] and st["blue_bound_num"] == c["blueBoundNum"]
+    assert st["red_capacity"] == c["redCapacity"] and st["blue_capacity"] == c["blueCapacity"]
+    assert st["sp_len"] + 32 == c["spCodeLen"] and st["special_branch_num"] == c["specialBranchNum"]
+    d.close()
+
+
+@pytest.mark.parametrize("entry", [e for e in MANIFEST if e["n"] < 400000], ids=golden_id)
+def test_hip_kmer_count_matches_reference_kmerinfo(api, entry):
+    d = api.DeBWT(k=entry["k"])
+    d.load_records(golden_records(entry))
+    km, ct = d.kmer_count_sorted()
+    assert _sha(np.stack([km, ct], axis=1)) == entry["sha256"]["kmerInfo"]     # src/mySort.c:193-195
+    d.close()
+
+
+def _adversarial(rng):
+    nrec = int(rng.integers(1, 7))
+    base = rng.integers(0, 4, size=int(rng.integers(60, 400))).astype(np.uint8)
+    recs = []
+    for _ in range(nrec):
+        L = int(rng.integers(33, 900))
+        x = rng.integers(0, 4, size=L).astype(np.uint8)
+        if rng.random() < 0.7:
+            seg = base[:min(len(base), L)]
+            p = int(rng.integers(0, L - len(seg) + 1))
+            x[p:p + len(seg)] = seg
+        if rng.random() < 0.3:
+            x[-min(L, 40):] = base[:min(L, 40)]
+        if rng.random() < 0.2:
+            x[:min(L, 50)] = rng.integers(0, 4)
+        recs.append(x)
+    if rng.random() < 0.4:
+        recs.append(recs[0].copy())
+    if rng.random() < 0.3:
+        recs.append(recs[-1][:max(33, len(recs[-1]) // 2)].copy())
+    return recs
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_hip_stagewise_equals_oracle_on_adversarial_inputs(api, oracle, seed):
+    rng = np.random.default_rng(7000 + seed)
+    recs = _adversarial(rng)
+    sym = oracle.sym_from_codes(recs)
+    k = int(rng.choice([12, 15, 20, 31, 32]))
+    ow, oh, od, ost, osp, ored = oracle.build_bwt(sym, k, want_intermediates=True)
+    d = api.DeBWT(k=k)
+    d.load_records(recs)
+    d.kmer_sort_rle()
+    keys = d.fetch_array(api.ARR_SORTED_KEYS)
+    assert (keys[1:] >= keys[:-1]).all()
+    d.classify()
+    assert np.array_equal(d.fetch_array(api.ARR_RED), ored)
+    d.sp_generate()
+    assert np.array_equal(d.fetch_array(api.ARR_SP_SYMBOLS), osp)
+    d.blue_sort()
+    d.bwt_assemble()
+    words, hrows, drow = d.fetch()
+    assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
+    st = d.stats()
+    for a, b in (("red_capacity", "red_capacity"), ("blue_capacity", "blue_capacity"),
+                 ("blue_bound_num", "blue_bound_num"), ("sp_len", "sp_len"),
+                 ("special_branch_num", "special_branch_num")):
+        assert st[a] == ost[b], a
+    rows = d.fetch_array(api.ARR_ROW_SYMBOLS)
+    assert np.array_equal(rows, oracle.unpack_bwt(ow, len(sym), oh, od))
+    km, ct = d.kmer_count_sorted()
+    okm, oct_ = oracle.kmer_count(sym, k)
+    assert np.array_equal(km, okm) and np.array_equal(ct, oct_)
+    d.close()
+
+
+@pytest.mark.parametrize("name,k", [("pan_16M_4", 32), ("uniform_16M", 32), ("pan_16M_4", 21)])
+def test_hip_equals_oracle_midsize(api, oracle, name, k):
+    from debwt_amd import synth
+    recs = synth.make_workload(name)
+    sym = oracle.sym_from_codes(recs)
+    ow, oh, od, ost = oracle.build_bwt(sym, k)
+    d, (words, hrows, drow), st = _run(api, recs, k)
+    assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
+    assert st["red_capacity"] == ost["red_capacity"] and st["sp_len"] == ost["sp_len"]
+    assert st["blue_capacity"] == ost["blue_capacity"]
+    d.close()
+
+
+def test_hip_large_block_path(api, oracle):
+    """A node with more occurrences than one workgroup's LDS holds goes through the HBM bitonic path."""
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, size=40).astype(np.uint8)
+    parts = []
+    for i in range(5000):
+        parts.append(unit)
+        parts.append(rng.integers(0, 4, size=int(rng.integers(3, 9))).astype(np.uint8))
+    recs = [np.concatenate(parts), rng.integers(0, 4, size=500).astype(np.uint8)]
+    sym = oracle.sym_from_codes(recs)
+    ow, oh, od, _ = oracle.build_bwt(sym, 32)
+    d, (words, hrows, drow), st = _run(api, recs, 32)
+    assert st["blue_large_blocks"] >= 1 and st["blue_max_block"] > 2048
+    assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
+    d.close()
+
+
+def test_hip_properties_at_bench_size(api):
+    """BASELINE configs[1]-sized input: inverse BWT reproduces the text, k-invariance, symbol census."""
+    from debwt_amd import synth
+    recs = synth.make_workload("pan_100M_4")
+    d, (words, hrows, drow), st = _run(api, recs, 32)
+    n = st["n"]
+    rc, inv = api.verify_inverse(words, n, hrows, drow)
+    assert rc == 0
+    o = 0
+    for i, r in enumerate(recs):
+        assert np.array_equal(inv[o:o + len(r)], r)
+        assert inv[o + len(r)] == (5 if i + 1 == len(recs) else 4)
+        o += len(r) + 1
+    assert (np.diff(hrows.astype(np.int64)) > 0).all()
+    d.close()
+    d2, (w2, h2, dr2), _ = _run(api, recs, 24)
+    assert np.array_equal(words, w2) and np.array_equal(hrows, h2) and drow == dr2
+    d2.close()
+
+
+@pytest.mark.parametrize("count,bits", [(1, 64), (2, 64), (4095, 64), (4097, 40), (1 << 20, 64), (3_000_001, 62),
+                                        (5_000_000, 24)])
+def test_radix_sort_primitive(api, count, bits):
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(count)
+    hi = torch.randint(0, 2 ** 31, (count,), generator=g, dtype=torch.int64)
+    lo = torch.randint(0, 2 ** 31, (count,), generator=g, dtype=torch.int64)
+    keys = (hi << 33) ^ (lo << 2) ^ (hi >> 7)
+    if bits < 64:
+        keys &= (1 << bits) - 1
+    ref = np.sort(keys.numpy().view(np.uint64))
+    dk = keys.cuda()
+    tmp = torch.empty_like(dk)
+    d = api.DeBWT(k=32)
+    d.radix_sort_device(dk.data_ptr(), tmp.data_ptr(), count, bits)
+    assert np.array_equal(dk.cpu().numpy().view(np.uint64), ref)
+    d.close()
+
+
+def test_stage_order_and_errors(api):
+    from debwt_amd import synth
+    with pytest.raises(api.DebwtError):
+        api.DeBWT(k=33)                                    # src/main.c:45-46
+    d = api.DeBWT(k=32)
+    with pytest.raises(api.DebwtError):
+        d.build()                                          # nothing loaded
+    d.load_records(synth.pan_genome(5000, 2))
+    with pytest.raises(api.DebwtError):
+        d.classify()                                       # out of order
+    with pytest.raises(ValueError):
+        api.pack_records([np.zeros(32, np.uint8)])         # src/collect#$.c:41-45
+    d.build()
+    a = d.fetch()
+    d.build()                                              # a context is reusable
+    b = d.fetch()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    d.load_ascii(["ACGT" * 30 + "TTGACCA" * 9, "acgtacgttgca" * 11])
+    d.build()
+    d.close()
