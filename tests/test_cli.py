@@ -1,0 +1,63 @@
+"""The C host program keeps the reference's command line (src/main.c:25-58) and output files
+(src/insertCase3.c:115-131)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_manifest, golden_outputs, golden_records
+
+CLI = os.path.join(ROOT, "cli", "deBWT")
+
+
+def _have_cli():
+    if not os.path.exists(CLI):
+        subprocess.call(["make", "-C", os.path.join(ROOT, "cli")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return os.path.exists(CLI)
+
+
+def test_cli_argument_errors(tmp_path):
+    if not _have_cli():
+        pytest.skip("cli not built")
+    r = subprocess.run([CLI], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
+    fa = tmp_path / "x.fa"
+    fa.write_text(">a\n" + "ACGT" * 20 + "\n")
+    r = subprocess.run([CLI, "-o", str(tmp_path / "o"), "-k", "40", str(fa)], capture_output=True, text=True)
+    assert r.returncode == 1 and "k-mer length" in r.stderr
+    r = subprocess.run([CLI, "-o", str(tmp_path / "o"), "-t", "zero", str(fa)], capture_output=True, text=True)
+    assert r.returncode == 1 and "thread number" in r.stderr
+    r = subprocess.run([CLI, "-o", "/nonexistent_dir/o", str(fa)], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot create" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k", [("special_branches", 32), ("shared_ends_duplicates", 16), ("lowercase_3x2500", 32)])
+def test_cli_outputs_equal_reference_files(tmp_path, name, k):
+    assert _have_cli()
+    entry = next(e for e in golden_manifest() if e["name"] == name and e["k"] == k)
+    out = str(tmp_path / "OUT")
+    fa = os.path.join(ROOT, "tests", "golden", name + ".fa")
+    r = subprocess.run([CLI, "-o", out, "-k", str(k), "-t", "4", "-j", "/ignored", fa], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    words, hrows, drow = golden_outputs(entry)
+    assert np.array_equal(np.fromfile(out, dtype=np.uint64), words)
+    assert np.array_equal(np.fromfile(out + ".#", dtype=np.uint64), hrows)
+    assert int(np.fromfile(out + ".$", dtype=np.uint64)[0]) == drow
+    assert f"the redCapacity is {entry['counters']['redCapacity']}" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_gzip_input(tmp_path):
+    import gzip
+    assert _have_cli()
+    entry = next(e for e in golden_manifest() if e["name"] == "t1_three_records" and e["k"] == 32)
+    src = os.path.join(ROOT, "tests", "golden", "t1_three_records.fa")
+    gz = tmp_path / "in.fa.gz"
+    with open(src, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    out = str(tmp_path / "OUT")
+    r = subprocess.run([CLI, "-o", out, str(gz)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(out, dtype=np.uint64), golden_outputs(entry)[0])
