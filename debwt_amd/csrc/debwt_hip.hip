@@ -49,7 +49,7 @@ struct debwt_ctx {
     // device buffers
     DevBuf text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, pidx, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
-        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym;
+        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits;
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
     int pbits = 8;
@@ -100,6 +100,17 @@ template <class F> int cp_count(debwt_ctx *c, const F &f, u64 n, u32 *counts, in
     u32 *total = counts + CP_MAXCHUNKS;
     cp_scan_kernel<<<1, 1024, 0, c->stream>>>(counts, n ? nchunks : 1, total);
     HIPCHK(c, hipMemcpyAsync(&c->h_scalars[slot], total, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    return DEBWT_OK;
+}
+template <class F> int cp_count2(debwt_ctx *c, const F &f, u64 n, u32 *ca, int slot_a, u32 *cb, int slot_b) {
+    u32 nchunks; u64 chunk;
+    plan_chunks(n, &nchunks, &chunk);
+    if (n) cp_count2_kernel<F><<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(f, n, chunk, ca, cb);
+    else { HIPCHK(c, hipMemsetAsync(ca, 0, sizeof(u32), c->stream)); HIPCHK(c, hipMemsetAsync(cb, 0, sizeof(u32), c->stream)); }
+    cp_scan_kernel<<<1, 1024, 0, c->stream>>>(ca, n ? nchunks : 1, ca + CP_MAXCHUNKS);
+    cp_scan_kernel<<<1, 1024, 0, c->stream>>>(cb, n ? nchunks : 1, cb + CP_MAXCHUNKS);
+    HIPCHK(c, hipMemcpyAsync(&c->h_scalars[slot_a], ca + CP_MAXCHUNKS, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->h_scalars[slot_b], cb + CP_MAXCHUNKS, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     return DEBWT_OK;
 }
 template <class F> int cp_emit(debwt_ctx *c, const F &f, u64 n, const u32 *counts) {
@@ -191,7 +202,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q, &c->pidx,
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
-                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym};
+                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -328,10 +339,12 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     int rc;
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     ClassifyCommon cc{c->dk.as<u64>(), c->dstart.as<u32>(), D, M, c->head_keys.as<u64>(), nrec};
-    MultiInF fin{cc, nullptr, nullptr, nullptr};
-    MultiOutF fout{cc, c->K, nullptr};
-    if ((rc = cp_count(c, fin, D, cp_area(c, 1), 1))) return rc;
-    if ((rc = cp_count(c, fout, D, cp_area(c, 2), 2))) return rc;
+    // pflag (n bytes) is free until the SP stage: it holds the per-distinct-key classification byte
+    u8 *cf = c->pflag.as<u8>();
+    ClassifyFlagsF ff{cc, c->K, cf};
+    MultiInF fin{cc, cf, nullptr, nullptr, nullptr};
+    MultiOutF fout{cc, c->K, cf, nullptr};
+    if ((rc = cp_count2(c, ff, D, cp_area(c, 1), 1, cp_area(c, 2), 2))) return rc;
     if ((rc = sync_check(c))) return rc;
     c->Q = c->h_scalars[1];
     c->Rmo = c->h_scalars[2];
@@ -402,11 +415,27 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     // S <= n; the SP symbol buffer is sized for the worst case once
     ENSURE(c, c->spsym, c->n + 64);
+    const u64 ngroups = (c->n + 31) >> 5;
+    ENSURE(c, c->momask, ngroups * 4 + 64);
+    ENSURE(c, c->mimask, ngroups * 4 + 64);
+    // prefilter bitmap: 8 bins per prefix-index bin
+    int pb = c->pbits + 3;
+    if (pb > 2 * c->K) pb = 2 * c->K;
+    if (pb < 5) pb = 5;
+    size_t rb_bytes = ((size_t)1 << pb) / 8 + 64;
+    ENSURE(c, c->rbits, rb_bytes);
+    HIPCHK(c, hipMemsetAsync(c->rbits.p, 0, rb_bytes, c->stream));
+    if (c->R)
+        k_build_rbits<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->K, pb, c->rbits.as<u32>());
+    k_sp_flags<<<grid_for(ngroups, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+        c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->red.as<u64>(), c->pidx.as<u32>(), c->pbits,
+        c->rbits.as<u32>(), pb, c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(),
+        c->mimask.as<u32>(), ngroups);
     SpF f{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->red.as<u64>(), c->pidx.as<u32>(), c->pbits,
-          c->red_q.as<u32>(), c->branch.as<u64>(), (u64)c->special.branch.size(), c->pflag.as<u8>(),
-          c->spsym.as<u8>(), c->bstart.as<u32>(), c->cursor.as<u32>(), c->blue.as<u64>()};
-    if ((rc = cp_count(c, f, c->n, cp_area(c, 0), 8))) return rc;
-    if ((rc = cp_emit(c, f, c->n, cp_area(c, 0)))) return rc;
+          c->red_q.as<u32>(), c->momask.as<u32>(), c->mimask.as<u32>(), c->spsym.as<u8>(), c->bstart.as<u32>(),
+          c->cursor.as<u32>(), c->blue.as<u64>()};
+    if ((rc = cp_count(c, f, ngroups, cp_area(c, 0), 8))) return rc;
+    if ((rc = cp_emit(c, f, ngroups, cp_area(c, 0)))) return rc;
     if ((rc = sync_check(c))) return rc;
     c->S = c->h_scalars[8];
     u64 nwords = (c->S >> 4) + 3;
@@ -428,7 +457,11 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     const u64 Q = c->Q;
     if (Q) {
-        u32 grid = Q < (1u << 20) ? (u32)Q : (1u << 20);
+        u32 wgrid = (u32)std::min<u64>((Q + DEBWT_WAVES - 1) / DEBWT_WAVES, 1u << 15);
+        k_blue_sort_wave<<<wgrid, DEBWT_BLOCK, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
+                                                              c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q,
+                                                              c->spn.as<u64>(), c->S, c->mchar.as<u8>());
+        u32 grid = (u32)std::min<u64>(Q, 1u << 13);
         k_blue_sort_lds<<<grid, DEBWT_BLOCK, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
                                                              c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q,
                                                              c->spn.as<u64>(), c->S, c->mchar.as<u8>());

@@ -34,22 +34,31 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict
     counts[(u64)threadIdx.x * nchunks + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan in place over `total` u32 values, one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void rs_scan_kernel(u32 *__restrict__ v, u32 total) {
+// exclusive scan of one digit's chunk counts in place (workgroup d <-> digit d), digit total to tot[d]
+__global__ __launch_bounds__(1024) void rs_scan_digit_kernel(u32 *__restrict__ counts, u32 nchunks,
+                                                              u32 *__restrict__ tot) {
     __shared__ u32 wsum[16];
-    u32 per = (total + 1023u) / 1024u;
+    u32 *v = counts + (u64)blockIdx.x * nchunks;
+    u32 per = (nchunks + 1023u) / 1024u;
     u32 beg = threadIdx.x * per;
-    u32 end = beg + per < total ? beg + per : total;
+    u32 end = beg + per < nchunks ? beg + per : nchunks;
     u32 s = 0;
     for (u32 i = beg; i < end; i++) s += v[i];
     u32 incl = wave_scan_incl(s);
     u32 w = threadIdx.x >> 6;
     if (lane_id() == 63) wsum[w] = incl;
     __syncthreads();
-    u32 base = 0;
-    for (u32 i = 0; i < w; i++) base += wsum[i];
+    u32 base = 0, all = 0;
+    for (u32 i = 0; i < 16; i++) { if (i < w) base += wsum[i]; all += wsum[i]; }
     u32 run = base + incl - s;
     for (u32 i = beg; i < end; i++) { u32 c = v[i]; v[i] = run; run += c; }
+    if (threadIdx.x == 0) tot[blockIdx.x] = all;
+}
+// exclusive scan of the 256 digit totals in place
+__global__ __launch_bounds__(RS_RADIX) void rs_scan_tot_kernel(u32 *__restrict__ tot) {
+    __shared__ u32 tmp[8];
+    u32 t, v = tot[threadIdx.x];
+    tot[threadIdx.x] = block_scan_excl(v, tmp, &t);
 }
 
 // Rank one tile.  On return skeys holds the tile's keys grouped by digit (stable), lstart[d] the
@@ -109,14 +118,15 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile
 
 __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out,
                                                                u64 n, u64 chunk, int shift, u32 mask,
-                                                               const u32 *__restrict__ offsets, u32 nchunks) {
+                                                               const u32 *__restrict__ offsets,
+                                                               const u32 *__restrict__ digit_base, u32 nchunks) {
     __shared__ u64 skeys[RS_TILE];
     __shared__ u32 wavecnt[DEBWT_WAVES][RS_RADIX];
     __shared__ u32 lstart[RS_RADIX];
     __shared__ u32 run[RS_RADIX];
     __shared__ u32 scan_tmp[8];
     const u32 tid = threadIdx.x;
-    run[tid] = offsets[(u64)tid * nchunks + blockIdx.x];
+    run[tid] = offsets[(u64)tid * nchunks + blockIdx.x] + digit_base[tid];
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < n ? beg + chunk : n;
     for (u64 tile = beg; tile < end; tile += RS_TILE) {
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
 
 size_t radix_workspace_bytes(u64 max_keys) {
     (void)max_keys;
-    return (size_t)RS_RADIX * RS_MAXCHUNKS * sizeof(u32);
+    return (size_t)RS_RADIX * (RS_MAXCHUNKS + 1) * sizeof(u32);
 }
 
 static void rs_plan(u64 n, u32 *nchunks, u64 *chunk) {
@@ -167,9 +177,11 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
         u32 mask = (1u << bits) - 1u;
         bool ev = pass_events && p < max_pairs;
         rs_hist_kernel<<<nchunks, RS_BLOCK, 0, stream>>>(src, n, chunk, shift, mask, ws.counts, nchunks);
-        rs_scan_kernel<<<1, 1024, 0, stream>>>(ws.counts, RS_RADIX * nchunks);
+        u32 *digit_tot = ws.counts + (size_t)RS_RADIX * RS_MAXCHUNKS;
+        rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
+        rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
         if (ev) (void)hipEventRecord(pass_events[2 * p], stream);
-        rs_scatter_kernel<<<nchunks, RS_BLOCK, 0, stream>>>(src, dst, n, chunk, shift, mask, ws.counts, nchunks);
+        rs_scatter_kernel<<<nchunks, RS_BLOCK, 0, stream>>>(src, dst, n, chunk, shift, mask, ws.counts, digit_tot, nchunks);
         if (ev) { (void)hipEventRecord(pass_events[2 * p + 1], stream); if (npairs) *npairs = p + 1; }
         u64 *t = src; src = dst; dst = t;
     }

@@ -29,6 +29,29 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void cp_count_kernel(F f, u64 n, u64 c
     }
 }
 
+// two counters in one sweep: f.count2(i, &a, &b)
+template <class F>
+__global__ __launch_bounds__(DEBWT_BLOCK) void cp_count2_kernel(F f, u64 n, u64 chunk, u32 *__restrict__ counts_a,
+                                                                 u32 *__restrict__ counts_b) {
+    __shared__ u32 red[2][DEBWT_WAVES];
+    u64 beg = (u64)blockIdx.x * chunk;
+    u64 end = beg + chunk < n ? beg + chunk : n;
+    u32 la = 0, lb = 0;
+    for (u64 i = beg + threadIdx.x; i < end; i += DEBWT_BLOCK) {
+        u32 a, b;
+        f.count2(i, &a, &b);
+        la += a; lb += b;
+    }
+    u32 ia = wave_scan_incl(la), ib = wave_scan_incl(lb);
+    if (lane_id() == 63) { red[0][threadIdx.x >> 6] = ia; red[1][threadIdx.x >> 6] = ib; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 sa = 0, sb = 0;
+        for (int w = 0; w < DEBWT_WAVES; w++) { sa += red[0][w]; sb += red[1][w]; }
+        counts_a[blockIdx.x] = sa; counts_b[blockIdx.x] = sb;
+    }
+}
+
 // exclusive scan of counts[0..m) in place (m <= CP_MAXCHUNKS), total to *total; one workgroup
 __global__ __launch_bounds__(1024) void cp_scan_kernel(u32 *__restrict__ counts, u32 m, u32 *__restrict__ total) {
     __shared__ u32 wsum[16];
@@ -134,60 +157,74 @@ struct ClassifyCommon {
 };
 
 // multi-in nodes: >= 2 distinct real predecessors or a record-start occurrence (src/INandOut.c:282-343)
+__device__ __forceinline__ bool eval_multi_in(const ClassifyCommon &c, u64 e, u32 *freq) {
+    u64 node = c.dk[e] >> 2;
+    if (e && (c.dk[e - 1] >> 2) == node) return false;
+    u32 preds = 0;
+    u64 f = e;
+    for (; f < c.D && f < e + 4 && (c.dk[f] >> 2) == node; f++)
+        if (c.real_count(f)) preds |= 1u << (c.dk[f] & 3);
+    *freq = (f < c.D ? c.dstart[f] : (u32)c.M) - c.dstart[e];
+    return __popc(preds) >= 2 || c.is_head(node);
+}
+
+// multi-out facts: within the group of keys sharing the (K-1)-symbol node prefix W, every pred c with
+// >= 2 distinct last symbols d among real keys (W.d, c) makes node c.W multi-out
+// (out-degree > 1, src/INandOut.c:271-281, read off the same sorted edge list)
+__device__ __forceinline__ u32 eval_multi_out(const ClassifyCommon &c, int K, u64 e, u64 *facts) {
+    u64 W = c.dk[e] >> 4;
+    if (e && (c.dk[e - 1] >> 4) == W) return 0;
+    u32 succ[4] = {0, 0, 0, 0};
+    for (u64 f = e; f < c.D && f < e + 16 && (c.dk[f] >> 4) == W; f++) {
+        if (!c.real_count(f)) continue;
+        u64 k = c.dk[f];
+        succ[k & 3] |= 1u << ((k >> 2) & 3);
+    }
+    u32 m = 0;
+    for (u32 p = 0; p < 4; p++)
+        if (__popc(succ[p]) >= 2) {
+            if (facts) facts[m] = ((((u64)p << (2 * (K - 1))) | W) << 2) | 1ull;
+            m++;
+        }
+    return m;
+}
+
+// one sweep over the distinct keys: cf[e] = multi-in node start | (multi-out facts of the W-group) << 1
+struct ClassifyFlagsF {
+    ClassifyCommon c;
+    int K;
+    u8 *cf;
+    __device__ void count2(u64 e, u32 *a, u32 *b) const {
+        u32 fr;
+        u32 mi = eval_multi_in(c, e, &fr) ? 1u : 0u;
+        u32 mo = eval_multi_out(c, K, e, nullptr);
+        cf[e] = (u8)(mi | (mo << 1));
+        *a = mi; *b = mo;
+    }
+};
 struct MultiInF {
     ClassifyCommon c;
+    const u8 *cf;
     u64 *mi_fact; u32 *mi_j0; u32 *mi_freq;
-    __device__ bool eval(u64 e, u32 *freq) const {
-        u64 node = c.dk[e] >> 2;
-        if (e && (c.dk[e - 1] >> 2) == node) return false;
-        u32 preds = 0;
-        u64 f = e;
-        for (; f < c.D && f < e + 4 && (c.dk[f] >> 2) == node; f++)
-            if (c.real_count(f)) preds |= 1u << (c.dk[f] & 3);
-        *freq = (f < c.D ? c.dstart[f] : (u32)c.M) - c.dstart[e];
-        return __popc(preds) >= 2 || c.is_head(node);
-    }
-    __device__ u32 count(u64 e) const { u32 fr; return eval(e, &fr) ? 1u : 0u; }
-    __device__ u32 recount(u64 e) const { return count(e); }
+    __device__ u32 recount(u64 e) const { return cf[e] & 1u; }
     __device__ void emit(u64 e, u32 off, u32 cnt) const {
         if (!cnt) return;
-        u32 fr; eval(e, &fr);
+        u32 fr; eval_multi_in(c, e, &fr);
         mi_fact[off] = ((c.dk[e] >> 2) << 2) | 2ull;
         mi_j0[off] = c.dstart[e];
         mi_freq[off] = fr;
     }
 };
-
-// multi-out facts: within the group of keys sharing the (K-1)-symbol node prefix W, every pred c with
-// >= 2 distinct last symbols d among real keys (W.d, c) makes node c.W multi-out
-// (out-degree > 1, src/INandOut.c:271-281, read off the same sorted edge list)
 struct MultiOutF {
     ClassifyCommon c;
     int K;
+    const u8 *cf;
     u64 *mo_fact;
-    __device__ u32 eval(u64 e, u64 *facts) const {
-        u64 W = c.dk[e] >> 4;
-        if (e && (c.dk[e - 1] >> 4) == W) return 0;
-        u32 succ[4] = {0, 0, 0, 0};
-        for (u64 f = e; f < c.D && f < e + 16 && (c.dk[f] >> 4) == W; f++) {
-            if (!c.real_count(f)) continue;
-            u64 k = c.dk[f];
-            succ[k & 3] |= 1u << ((k >> 2) & 3);
-        }
-        u32 m = 0;
-        for (u32 p = 0; p < 4; p++)
-            if (__popc(succ[p]) >= 2) {
-                if (facts) facts[m] = ((((u64)p << (2 * (K - 1))) | W) << 2) | 1ull;
-                m++;
-            }
-        return m;
-    }
-    __device__ u32 count(u64 e) const { return eval(e, nullptr); }
-    __device__ u32 recount(u64 e) const { return count(e); }
+    __device__ u32 recount(u64 e) const { return cf[e] >> 1; }
     __device__ void emit(u64 e, u32 off, u32 cnt) const {
         if (!cnt) return;
         u64 facts[4];
-        eval(e, facts);
+        eval_multi_out(c, K, e, facts);
         for (u32 m = 0; m < cnt; m++) mo_fact[off + m] = facts[m];
     }
 };
@@ -263,46 +300,92 @@ __global__ void k_special_rows(const u64 *__restrict__ sk, u64 M, const u64 *__r
 // ---------------------------------------------------------------------------------------------------
 // SP code + blue entries (multiGenerateSP, src/generateSP.c:534-683)
 
+// prefilter bitmap over the top pb bits of the red nodes: most positions are not branching nodes and are
+// rejected by one read of an L2-resident table
+__global__ void k_build_rbits(const u64 *__restrict__ red, u64 R, int K, int pb, u32 *__restrict__ rbits) {
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    u64 h = (red[r] >> 2) >> (2 * K - pb);
+    atomicOr(&rbits[h >> 5], 1u << (h & 31));
+}
+
+// pass 1: one lane = 32 consecutive positions = one text word (coalesced 8-byte loads); per position the
+// node is a shift of the 128-bit (w0,w1) pair; flags go out as two 32-bit masks per group
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict__ text, const u64 *__restrict__ sepbits,
+                                                           u64 n, int K, const u64 *__restrict__ red,
+                                                           const u32 *__restrict__ pidx, int p,
+                                                           const u32 *__restrict__ rbits, int pb,
+                                                           const u64 *__restrict__ branch, u64 nbranch,
+                                                           u32 *__restrict__ momask, u32 *__restrict__ mimask,
+                                                           u64 ngroups) {
+    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const u64 w0 = text[g], w1 = text[g + 1];
+    const u64 sb = sep_window(sepbits, g << 5);
+    const u64 kmask = (1ull << K) - 1ull;
+    const u64 i0 = g << 5;
+    u32 lim = (n - i0) < 32 ? (u32)(n - i0) : 32u;
+    u32 mo = 0, mi = 0;
+#pragma unroll 8
+    for (u32 t = 0; t < 32; t++) {
+        if (t >= lim) break;
+        u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
+        if ((sb >> t) & kmask) {
+            // special module: multi-out iff listed in specialBranch (src/generateSP.c:612-624)
+            if (nbranch) {
+                u64 i = i0 + t;
+                u64 lo = lower_bound_dev<u64>(branch, 0, nbranch, i);
+                if (lo < nbranch && branch[lo] == i) mo |= 1u << t;
+            }
+        } else {
+            u64 node = win >> (64 - 2 * K);
+            u64 hb = node >> (2 * K - pb);
+            if ((rbits[hb >> 5] >> (hb & 31)) & 1u) {
+                u32 fl;
+                red_lookup(red, pidx, K, p, node, &fl);
+                mo |= (fl & 1u) << t;
+                mi |= ((fl >> 1) & 1u) << t;
+            }
+        }
+    }
+    momask[g] = mo;
+    mimask[g] = mi;
+}
+
+// pass 2 (over groups of 32 positions): spIndex = exclusive scan of the multi-out bits; SP symbols and blue
+// entries are written in position order
 struct SpF {
     const u64 *text; const u64 *sepbits; u64 n; int K;
     const u64 *red; const u32 *pidx; int p; const u32 *red_q;
-    const u64 *branch; u64 nbranch;
-    u8 *pflag;                 // bit0 multi-out, bit1 multi-in, per position
+    const u32 *momask; const u32 *mimask;
     u8 *spsym;                 // SP symbols 0..5
     const u32 *bstart; u32 *cursor; u64 *blue;
 
-    __device__ u32 count(u64 i) const {
-        u64 sw = sep_window(sepbits, i);
-        u32 fl = 0;
-        if (sw & ((1ull << K) - 1ull)) {
-            // special module: multi-out iff listed in specialBranch (src/generateSP.c:612-624)
-            u64 lo = lower_bound_dev<u64>(branch, 0, nbranch, i);
-            if (lo < nbranch && branch[lo] == i) fl = 1;
-        } else {
-            u64 node = text_window(text, i) >> (64 - 2 * K);
-            red_lookup(red, pidx, K, p, node, &fl);
-        }
-        pflag[i] = (u8)fl;
-        return fl & 1u;
-    }
-    __device__ u32 recount(u64 i) const { return pflag[i] & 1u; }
-    __device__ void emit(u64 i, u32 off, u32 c) const {
-        u32 fl = pflag[i];
-        if (c) {
-            // the symbol K ahead; the separator itself when it follows the window (:626-660)
-            u64 j = i + (u64)K;
-            u8 s;
-            if (sep_at(sepbits, j)) s = (j == n - 1) ? 5 : 4; else s = (u8)text_symbol(text, j);
-            spsym[off] = s;
-        }
-        if (fl & 2u) {
-            u64 node = text_window(text, i) >> (64 - 2 * K);
-            u32 f2;
-            u32 r = red_lookup(red, pidx, K, p, node, &f2);
-            u32 q = red_q[r];
-            u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
-            u32 slot = atomicAdd(&cursor[q], 1u);
-            blue[(u64)bstart[q] + slot] = pred | ((u64)off << 4);          // src/generateSP.c:666-672
+    __device__ u32 count(u64 g) const { return (u32)__popc(momask[g]); }
+    __device__ u32 recount(u64 g) const { return (u32)__popc(momask[g]); }
+    __device__ void emit(u64 g, u32 off, u32) const {
+        u32 mo = momask[g], mi = mimask[g];
+        u32 all = mo | mi;
+        while (all) {
+            u32 t = (u32)__ffs(all) - 1u;
+            all &= all - 1u;
+            u64 i = (g << 5) + t;
+            if ((mi >> t) & 1u) {
+                u64 node = text_window(text, i) >> (64 - 2 * K);
+                u32 f2;
+                u32 r = red_lookup(red, pidx, K, p, node, &f2);
+                u32 q = red_q[r];
+                u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
+                u32 slot = atomicAdd(&cursor[q], 1u);
+                blue[(u64)bstart[q] + slot] = pred | ((u64)off << 4);      // src/generateSP.c:666-672
+            }
+            if ((mo >> t) & 1u) {
+                // the symbol K ahead; the separator itself when it follows the window (:626-660)
+                u64 j = i + (u64)K;
+                u8 sy;
+                if (sep_at(sepbits, j)) sy = (j == n - 1) ? 5 : 4; else sy = (u8)text_symbol(text, j);
+                spsym[off++] = sy;
+            }
         }
     }
 };
@@ -345,6 +428,49 @@ __device__ __forceinline__ bool sp_less_deep(const u64 *__restrict__ spn, u64 S,
     return a > b;   // not reached on consistent input
 }
 
+#define BLUE_WAVE_CAP 64
+
+// blocks of <= 64 entries (the bulk: SURVEY 8a workload shape): one wave per block, one entry per lane,
+// bitonic network over lanes by shuffles; no LDS, no barriers
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_sort_wave(u64 *__restrict__ blue, const u32 *__restrict__ bstart,
+                                                                 const u32 *__restrict__ mi_freq,
+                                                                 const u32 *__restrict__ mi_j0, u32 Q,
+                                                                 const u64 *__restrict__ spn, u64 S,
+                                                                 u8 *__restrict__ mchar) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 nwaves = gridDim.x * DEBWT_WAVES;
+    for (u32 q = blockIdx.x * DEBWT_WAVES + (threadIdx.x >> 6); q < Q; q += nwaves) {
+        u32 m = mi_freq[q];
+        if (m > BLUE_WAVE_CAP) continue;
+        u64 b0 = bstart[q];
+        u32 j0 = mi_j0[q];
+        bool have = lane < m;
+        u64 e = have ? blue[b0 + lane] : ~0ull;
+        u64 k0 = have ? sp_window(spn, e >> 4) : ~0ull;
+        u32 sym = (u32)(e & 15);
+        u32 distinct = 0;
+#pragma unroll
+        for (u32 c = 0; c < 6; c++) distinct += __ballot(have && sym == c) != 0ull;
+        if (distinct >= 2) {                                  // src/sortBlue.c:192-219
+            u32 P = 2;
+            while (P < m) P <<= 1;
+            for (u32 kk = 2; kk <= P; kk <<= 1) {
+                for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+                    u64 pk = __shfl_xor(k0, (int)jj, 64);
+                    u64 pe = __shfl_xor(e, (int)jj, 64);
+                    bool mine_less;
+                    if (k0 != pk) mine_less = k0 < pk;
+                    else if (e == ~0ull || pe == ~0ull) mine_less = e < pe;
+                    else mine_less = sp_less_deep(spn, S, e, pe);
+                    bool take_min = ((lane & jj) == 0) == ((lane & kk) == 0);
+                    if (take_min != mine_less) { k0 = pk; e = pe; }
+                }
+            }
+        }
+        if (have) { blue[b0 + lane] = e; mchar[j0 + lane] = (u8)(e & 15); }
+    }
+}
+
 #define BLUE_LDS_CAP 2048
 
 // one workgroup per block of <= BLUE_LDS_CAP entries: bitonic sort in LDS on (first window, entry),
@@ -359,13 +485,9 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_sort_lds(u64 *__restrict__
     __shared__ u32 seen;
     for (u32 q = blockIdx.x; q < Q; q += gridDim.x) {
         u32 m = mi_freq[q];
-        if (m > BLUE_LDS_CAP) continue;
+        if (m > BLUE_LDS_CAP || m <= BLUE_WAVE_CAP) continue;
         u64 b0 = bstart[q];
         u32 j0 = mi_j0[q];
-        if (m == 1) {
-            if (threadIdx.x == 0) mchar[j0] = (u8)(blue[b0] & 15);
-            continue;
-        }
         if (threadIdx.x == 0) seen = 0;
         __syncthreads();
         u32 P = 2;
