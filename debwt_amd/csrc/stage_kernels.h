@@ -428,46 +428,88 @@ __device__ __forceinline__ bool sp_less_deep(const u64 *__restrict__ spn, u64 S,
     return a > b;   // not reached on consistent input
 }
 
-#define BLUE_WAVE_CAP 64
+#define BLUE_WAVE_CAP 512   // largest block sorted by a single wave (8 entries per lane)
 
-// blocks of <= 64 entries (the bulk: SURVEY 8a workload shape): one wave per block, one entry per lane,
-// bitonic network over lanes by shuffles; no LDS, no barriers
+__device__ __noinline__ bool blue_less_slow(const u64 *__restrict__ spn, u64 S, u64 ea, u64 eb) {
+    if (ea == ~0ull || eb == ~0ull) return ea < eb;
+    return sp_less_deep(spn, S, ea, eb);
+}
+__device__ __forceinline__ bool blue_less(const u64 *__restrict__ spn, u64 S, u64 ka, u64 ea, u64 kb, u64 eb) {
+    return ka != kb ? ka < kb : blue_less_slow(spn, S, ea, eb);
+}
+
+// Blocks of lo < m <= 64*EPL entries (the bulk: SURVEY 8a workload shape): one wave per block, EPL entries
+// per lane (entry x = r*64 + lane), bitonic network with shuffles for distances < 64 and register
+// exchanges above; no LDS, no barriers.  The network is fully unrolled so register indices are static.
+template <int EPL, int LOGP_MAX>
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_sort_wave(u64 *__restrict__ blue, const u32 *__restrict__ bstart,
                                                                  const u32 *__restrict__ mi_freq,
-                                                                 const u32 *__restrict__ mi_j0, u32 Q,
+                                                                 const u32 *__restrict__ mi_j0, u32 Q, u32 lo_excl,
                                                                  const u64 *__restrict__ spn, u64 S,
                                                                  u8 *__restrict__ mchar) {
     const u32 lane = threadIdx.x & 63u;
     const u32 nwaves = gridDim.x * DEBWT_WAVES;
     for (u32 q = blockIdx.x * DEBWT_WAVES + (threadIdx.x >> 6); q < Q; q += nwaves) {
-        u32 m = mi_freq[q];
-        if (m > BLUE_WAVE_CAP) continue;
-        u64 b0 = bstart[q];
-        u32 j0 = mi_j0[q];
-        bool have = lane < m;
-        u64 e = have ? blue[b0 + lane] : ~0ull;
-        u64 k0 = have ? sp_window(spn, e >> 4) : ~0ull;
-        u32 sym = (u32)(e & 15);
-        u32 distinct = 0;
+        const u32 m = mi_freq[q];
+        if (m <= lo_excl || m > 64u * EPL) continue;
+        const u64 b0 = bstart[q];
+        const u32 j0 = mi_j0[q];
+        u64 e[EPL], k0[EPL];
+        u32 symmask = 0;
 #pragma unroll
-        for (u32 c = 0; c < 6; c++) distinct += __ballot(have && sym == c) != 0ull;
-        if (distinct >= 2) {                                  // src/sortBlue.c:192-219
+        for (int r = 0; r < EPL; r++) {
+            u32 x = r * 64 + lane;
+            bool have = x < m;
+            e[r] = have ? blue[b0 + x] : ~0ull;
+            if (have) symmask |= 1u << (e[r] & 15);
+        }
+#pragma unroll
+        for (int r = 0; r < EPL; r++) k0[r] = (r * 64 + lane < m) ? sp_window(spn, e[r] >> 4) : ~0ull;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) symmask |= __shfl_xor(symmask, d, 64);
+        if (symmask & (symmask - 1)) {                        // >= 2 distinct symbols (src/sortBlue.c:192-219)
             u32 P = 2;
             while (P < m) P <<= 1;
-            for (u32 kk = 2; kk <= P; kk <<= 1) {
-                for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
-                    u64 pk = __shfl_xor(k0, (int)jj, 64);
-                    u64 pe = __shfl_xor(e, (int)jj, 64);
-                    bool mine_less;
-                    if (k0 != pk) mine_less = k0 < pk;
-                    else if (e == ~0ull || pe == ~0ull) mine_less = e < pe;
-                    else mine_less = sp_less_deep(spn, S, e, pe);
-                    bool take_min = ((lane & jj) == 0) == ((lane & kk) == 0);
-                    if (take_min != mine_less) { k0 = pk; e = pe; }
+#pragma unroll
+            for (int lk = 1; lk <= LOGP_MAX; lk++) {
+                const u32 kk = 1u << lk;
+                if (kk <= P) {
+#pragma unroll
+                    for (int lj = lk - 1; lj >= 0; lj--) {
+                        const u32 jj = 1u << lj;
+                        if (jj >= 64) {
+                            const int rr = (int)(jj >> 6);
+#pragma unroll
+                            for (int r = 0; r < EPL; r++) {
+                                if ((r & rr) == 0 && (r | rr) < EPL) {
+                                    const int pr = r | rr;
+                                    bool up = (((u32)r * 64u + lane) & kk) == 0;
+                                    bool swap = blue_less(spn, S, k0[pr], e[pr], k0[r], e[r]) == up;
+                                    if (swap) {
+                                        u64 tk = k0[r]; k0[r] = k0[pr]; k0[pr] = tk;
+                                        u64 te = e[r]; e[r] = e[pr]; e[pr] = te;
+                                    }
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < EPL; r++) {
+                                u64 pk = __shfl_xor(k0[r], (int)jj, 64);
+                                u64 pe = __shfl_xor(e[r], (int)jj, 64);
+                                bool mine_less = blue_less(spn, S, k0[r], e[r], pk, pe);
+                                bool take_min = ((lane & jj) == 0) == ((((u32)r * 64u + lane) & kk) == 0);
+                                if (take_min != mine_less) { k0[r] = pk; e[r] = pe; }
+                            }
+                        }
+                    }
                 }
             }
         }
-        if (have) { blue[b0 + lane] = e; mchar[j0 + lane] = (u8)(e & 15); }
+#pragma unroll
+        for (int r = 0; r < EPL; r++) {
+            u32 x = r * 64 + lane;
+            if (x < m) { blue[b0 + x] = e[r]; mchar[j0 + x] = (u8)(e[r] & 15); }
+        }
     }
 }
 

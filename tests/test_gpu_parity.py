@@ -130,6 +130,27 @@ def test_hip_equals_oracle_midsize(api, oracle, name, k):
     d.close()
 
 
+def test_hip_block_size_classes(api, oracle):
+    """Blocks of 65..2048 rows: the 2/4/8-entries-per-lane wave sorts and the LDS workgroup sort."""
+    rng = np.random.default_rng(11)
+    parts = []
+    for copies in (70, 100, 130, 200, 300, 500, 600, 1100, 1900):
+        unit = rng.integers(0, 4, size=36).astype(np.uint8)
+        for i in range(copies):
+            parts.append(unit)
+            parts.append(rng.integers(0, 4, size=int(rng.integers(2, 7))).astype(np.uint8))
+    recs = [np.concatenate(parts), rng.integers(0, 4, size=300).astype(np.uint8)]
+    sym = oracle.sym_from_codes(recs)
+    ow, oh, od, ost = oracle.build_bwt(sym, 32)
+    d, (words, hrows, drow), st = _run(api, recs, 32)
+    assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
+    blue = d.fetch_array(api.ARR_BLUE)
+    bound = d.fetch_array(api.ARR_BLUE_BOUND)
+    sizes = np.diff(np.concatenate([[-1], bound.astype(np.int64)]))
+    assert (sizes > 64).sum() >= 9 and (sizes > 512).sum() >= 3 and len(blue) == st["blue_capacity"]
+    d.close()
+
+
 def test_hip_large_block_path(api, oracle):
     """A node with more occurrences than one workgroup's LDS holds goes through the HBM bitonic path."""
     rng = np.random.default_rng(5)
