@@ -457,20 +457,15 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     const u64 Q = c->Q;
     if (Q) {
-        u32 wgrid = (u32)std::min<u64>((Q + DEBWT_WAVES - 1) / DEBWT_WAVES, 1u << 15);
-#define LAUNCH_WAVE_SORT(EPL, LOGP, LO)                                                                     \
-        k_blue_sort_wave<EPL, LOGP><<<wgrid, DEBWT_BLOCK, 0, c->stream>>>(                                      \
-            c->blue.as<u64>(), c->bstart.as<u32>(), c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q, LO,       \
-            c->spn.as<u64>(), c->S, c->mchar.as<u8>())
-        LAUNCH_WAVE_SORT(1, 6, 0u);        // 1..64 rows
-        LAUNCH_WAVE_SORT(2, 7, 64u);       // 65..128
-        LAUNCH_WAVE_SORT(4, 8, 128u);      // 129..256
-        LAUNCH_WAVE_SORT(8, 9, 256u);      // 257..512
-#undef LAUNCH_WAVE_SORT
-        u32 grid = (u32)std::min<u64>(Q, 1u << 13);
-        k_blue_sort_lds<<<grid, DEBWT_BLOCK, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
-                                                             c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q,
-                                                             c->spn.as<u64>(), c->S, c->mchar.as<u8>());
+        u32 g1 = (u32)std::min<u64>(Q, 1u << 16);
+        k_blue_refine<64, BLUE_WAVE_CAP><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
+                                                                  c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q,
+                                                                  0u, c->spn.as<u64>(), c->S, c->mchar.as<u8>());
+        u32 g2 = (u32)std::min<u64>(Q, 1u << 12);
+        k_blue_refine<256, BLUE_LDS_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
+                                                                   c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q,
+                                                                   (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
+                                                                   c->mchar.as<u8>());
     }
     c->st.blue_max_block = 0;
     if (c->nlarge) {

@@ -428,152 +428,179 @@ __device__ __forceinline__ bool sp_less_deep(const u64 *__restrict__ spn, u64 S,
     return a > b;   // not reached on consistent input
 }
 
-#define BLUE_WAVE_CAP 512   // largest block sorted by a single wave (8 entries per lane)
+#define BLUE_WAVE_CAP 512   // largest block sorted by a single-wave workgroup
 
-__device__ __noinline__ bool blue_less_slow(const u64 *__restrict__ spn, u64 S, u64 ea, u64 eb) {
-    if (ea == ~0ull || eb == ~0ull) return ea < eb;
-    return sp_less_deep(spn, S, ea, eb);
-}
-__device__ __forceinline__ bool blue_less(const u64 *__restrict__ spn, u64 S, u64 ka, u64 ea, u64 kb, u64 eb) {
-    return ka != kb ? ka < kb : blue_less_slow(spn, S, ea, eb);
-}
-
-// Blocks of lo < m <= 64*EPL entries (the bulk: SURVEY 8a workload shape): one wave per block, EPL entries
-// per lane (entry x = r*64 + lane), bitonic network with shuffles for distances < 64 and register
-// exchanges above; no LDS, no barriers.  The network is fully unrolled so register indices are static.
-template <int EPL, int LOGP_MAX>
-__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_sort_wave(u64 *__restrict__ blue, const u32 *__restrict__ bstart,
-                                                                 const u32 *__restrict__ mi_freq,
-                                                                 const u32 *__restrict__ mi_j0, u32 Q, u32 lo_excl,
-                                                                 const u64 *__restrict__ spn, u64 S,
-                                                                 u8 *__restrict__ mchar) {
-    const u32 lane = threadIdx.x & 63u;
-    const u32 nwaves = gridDim.x * DEBWT_WAVES;
-    for (u32 q = blockIdx.x * DEBWT_WAVES + (threadIdx.x >> 6); q < Q; q += nwaves) {
+// Block sort by level-wise refinement (the data-parallel form of myQsort + cmpSP, src/sortBlue.c:109-280):
+// round d orders the still-tied entries by their d-th 16-symbol SP window; entries whose tie group has
+// become a single row, or whose group carries a single BWT symbol (the reference's early-out,
+// src/sortBlue.c:192-219), leave the game.  One SP gather per unresolved entry per round -- not per
+// comparison.  A workgroup of NT threads holds the block in LDS; each round is a bitonic network on
+// (group, window) pairs, a prefix-max for the new group ids and LDS atomics for the group census.
+template <int NT, int CAP>
+__global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, const u32 *__restrict__ bstart,
+                                                     const u32 *__restrict__ mi_freq, const u32 *__restrict__ mi_j0,
+                                                     u32 Q, u32 lo_excl, const u64 *__restrict__ spn, u64 S,
+                                                     u8 *__restrict__ mchar) {
+    __shared__ u64 se[CAP];     // entries
+    __shared__ u64 sw[CAP];     // current window
+    __shared__ u32 sg[CAP];     // tie group = index of its first row
+    __shared__ u32 gcnt[CAP];   // rows per group   (also scratch for the boundary scan)
+    __shared__ u32 gmsk[CAP];   // BWT symbols present per group
+    __shared__ u32 wtot[NT / 64 + 1];
+    __shared__ u32 flag;
+    __shared__ u32 smax;
+    const u32 tid = threadIdx.x;
+    for (u32 q = blockIdx.x; q < Q; q += gridDim.x) {
         const u32 m = mi_freq[q];
-        if (m <= lo_excl || m > 64u * EPL) continue;
+        if (m <= lo_excl || m > CAP) continue;
+        u32 maxg = m;
         const u64 b0 = bstart[q];
         const u32 j0 = mi_j0[q];
-        u64 e[EPL], k0[EPL];
-        u32 symmask = 0;
-#pragma unroll
-        for (int r = 0; r < EPL; r++) {
-            u32 x = r * 64 + lane;
-            bool have = x < m;
-            e[r] = have ? blue[b0 + x] : ~0ull;
-            if (have) symmask |= 1u << (e[r] & 15);
+        u32 P = 2;
+        while (P < m) P <<= 1;
+        u32 mask = 0;
+        if (tid == 0) flag = 0;
+        for (u32 x = tid; x < P; x += NT) {
+            if (x < m) {
+                u64 e = blue[b0 + x];
+                se[x] = e; sg[x] = 0; mask |= 1u << (e & 15);
+            } else { se[x] = ~0ull; sg[x] = 0xFFFFFFFFu; sw[x] = ~0ull; }
+            gcnt[x] = m; gmsk[x] = 0x3u;                      // round 0: one group, unresolved
         }
+        __syncthreads();
+        if (mask) atomicOr(&flag, mask);
+        __syncthreads();
+        bool active = (flag & (flag - 1)) != 0;               // >= 2 distinct symbols in the block
+        __syncthreads();
+        for (u64 depth = 0; active; depth++) {
+            // 1. next window of every unresolved row
+            for (u32 x = tid; x < m; x += NT) {
+                u32 g = sg[x];
+                bool unresolved = gcnt[g] > 1 && (gmsk[g] & (gmsk[g] - 1));
+                u64 pos = (se[x] >> 4) + (depth << 4);
+                sw[x] = (unresolved && pos < S) ? sp_window(spn, pos) : 0ull;
+            }
+            __syncthreads();
+            // 2. order every unresolved group by window: small groups by counting ranks inside the group
+            //    (cost ~ group size), otherwise a bitonic network on (group, window) over the whole block
+            if (maxg <= 32) {
+                constexpr int EPT = CAP / NT;
+                u32 npos[EPT];
+                u64 ne[EPT], nw[EPT];
 #pragma unroll
-        for (int r = 0; r < EPL; r++) k0[r] = (r * 64 + lane < m) ? sp_window(spn, e[r] >> 4) : ~0ull;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) symmask |= __shfl_xor(symmask, d, 64);
-        if (symmask & (symmask - 1)) {                        // >= 2 distinct symbols (src/sortBlue.c:192-219)
-            u32 P = 2;
-            while (P < m) P <<= 1;
-#pragma unroll
-            for (int lk = 1; lk <= LOGP_MAX; lk++) {
-                const u32 kk = 1u << lk;
-                if (kk <= P) {
-#pragma unroll
-                    for (int lj = lk - 1; lj >= 0; lj--) {
-                        const u32 jj = 1u << lj;
-                        if (jj >= 64) {
-                            const int rr = (int)(jj >> 6);
-#pragma unroll
-                            for (int r = 0; r < EPL; r++) {
-                                if ((r & rr) == 0 && (r | rr) < EPL) {
-                                    const int pr = r | rr;
-                                    bool up = (((u32)r * 64u + lane) & kk) == 0;
-                                    bool swap = blue_less(spn, S, k0[pr], e[pr], k0[r], e[r]) == up;
-                                    if (swap) {
-                                        u64 tk = k0[r]; k0[r] = k0[pr]; k0[pr] = tk;
-                                        u64 te = e[r]; e[r] = e[pr]; e[pr] = te;
-                                    }
-                                }
+                for (int c = 0; c < EPT; c++) {
+                    u32 x = tid + (u32)c * NT;
+                    npos[c] = 0xFFFFFFFFu;
+                    if (x < m) {
+                        u32 g = sg[x];
+                        u32 cnt = gcnt[g];
+                        if (cnt > 1 && (gmsk[g] & (gmsk[g] - 1))) {
+                            u64 wx = sw[x];
+                            u32 rank = 0;
+                            for (u32 y = g; y < g + cnt; y++) {
+                                u64 wy = sw[y];
+                                rank += (wy < wx || (wy == wx && y < x)) ? 1u : 0u;
                             }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < EPL; r++) {
-                                u64 pk = __shfl_xor(k0[r], (int)jj, 64);
-                                u64 pe = __shfl_xor(e[r], (int)jj, 64);
-                                bool mine_less = blue_less(spn, S, k0[r], e[r], pk, pe);
-                                bool take_min = ((lane & jj) == 0) == ((((u32)r * 64u + lane) & kk) == 0);
-                                if (take_min != mine_less) { k0[r] = pk; e[r] = pe; }
-                            }
+                            npos[c] = g + rank; ne[c] = se[x]; nw[c] = wx;
                         }
                     }
                 }
-            }
-        }
+                __syncthreads();
 #pragma unroll
-        for (int r = 0; r < EPL; r++) {
-            u32 x = r * 64 + lane;
-            if (x < m) { blue[b0 + x] = e[r]; mchar[j0 + x] = (u8)(e[r] & 15); }
+                for (int c = 0; c < EPT; c++)
+                    if (npos[c] != 0xFFFFFFFFu) { se[npos[c]] = ne[c]; sw[npos[c]] = nw[c]; }
+                __syncthreads();
+            } else {
+                for (u32 kk = 2; kk <= P; kk <<= 1) {
+                    for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+                        for (u32 t = tid; t < (P >> 1); t += NT) {
+                            u32 i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+                            u32 l = i | jj;
+                            u32 gi = sg[i], gl = sg[l];
+                            u64 wi = sw[i], wl = sw[l];
+                            bool l_less = gl != gi ? gl < gi : wl < wi;
+                            bool i_less = gl != gi ? gi < gl : wi < wl;
+                            bool up = (i & kk) == 0;
+                            if (up ? l_less : i_less) {
+                                u64 ei = se[i], el = se[l];
+                                sg[i] = gl; sg[l] = gi; sw[i] = wl; sw[l] = wi; se[i] = el; se[l] = ei;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+            // 3. new groups: first row of each run of equal (group, window); prefix-max of (index+1)
+            const u32 C = P > NT ? P / NT : 1;               // rows per thread, contiguous
+            u32 xb = tid * C, run = 0;
+            u32 loc[CAP / NT > 0 ? CAP / NT : 1];
+            if (xb < P) {
+#pragma unroll
+                for (u32 c = 0; c < (CAP / NT > 0 ? CAP / NT : 1); c++) {
+                    if (c < C) {
+                        u32 x = xb + c;
+                        bool bnd = x == 0 || sg[x] != sg[x - 1] || sw[x] != sw[x - 1];
+                        if (bnd) run = x + 1;
+                        loc[c] = run;
+                    }
+                }
+            }
+            // exclusive prefix-max of `run` over threads
+            u32 incl = run;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                u32 o = __shfl_up(incl, d, 64);
+                if ((int)(tid & 63) >= d) incl = incl > o ? incl : o;
+            }
+            u32 excl = __shfl_up(incl, 1, 64);
+            if ((tid & 63) == 0) excl = 0;
+            if (NT > 64) {
+                if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+                __syncthreads();
+                for (u32 w = 0; w < (tid >> 6); w++) excl = excl > wtot[w] ? excl : wtot[w];
+            }
+            __syncthreads();                                   // all reads of sg/sw for boundaries done
+            if (xb < P) {
+#pragma unroll
+                for (u32 c = 0; c < (CAP / NT > 0 ? CAP / NT : 1); c++) {
+                    if (c < C) {
+                        u32 x = xb + c;
+                        u32 v = loc[c] > excl ? loc[c] : excl;
+                        if (x < m) sg[x] = v - 1;
+                        gcnt[x] = 0; gmsk[x] = 0;
+                    }
+                }
+            }
+            if (tid == 0) { flag = 0; smax = 0; }
+            __syncthreads();
+            // 4. census of the new groups
+            for (u32 x = tid; x < m; x += NT) {
+                u32 g = sg[x];
+                atomicAdd(&gcnt[g], 1u);
+                atomicOr(&gmsk[g], 1u << (se[x] & 15));
+            }
+            __syncthreads();
+            u32 any = 0;
+            for (u32 x = tid; x < m; x += NT) {
+                u32 g = sg[x];
+                if (g == x && gcnt[g] > 1 && (gmsk[g] & (gmsk[g] - 1))) any = any > gcnt[g] ? any : gcnt[g];
+            }
+            if (any) { flag = 1; atomicMax(&smax, any); }
+            __syncthreads();
+            active = flag != 0 && ((depth + 1) << 4) < S + 16;
+            maxg = smax;
+            __syncthreads();
         }
+        for (u32 x = tid; x < m; x += NT) {
+            u64 e = se[x];
+            blue[b0 + x] = e;
+            mchar[j0 + x] = (u8)(e & 15);
+        }
+        __syncthreads();
     }
 }
 
 #define BLUE_LDS_CAP 2048
-
-// one workgroup per block of <= BLUE_LDS_CAP entries: bitonic sort in LDS on (first window, entry),
-// deeper windows fetched only on ties; writes the block's BWT symbols to their rows in mchar
-__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_sort_lds(u64 *__restrict__ blue, const u32 *__restrict__ bstart,
-                                                                const u32 *__restrict__ mi_freq,
-                                                                const u32 *__restrict__ mi_j0, u32 Q,
-                                                                const u64 *__restrict__ spn, u64 S,
-                                                                u8 *__restrict__ mchar) {
-    __shared__ u64 k0[BLUE_LDS_CAP];
-    __shared__ u64 en[BLUE_LDS_CAP];
-    __shared__ u32 seen;
-    for (u32 q = blockIdx.x; q < Q; q += gridDim.x) {
-        u32 m = mi_freq[q];
-        if (m > BLUE_LDS_CAP || m <= BLUE_WAVE_CAP) continue;
-        u64 b0 = bstart[q];
-        u32 j0 = mi_j0[q];
-        if (threadIdx.x == 0) seen = 0;
-        __syncthreads();
-        u32 P = 2;
-        while (P < m) P <<= 1;
-        u32 mask = 0;
-        for (u32 t = threadIdx.x; t < P; t += DEBWT_BLOCK) {
-            if (t < m) {
-                u64 e = blue[b0 + t];
-                en[t] = e;
-                k0[t] = sp_window(spn, e >> 4);
-                mask |= 1u << (e & 15);
-            } else {
-                en[t] = ~0ull; k0[t] = ~0ull;
-            }
-        }
-        if (mask) atomicOr(&seen, mask);
-        __syncthreads();
-        u32 sm = seen;
-        if (sm & (sm - 1)) {                                  // >= 2 distinct symbols: sort (src/sortBlue.c:192-219)
-            for (u32 kk = 2; kk <= P; kk <<= 1) {
-                for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
-                    for (u32 t = threadIdx.x; t < (P >> 1); t += DEBWT_BLOCK) {
-                        u32 i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
-                        u32 l = i | jj;
-                        bool up = (i & kk) == 0;
-                        u64 ka = k0[i], kb = k0[l], ea = en[i], eb = en[l];
-                        bool lt;   // element l sorts before element i
-                        if (ka != kb) lt = kb < ka;
-                        else if (ea == ~0ull || eb == ~0ull) lt = eb < ea;
-                        else lt = sp_less_deep(spn, S, eb, ea);
-                        if (lt == up) { k0[i] = kb; k0[l] = ka; en[i] = eb; en[l] = ea; }
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-        for (u32 t = threadIdx.x; t < m; t += DEBWT_BLOCK) {
-            u64 e = en[t];
-            blue[b0 + t] = e;
-            mchar[j0 + t] = (u8)(e & 15);
-        }
-        __syncthreads();
-    }
-}
 
 // large blocks: bitonic network in global memory, one launch per compare-exchange distance
 __global__ void k_large_load(const u64 *__restrict__ blue, u64 b0, u32 m, u64 P, const u64 *__restrict__ spn,
