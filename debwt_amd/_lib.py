@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdebwt_hip.so")
+LIB_PATH = os.environ.get("DEBWT_HIP_LIB", os.path.join(_HERE, "libdebwt_hip.so"))   # override: kernel experiments only
 _lib = None
 
 

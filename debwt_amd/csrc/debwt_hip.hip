@@ -49,7 +49,8 @@ struct debwt_ctx {
     // device buffers
     DevBuf text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, pidx, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
-        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits;
+        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew;
+    u32 *h_over = nullptr;      // pinned mirror of rs_over
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
     int pbits = 8;
@@ -134,6 +135,9 @@ inline u32 grid_for(u64 n, u32 block) { return (u32)((n + block - 1) / block); }
 RadixWorkspace radix_ws(debwt_ctx *c) {
     RadixWorkspace ws{};
     ws.counts = c->rs_counts.as<u32>();
+    ws.over = c->rs_over.as<u32>();
+    ws.h_over = c->h_over;
+    ws.skew_list = c->rs_skew.as<u32>();
     return ws;
 }
 
@@ -177,7 +181,7 @@ extern "C" int debwt_create(const debwt_config *cfg, debwt_ctx **out) {
     debwt_ctx *c = new (std::nothrow) debwt_ctx();
     if (!c) return DEBWT_ENOMEM;
     c->cfg = *cfg;
-    if (c->cfg.sort_algo == 0) c->cfg.sort_algo = 1;
+    if (c->cfg.sort_algo == 0) c->cfg.sort_algo = 3;
     c->K = cfg->k - 1;
     int rc = DEBWT_OK;
     auto fail = [&](int code) { debwt_destroy(c); return code; };
@@ -188,6 +192,9 @@ extern "C" int debwt_create(const debwt_config *cfg, debwt_ctx **out) {
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) return fail(DEBWT_EDEVICE);
     for (auto &p : c->ev_pass) for (auto &e : p) if (hipEventCreate(&e) != hipSuccess) return fail(DEBWT_EDEVICE);
     if ((rc = ensure(c, c->rs_counts, radix_workspace_bytes(0))) != DEBWT_OK) return fail(rc);
+    if ((rc = ensure(c, c->rs_over, radix_over_bytes())) != DEBWT_OK) return fail(rc);
+    if (hipHostMalloc((void **)&c->h_over, radix_over_bytes(), hipHostMallocDefault) != hipSuccess)
+        return fail(DEBWT_ENOMEM);
     if ((rc = ensure(c, c->cp_counts, 8 * (CP_MAXCHUNKS + 16) * sizeof(u32))) != DEBWT_OK) return fail(rc);
     if ((rc = ensure(c, c->dollar, 64)) != DEBWT_OK) return fail(rc);
     *out = c;
@@ -202,9 +209,10 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q, &c->pidx,
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
-                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits};
+                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->h_over) (void)hipHostFree(c->h_over);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &p : c->ev_pass) for (auto &e : p) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -241,6 +249,7 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     // workspace that depends only on n
     ENSURE(c, c->keysA, M * 8 + 64);
     ENSURE(c, c->keysB, M * 8 + 64);
+    ENSURE(c, c->rs_skew, (M / 2048 + 2) * 4);
     ENSURE(c, c->dk, M * 8 + 64);
     ENSURE(c, c->dstart, M * 4 + 64);
     ENSURE(c, c->mchar, M + 64);
@@ -353,6 +362,7 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     c->nfacts = nf;
     ENSURE(c, c->facts, nf * 8 + 64);
     ENSURE(c, c->facts_tmp, nf * 8 + 64);
+    ENSURE(c, c->rs_skew, (nf / 2048 + 2) * 4);
     ENSURE(c, c->red, nf * 8 + 64);
     ENSURE(c, c->red_q, nf * 4 + 64);
     ENSURE(c, c->mi_j0, Q * 4 + 64);
@@ -687,6 +697,7 @@ extern "C" int debwt_radix_sort_u64(debwt_ctx *c, uint64_t *d_keys, uint64_t *d_
     if (!c || !d_keys || !d_tmp || key_bits < 1 || key_bits > 64) return DEBWT_EINVAL;
     if (count >= 0xFFFFFFF0ull) return DEBWT_ERANGE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    ENSURE(c, c->rs_skew, (count / 2048 + 2) * 4);
     RadixWorkspace ws = radix_ws(c);
     hipError_t e = hipSuccess;
     int np = 0;

@@ -5,23 +5,29 @@
 #include "common.h"
 
 #define RS_BLOCK 256
+#ifndef RS_ITEMS
 #define RS_ITEMS 16
+#endif
 #define RS_TILE (RS_BLOCK * RS_ITEMS)   // keys ranked per workgroup iteration
 #define RS_MAXCHUNKS 2048               // workgroups per pass (8 per CU)
 #define RS_RADIX 256
 
 struct RadixWorkspace {
-    u32 *counts;        // [RS_RADIX][RS_MAXCHUNKS] digit-major chunk histograms / offsets
-    u32 *lookback;      // single-sweep path: tile status words
-    u64 lookback_words; // capacity of `lookback` in u32
-    u32 *tile_counter;  // single-sweep path: dynamic tile ids, one per pass
+    u32 *counts;        // [RS_RADIX][RS_MAXCHUNKS + 1] digit-major chunk histograms / offsets + digit totals
+    u32 *over;          // hybrid path: [0] = number of oversize tiles, then RS_OVER_CAP (start,len) u64 pairs at +16 B
+    u32 *h_over;        // pinned host mirror of `over` (same size)
+    u32 *skew_list;     // hybrid path: ids of tiles finished by the LDS LSD kernel (one u32 per tile)
 };
+#define RS_OVER_CAP 4096
 
 size_t radix_workspace_bytes(u64 max_keys);
+size_t radix_over_bytes();
 
 // Sorts `n` keys ascending on their low `key_bits` bits.  a: input; b: scratch of n words.
 // Returns the buffer (a or b) that holds the result.  All work is enqueued on `stream`.
-// algo: 1 = histogram + scan + scatter per pass; 2 = single-sweep passes with decoupled look-back.
+// algo: 1 = LSD: histogram + scan + scatter per 8-bit digit, all digits in HBM;
+//       3 = hybrid (default): the top digits by the same LSD passes until buckets are a few keys long
+//           ("k-mer prefix bucketing"), then one kernel that finishes every bucket inside LDS.
 // pass_events (optional): max_pairs pairs of hipEvents; pair i is recorded on `stream` right before and
 // after the scatter kernel of pass i (no synchronisation); *npairs receives the number recorded.
 u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, const RadixWorkspace &ws,

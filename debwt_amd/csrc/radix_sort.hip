@@ -9,6 +9,10 @@
 // tile in LDS in digit order, then coalesced stores of each digit's run.
 #include "radix_sort.h"
 
+#include <algorithm>
+#include <utility>
+#include <vector>
+
 // ---------------------------------------------------------------------------------------------------
 // algo 1
 
@@ -143,6 +147,137 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// hybrid: local finish of prefix buckets in LDS
+
+#define RL_H (RS_TILE * 3 / 4) // tile stride: tile j starts at the first bucket boundary at or after j*RL_H
+#define RL_CAP RS_TILE      // keys a workgroup can finish in LDS
+
+// first index i >= x (0 < x < n) where the bucket prefix changes (or n); one wave, all lanes return it
+__device__ __forceinline__ u64 rl_boundary(const u64 *__restrict__ keys, u64 n, u64 x, int pshift) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 p = keys[x - 1] >> pshift;
+    for (u64 base = x; base < x + (RL_CAP - RL_H); base += 64) {
+        u64 i = base + lane;
+        bool diff = i >= n || (keys[i] >> pshift) != p;
+        u64 mk = __ballot(diff);
+        if (mk) return base + (u64)__ffsll((long long)mk) - 1;
+    }
+    u64 lo = x + (RL_CAP - RL_H), hi = n;         // a run that overflows the tile: bisect for its end
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if ((keys[mid] >> pshift) <= p) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// keys are ordered by their top (key_bits - pshift) bits.  Tile j = [B(j*RL_H), B((j+1)*RL_H)) with B(x) the
+// first bucket boundary >= x, so tiles are disjoint and bucket-aligned, and hold < RL_CAP keys unless a bucket
+// overshoots a tile start by more than RL_CAP - RL_H.  A tile is finished by one workgroup: a bitonic network
+// over RL_CAP keys held 16 per thread in registers (blocked layout: 42 of the 78 steps never leave the thread,
+// 33 are wave shuffles, 3 go through LDS) -- its cost does not depend on the key distribution, so runs of equal
+// k-mers (repeat families) cost the same as unique ones.  A tile that does not fit is queued for the HBM path.
+__device__ __forceinline__ void rl_tile_bounds(const u64 *__restrict__ keys, u64 n, int pshift, u64 j, u64 *sb) {
+    const u32 tid = threadIdx.x;
+    const u64 x0 = j * RL_H, x1 = x0 + RL_H;
+    if ((tid >> 6) == 0) { u64 v = x0 == 0 ? 0 : rl_boundary(keys, n, x0, pshift); if (tid == 0) sb[0] = v; }
+    if ((tid >> 6) == 1) { u64 v = x1 >= n ? n : rl_boundary(keys, n, x1, pshift); if (tid == 64) sb[1] = v; }
+}
+
+#define RL_PAD(x) ((x) + ((x) >> 4))          // one spare word per 16: blocked 128-byte reads hit distinct banks
+
+__device__ __forceinline__ void rl_cex(u64 &a, u64 &b, bool up) {      // (a,b) ascending when up
+    bool sw = (a > b) == up;
+    u64 lo = sw ? b : a, hi = sw ? a : b;
+    a = lo; b = hi;
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void rs_local_kernel(u64 *__restrict__ keys, u64 n, int pshift,
+                                                             u32 *__restrict__ over) {
+    constexpr int KPT = RL_CAP / RS_BLOCK;        // 16 keys per thread
+    constexpr int LOGN = 12;                      // RL_CAP = 4096
+    static_assert(RL_CAP == 4096 && KPT == 16, "network below is laid out for 4096 keys, 16 per thread");
+    __shared__ u64 A[RL_CAP + RL_CAP / 16];
+    __shared__ u64 sb[2];
+    const u32 tid = threadIdx.x;
+    rl_tile_bounds(keys, n, pshift, blockIdx.x, sb);
+    __syncthreads();
+    const u64 s = sb[0], e = sb[1];
+    if (s >= e) return;
+    const u64 cnt64 = e - s;
+    if (cnt64 > RL_CAP) {
+        if (tid == 0) {
+            u32 idx = atomicAdd(&over[0], 1u);
+            if (idx < RS_OVER_CAP) {
+                u64 *list = reinterpret_cast<u64 *>(over + 4);
+                list[2 * idx] = s; list[2 * idx + 1] = cnt64;
+            }
+        }
+        return;
+    }
+    const u32 cnt = (u32)cnt64;
+    for (u32 i = tid; i < RL_CAP; i += RS_BLOCK) A[RL_PAD(i)] = i < cnt ? keys[s + i] : ~0ull;
+    __syncthreads();
+    u64 k[KPT];
+#pragma unroll
+    for (int r = 0; r < KPT; r++) k[r] = A[RL_PAD(tid * KPT + r)];
+    __syncthreads();
+#pragma unroll
+    for (int lk = 1; lk <= LOGN; lk++) {
+        const u32 kk = 1u << lk;
+#pragma unroll
+        for (int lj = lk - 1; lj >= 0; lj--) {
+            if (lj < 4) {                                         // partner in the same thread
+                const int jj = 1 << lj;
+#pragma unroll
+                for (int r = 0; r < KPT; r++)
+                    if ((r & jj) == 0) rl_cex(k[r], k[r | jj], ((tid * KPT + r) & kk) == 0);
+            } else if (lj < 10) {                                 // partner lane in the same wave
+                const int dl = 1 << (lj - 4);
+                const bool lower = (tid & dl) == 0;
+#pragma unroll
+                for (int r = 0; r < KPT; r++) {
+                    u64 pk = __shfl_xor(k[r], dl, 64);
+                    bool up = ((tid * KPT + r) & kk) == 0;
+                    bool take_min = lower == up;
+                    bool pless = pk < k[r];
+                    k[r] = (take_min == pless) ? pk : k[r];
+                }
+            } else {                                              // partner in another wave: through LDS
+                const u32 dt = 1u << (lj - 4);
+#pragma unroll
+                for (int r = 0; r < KPT; r++) A[RL_PAD(tid * KPT + r)] = k[r];
+                __syncthreads();
+                const bool lower = (tid & dt) == 0;
+#pragma unroll
+                for (int r = 0; r < KPT; r++) {
+                    u64 pk = A[RL_PAD((tid ^ dt) * KPT + r)];
+                    bool up = ((tid * KPT + r) & kk) == 0;
+                    bool take_min = lower == up;
+                    bool pless = pk < k[r];
+                    k[r] = (take_min == pless) ? pk : k[r];
+                }
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < KPT; r++) A[RL_PAD(tid * KPT + r)] = k[r];
+    __syncthreads();
+    for (u32 i = tid; i < cnt; i += RS_BLOCK) keys[s + i] = A[RL_PAD(i)];
+}
+
+// oversize tiles: gather their keys into one contiguous scratch array / copy the sorted result back
+__global__ void rs_over_move(u64 *__restrict__ keys, u64 *__restrict__ scratch, const u64 *__restrict__ list,
+                             const u64 *__restrict__ offs, u32 nranges, u64 total, int back) {
+    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    u32 lo = 0, hi = nranges;
+    while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= g) lo = mid; else hi = mid; }
+    u64 src = list[2 * lo] + (g - offs[lo]);
+    if (back) keys[src] = scratch[g]; else scratch[g] = keys[src];
+}
+
+// ---------------------------------------------------------------------------------------------------
 
 size_t radix_workspace_bytes(u64 max_keys) {
     (void)max_keys;
@@ -160,30 +295,86 @@ static void rs_plan(u64 n, u32 *nchunks, u64 *chunk) {
     if (*nchunks == 0) *nchunks = 1;
 }
 
-u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, const RadixWorkspace &ws, int algo,
-                    hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err) {
-    (void)algo;
-    *err = hipSuccess;
-    if (npairs) *npairs = 0;
-    if (n < 2 || key_bits <= 0) return a;
-    if (key_bits > 64) key_bits = 64;
+size_t radix_over_bytes() { return 16 + (size_t)RS_OVER_CAP * 16 + 16; }
+
+static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
+                   hipEvent_t *pass_events, int max_pairs, int *npairs) {
+    // stable LSD passes over bits [lo_bit, hi_bit), 8 bits per pass starting at lo_bit
     u32 nchunks; u64 chunk;
     rs_plan(n, &nchunks, &chunk);
-    int passes = (key_bits + 7) / 8;
     u64 *src = a, *dst = b;
-    for (int p = 0; p < passes; p++) {
-        int shift = 8 * p;
-        int bits = key_bits - shift < 8 ? key_bits - shift : 8;
+    int p = 0;
+    for (int shift = lo_bit; shift < hi_bit; shift += 8, p++) {
+        int bits = hi_bit - shift < 8 ? hi_bit - shift : 8;
         u32 mask = (1u << bits) - 1u;
         bool ev = pass_events && p < max_pairs;
-        rs_hist_kernel<<<nchunks, RS_BLOCK, 0, stream>>>(src, n, chunk, shift, mask, ws.counts, nchunks);
         u32 *digit_tot = ws.counts + (size_t)RS_RADIX * RS_MAXCHUNKS;
+        rs_hist_kernel<<<nchunks, RS_BLOCK, 0, stream>>>(src, n, chunk, shift, mask, ws.counts, nchunks);
         rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
         rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
         if (ev) (void)hipEventRecord(pass_events[2 * p], stream);
         rs_scatter_kernel<<<nchunks, RS_BLOCK, 0, stream>>>(src, dst, n, chunk, shift, mask, ws.counts, digit_tot, nchunks);
         if (ev) { (void)hipEventRecord(pass_events[2 * p + 1], stream); if (npairs) *npairs = p + 1; }
         u64 *t = src; src = dst; dst = t;
+    }
+    return src;
+}
+
+u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, const RadixWorkspace &ws, int algo,
+                    hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err) {
+    *err = hipSuccess;
+    if (npairs) *npairs = 0;
+    if (n < 2 || key_bits <= 0) return a;
+    if (key_bits > 64) key_bits = 64;
+    // hybrid: T top digits in HBM so that a bucket holds <= ~16 keys on average, the rest in LDS
+    int T = 0;
+    while ((n >> (8 * T)) > 16 && T < 4) T++;
+    if (algo != 3 || T == 0 || key_bits - 8 * T < 1 || !ws.over || !ws.h_over) {
+        u64 *r = rs_lsd(stream, a, b, n, 0, key_bits, ws, pass_events, max_pairs, npairs);
+        *err = hipGetLastError();
+        return r;
+    }
+    const int pshift = key_bits - 8 * T;
+    u64 *src = rs_lsd(stream, a, b, n, pshift, key_bits, ws, pass_events, max_pairs, npairs);
+    u64 *other = src == a ? b : a;
+    (void)hipMemsetAsync(ws.over, 0, 16, stream);
+    u32 ntiles = (u32)((n + RL_H - 1) / RL_H);
+    rs_local_kernel<<<ntiles, RS_BLOCK, 0, stream>>>(src, n, pshift, ws.over);
+    (void)hipMemcpyAsync(ws.h_over, ws.over, 16, hipMemcpyDeviceToHost, stream);
+    if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;
+    u32 nover = ws.h_over[0];
+    if (nover) {
+        // heavy buckets (low-complexity k-mers): finish them together with the all-HBM passes
+        bool whole = nover > RS_OVER_CAP;
+        u64 total = 0;
+        std::vector<u64> offs;
+        if (!whole) {
+            (void)hipMemcpyAsync(ws.h_over, ws.over, radix_over_bytes(), hipMemcpyDeviceToHost, stream);
+            if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;
+            u64 *list = reinterpret_cast<u64 *>(ws.h_over + 4);
+            // ascending by start: the sorted scratch array maps back onto the ranges in address order
+            std::vector<std::pair<u64, u64>> rg(nover);
+            for (u32 i = 0; i < nover; i++) rg[i] = {list[2 * i], list[2 * i + 1]};
+            std::sort(rg.begin(), rg.end());
+            offs.resize(3 * (size_t)nover);
+            for (u32 i = 0; i < nover; i++) {
+                offs[i] = total; total += rg[i].second;
+                offs[nover + 2 * i] = rg[i].first; offs[nover + 2 * i + 1] = rg[i].second;
+            }
+            if (2 * total + 3 * (u64)nover > n) whole = true;
+        }
+        if (whole) {
+            src = rs_lsd(stream, src, other, n, 0, key_bits, ws, nullptr, 0, nullptr);
+        } else {
+            u64 *scratch = other, *tmp = other + total, *d_offs = other + 2 * total;
+            (void)hipMemcpyAsync(d_offs, offs.data(), 3 * (size_t)nover * 8, hipMemcpyHostToDevice, stream);
+            const u64 *d_list = d_offs + nover;
+            u32 grid = (u32)((total + 255) / 256);
+            rs_over_move<<<grid, 256, 0, stream>>>(src, scratch, d_list, d_offs, nover, total, 0);
+            u64 *r = rs_lsd(stream, scratch, tmp, total, 0, key_bits, ws, nullptr, 0, nullptr);
+            rs_over_move<<<grid, 256, 0, stream>>>(src, r, d_list, d_offs, nover, total, 1);
+            if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;   // offs is host memory
+        }
     }
     *err = hipGetLastError();
     return src;

@@ -37,7 +37,7 @@ typedef struct debwt_ctx debwt_ctx;
 typedef struct {
     int k;          /* edge length, KMER_LENGTH_PlusOne, 12..32 (src/main.c:41-47); node = k-1 */
     int device;     /* HIP device ordinal */
-    int sort_algo;  /* 0 = default; 1 = histogram+scatter LSD passes; 2 = single-sweep look-back passes */
+    int sort_algo;  /* 0 = default (3); 1 = all digits by LSD passes in HBM; 3 = top digits in HBM, rest in LDS */
     int reserved;
 } debwt_config;
 

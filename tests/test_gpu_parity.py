@@ -207,6 +207,49 @@ def test_radix_sort_primitive(api, count, bits):
     d.close()
 
 
+@pytest.mark.parametrize("case", ["all_equal", "few_values", "medium_buckets", "huge_and_small", "sorted", "reverse"])
+@pytest.mark.parametrize("algo", [1, 3])
+def test_radix_sort_skewed(api, case, algo):
+    """Bucket shapes the hybrid sort treats differently: long runs of equal keys (HBM fallback), buckets of
+    hundreds of keys (LSD inside LDS), tiny buckets (rank by counting)."""
+    import torch
+    rng = np.random.default_rng(99)
+    n = 3_000_000
+    if case == "all_equal":
+        keys = np.full(n, 0x0123456789ABCDEF, dtype=np.uint64)
+    elif case == "few_values":
+        keys = rng.choice(rng.integers(0, 2 ** 63, size=7, dtype=np.uint64), size=n)
+    elif case == "medium_buckets":
+        keys = (rng.integers(0, 3000, size=n, dtype=np.uint64) << np.uint64(44)) | rng.integers(0, 2 ** 30, size=n, dtype=np.uint64)
+    elif case == "huge_and_small":
+        keys = rng.integers(0, 2 ** 63, size=n, dtype=np.uint64)
+        keys[:700_000] = (np.uint64(0xABCDEF) << np.uint64(40)) | rng.integers(0, 2 ** 20, size=700_000, dtype=np.uint64)
+        keys[700_000:760_000] = np.uint64(42)
+        rng.shuffle(keys)
+    elif case == "sorted":
+        keys = np.sort(rng.integers(0, 2 ** 63, size=n, dtype=np.uint64))
+    else:
+        keys = np.sort(rng.integers(0, 2 ** 63, size=n, dtype=np.uint64))[::-1].copy()
+    ref = np.sort(keys)
+    dk = torch.from_numpy(keys.view(np.int64)).cuda()
+    tmp = torch.empty_like(dk)
+    d = api.DeBWT(k=32, sort_algo=algo)
+    d.radix_sort_device(dk.data_ptr(), tmp.data_ptr(), n, 64)
+    assert np.array_equal(dk.cpu().numpy().view(np.uint64), ref)
+    d.close()
+
+
+def test_sort_algorithms_agree_end_to_end(api):
+    from debwt_amd import synth
+    recs = synth.pan_genome(1_500_000, 3)
+    outs = []
+    for algo in (1, 3):
+        d, out, st = _run(api, recs, 32, algo=algo)
+        outs.append(out)
+        d.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
 def test_stage_order_and_errors(api):
     from debwt_amd import synth
     with pytest.raises(api.DebwtError):
