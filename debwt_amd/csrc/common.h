@@ -94,3 +94,39 @@ __device__ __forceinline__ u32 block_scan_excl(u32 v, u32 *smem, u32 *total) {
     *total = sum;
     return base + incl - v;
 }
+
+// exclusive scans of V independent values per thread over a 256-thread block (one pair of barriers for all V);
+// tot[v] = block sum of value v.  smem: >= V*DEBWT_WAVES u32.
+template <int V>
+__device__ __forceinline__ void block_scan_excl_vec(const u32 (&val)[V], u32 (&excl)[V], u32 (&tot)[V], u32 *smem) {
+    u32 incl[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) incl[v] = val[v];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            u32 t = __shfl_up(incl[v], d, 64);
+            if ((int)lane_id() >= d) incl[v] += t;
+        }
+    }
+    const u32 w = threadIdx.x >> 6;
+    if (lane_id() == 63) {
+#pragma unroll
+        for (int v = 0; v < V; v++) smem[v * DEBWT_WAVES + w] = incl[v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        u32 base = 0, sum = 0;
+#pragma unroll
+        for (u32 i = 0; i < DEBWT_WAVES; i++) {
+            u32 t = smem[v * DEBWT_WAVES + i];
+            if (i < w) base += t;
+            sum += t;
+        }
+        excl[v] = base + incl[v] - val[v];
+        tot[v] = sum;
+    }
+    __syncthreads();
+}

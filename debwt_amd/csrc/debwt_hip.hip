@@ -83,11 +83,12 @@ int ensure(debwt_ctx *c, DevBuf &b, size_t bytes) {
 #define ENSURE(c, b, bytes) do { int r_ = ensure((c), (b), (bytes)); if (r_) return r_; } while (0)
 
 void plan_chunks(u64 n, u32 *nchunks, u64 *chunk) {
-    u64 tiles = (n + DEBWT_BLOCK - 1) / DEBWT_BLOCK;
+    const u64 DEBWT_TILE = (u64)DEBWT_BLOCK * CP_VEC;
+    u64 tiles = (n + DEBWT_TILE - 1) / DEBWT_TILE;
     u64 c = tiles < CP_MAXCHUNKS ? tiles : CP_MAXCHUNKS;
     if (c == 0) c = 1;
     u64 per = (tiles + c - 1) / c;
-    *chunk = per * DEBWT_BLOCK;
+    *chunk = per * DEBWT_TILE;
     *nchunks = (u32)((n + *chunk - 1) / *chunk);
     if (*nchunks == 0) *nchunks = 1;
 }
@@ -351,8 +352,6 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     // pflag (n bytes) is free until the SP stage: it holds the per-distinct-key classification byte
     u8 *cf = c->pflag.as<u8>();
     ClassifyFlagsF ff{cc, c->K, cf};
-    MultiInF fin{cc, cf, nullptr, nullptr, nullptr};
-    MultiOutF fout{cc, c->K, cf, nullptr};
     if ((rc = cp_count2(c, ff, D, cp_area(c, 1), 1, cp_area(c, 2), 2))) return rc;
     if ((rc = sync_check(c))) return rc;
     c->Q = c->h_scalars[1];
@@ -372,10 +371,12 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     ENSURE(c, c->large_q, Q * 4 + 64);
     // fact list = [multi-out facts | tail# facts | multi-in facts]
     u64 *facts = c->facts.as<u64>();
-    fout.mo_fact = facts;
-    fin.mi_fact = facts + Rmo + nrec; fin.mi_j0 = c->mi_j0.as<u32>(); fin.mi_freq = c->mi_freq.as<u32>();
-    if ((rc = cp_emit(c, fout, D, cp_area(c, 2)))) return rc;
-    if ((rc = cp_emit(c, fin, D, cp_area(c, 1)))) return rc;
+    {
+        FactEmitArgs fa{cc, c->K, cf, facts + Rmo + nrec, c->mi_j0.as<u32>(), c->mi_freq.as<u32>(), facts};
+        u32 nchunks; u64 chunk;
+        plan_chunks(D, &nchunks, &chunk);       // same chunks as the counting sweep (multiples of 1024 keys)
+        if (D) k_emit_facts<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(fa, chunk, cp_area(c, 1), cp_area(c, 2));
+    }
     HIPCHK(c, hipMemcpyAsync(facts + Rmo, c->special.tail_facts.data(), nrec * 8, hipMemcpyHostToDevice, c->stream));
     u64 *sorted_facts = nullptr;
     if ((rc = sort_keys(c, facts, c->facts_tmp.as<u64>(), nf, 2 * c->cfg.k, &sorted_facts, false))) return rc;
@@ -468,9 +469,13 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
     const u64 Q = c->Q;
     if (Q) {
         u32 g1 = (u32)std::min<u64>(Q, 1u << 16);
+        // small blocks are the bulk: a small LDS footprint keeps 32 single-wave workgroups per CU in flight
+        k_blue_refine<64, 128><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
+                                                        c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q, 0u,
+                                                        c->spn.as<u64>(), c->S, c->mchar.as<u8>());
         k_blue_refine<64, BLUE_WAVE_CAP><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
                                                                   c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q,
-                                                                  0u, c->spn.as<u64>(), c->S, c->mchar.as<u8>());
+                                                                  128u, c->spn.as<u64>(), c->S, c->mchar.as<u8>());
         u32 g2 = (u32)std::min<u64>(Q, 1u << 12);
         k_blue_refine<256, BLUE_LDS_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
                                                                    c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q,

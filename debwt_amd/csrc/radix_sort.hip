@@ -149,7 +149,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
 // ---------------------------------------------------------------------------------------------------
 // hybrid: local finish of prefix buckets in LDS
 
-#define RL_H (RS_TILE * 3 / 4) // tile stride: tile j starts at the first bucket boundary at or after j*RL_H
+#define RL_H (RS_TILE * 7 / 8) // tile stride: tile j starts at the first bucket boundary at or after j*RL_H
 #define RL_CAP RS_TILE      // keys a workgroup can finish in LDS
 
 // first index i >= x (0 < x < n) where the bucket prefix changes (or n); one wave, all lanes return it

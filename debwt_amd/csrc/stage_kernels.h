@@ -12,13 +12,19 @@
 
 #define CP_MAXCHUNKS 2048
 
+#define CP_VEC 4   // consecutive elements per thread per iteration (independent loads in flight)
+
 template <class F>
 __global__ __launch_bounds__(DEBWT_BLOCK) void cp_count_kernel(F f, u64 n, u64 chunk, u32 *__restrict__ counts) {
     __shared__ u32 red[DEBWT_WAVES];
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < n ? beg + chunk : n;
     u32 local = 0;
-    for (u64 i = beg + threadIdx.x; i < end; i += DEBWT_BLOCK) local += f.count(i);
+    for (u64 i = beg + threadIdx.x; i < end; i += DEBWT_BLOCK * CP_VEC) {
+#pragma unroll
+        for (int v = 0; v < CP_VEC; v++)
+            if (i + (u64)v * DEBWT_BLOCK < end) local += f.count(i + (u64)v * DEBWT_BLOCK);
+    }
     u32 incl = wave_scan_incl(local);
     if (lane_id() == 63) red[threadIdx.x >> 6] = incl;
     __syncthreads();
@@ -37,10 +43,15 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void cp_count2_kernel(F f, u64 n, u64 
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < n ? beg + chunk : n;
     u32 la = 0, lb = 0;
-    for (u64 i = beg + threadIdx.x; i < end; i += DEBWT_BLOCK) {
-        u32 a, b;
-        f.count2(i, &a, &b);
-        la += a; lb += b;
+    for (u64 i = beg + threadIdx.x; i < end; i += DEBWT_BLOCK * CP_VEC) {
+#pragma unroll
+        for (int v = 0; v < CP_VEC; v++) {
+            if (i + (u64)v * DEBWT_BLOCK < end) {
+                u32 a, b;
+                f.count2(i + (u64)v * DEBWT_BLOCK, &a, &b);
+                la += a; lb += b;
+            }
+        }
     }
     u32 ia = wave_scan_incl(la), ib = wave_scan_incl(lb);
     if (lane_id() == 63) { red[0][threadIdx.x >> 6] = ia; red[1][threadIdx.x >> 6] = ib; }
@@ -72,17 +83,25 @@ __global__ __launch_bounds__(1024) void cp_scan_kernel(u32 *__restrict__ counts,
 
 template <class F>
 __global__ __launch_bounds__(DEBWT_BLOCK) void cp_emit_kernel(F f, u64 n, u64 chunk, const u32 *__restrict__ offsets) {
-    __shared__ u32 tmp[8];
+    __shared__ u32 tmp[CP_VEC * DEBWT_WAVES];
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < n ? beg + chunk : n;
     u32 base = offsets[blockIdx.x];
-    for (u64 tile = beg; tile < end; tile += DEBWT_BLOCK) {
-        u64 i = tile + threadIdx.x;
-        u32 c = i < end ? f.recount(i) : 0;
-        u32 tot;
-        u32 off = block_scan_excl(c, tmp, &tot);
-        if (i < end) f.emit(i, base + off, c);
-        base += tot;
+    // element (v, tid) of a tile is tile + v*256 + tid: coalesced loads, CP_VEC of them in flight per thread
+    for (u64 tile = beg; tile < end; tile += DEBWT_BLOCK * CP_VEC) {
+        u32 c[CP_VEC], ex[CP_VEC], tot[CP_VEC];
+#pragma unroll
+        for (int v = 0; v < CP_VEC; v++) {
+            u64 i = tile + (u64)v * DEBWT_BLOCK + threadIdx.x;
+            c[v] = i < end ? f.recount(i) : 0;
+        }
+        block_scan_excl_vec<CP_VEC>(c, ex, tot, tmp);
+#pragma unroll
+        for (int v = 0; v < CP_VEC; v++) {
+            u64 i = tile + (u64)v * DEBWT_BLOCK + threadIdx.x;
+            if (i < end) f.emit(i, base + ex[v], c[v]);
+            base += tot[v];
+        }
     }
 }
 
@@ -195,39 +214,83 @@ struct ClassifyFlagsF {
     int K;
     u8 *cf;
     __device__ void count2(u64 e, u32 *a, u32 *b) const {
-        u32 fr;
-        u32 mi = eval_multi_in(c, e, &fr) ? 1u : 0u;
-        u32 mo = eval_multi_out(c, K, e, nullptr);
+        // fast path: a (K-1)-prefix group of one key is one node with one predecessor: it can only be
+        // multi-in as a record start, and it contributes no multi-out fact
+        const u64 k = c.dk[e], W = k >> 4;
+        const bool alone = (e == 0 || (c.dk[e - 1] >> 4) != W) && (e + 1 >= c.D || (c.dk[e + 1] >> 4) != W);
+        u32 mi, mo;
+        if (alone) {
+            mi = ((k & 3) == 3 && c.is_head(k >> 2)) ? 1u : 0u;
+            mo = 0;
+        } else {
+            u32 fr;
+            mi = eval_multi_in(c, e, &fr) ? 1u : 0u;
+            mo = eval_multi_out(c, K, e, nullptr);
+        }
         cf[e] = (u8)(mi | (mo << 1));
         *a = mi; *b = mo;
     }
 };
-struct MultiInF {
-    ClassifyCommon c;
-    const u8 *cf;
-    u64 *mi_fact; u32 *mi_j0; u32 *mi_freq;
-    __device__ u32 recount(u64 e) const { return cf[e] & 1u; }
-    __device__ void emit(u64 e, u32 off, u32 cnt) const {
-        if (!cnt) return;
-        u32 fr; eval_multi_in(c, e, &fr);
-        mi_fact[off] = ((c.dk[e] >> 2) << 2) | 2ull;
-        mi_j0[off] = c.dstart[e];
-        mi_freq[off] = fr;
-    }
-};
-struct MultiOutF {
+// ordered compaction of both fact kinds from the classification bytes: every thread owns 16 consecutive
+// bytes (one 16-byte load); one block scan per 4096 distinct keys carries both running offsets
+struct FactEmitArgs {
     ClassifyCommon c;
     int K;
     const u8 *cf;
+    u64 *mi_fact; u32 *mi_j0; u32 *mi_freq;
     u64 *mo_fact;
-    __device__ u32 recount(u64 e) const { return cf[e] >> 1; }
-    __device__ void emit(u64 e, u32 off, u32 cnt) const {
-        if (!cnt) return;
-        u64 facts[4];
-        eval_multi_out(c, K, e, facts);
-        for (u32 m = 0; m < cnt; m++) mo_fact[off + m] = facts[m];
-    }
 };
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_emit_facts(FactEmitArgs a, u64 chunk, const u32 *__restrict__ off_mi,
+                                                             const u32 *__restrict__ off_mo) {
+    __shared__ u32 tmp[2 * DEBWT_WAVES];
+    const u64 D = a.c.D;
+    u64 beg = (u64)blockIdx.x * chunk;
+    u64 end = beg + chunk < D ? beg + chunk : D;
+    u32 base_mi = off_mi[blockIdx.x], base_mo = off_mo[blockIdx.x];
+    for (u64 tile = beg; tile < end; tile += DEBWT_BLOCK * 16) {
+        u64 e0 = tile + (u64)threadIdx.x * 16;
+        u32 w[4] = {0, 0, 0, 0};
+        if (e0 + 16 <= end) {
+            uint4 v = *reinterpret_cast<const uint4 *>(a.cf + e0);      // chunk and tile are multiples of 16
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            for (u32 t = 0; t < 16; t++)
+                if (e0 + t < end) w[t >> 2] |= (u32)a.cf[e0 + t] << ((t & 3) * 8);
+        }
+        u32 val[2] = {0, 0}, ex[2], tot[2];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            val[0] += __popc(w[q] & 0x01010101u);
+            u32 m = (w[q] >> 1) & 0x07070707u;
+            val[1] += (m & 0xFF) + ((m >> 8) & 0xFF) + ((m >> 16) & 0xFF) + (m >> 24);
+        }
+        block_scan_excl_vec<2>(val, ex, tot, tmp);
+        if (val[0] | val[1]) {
+            u32 omi = base_mi + ex[0], omo = base_mo + ex[1];
+            for (u32 t = 0; t < 16; t++) {
+                u32 f = (w[t >> 2] >> ((t & 3) * 8)) & 0xFFu;
+                if (!f) continue;
+                u64 e = e0 + t;
+                if (f & 1u) {
+                    u32 fr;
+                    eval_multi_in(a.c, e, &fr);
+                    a.mi_fact[omi] = ((a.c.dk[e] >> 2) << 2) | 2ull;
+                    a.mi_j0[omi] = a.c.dstart[e];
+                    a.mi_freq[omi] = fr;
+                    omi++;
+                }
+                u32 cnt = f >> 1;
+                if (cnt) {
+                    u64 facts[4];
+                    eval_multi_out(a.c, a.K, e, facts);
+                    for (u32 m = 0; m < cnt; m++) a.mo_fact[omo + m] = facts[m];
+                    omo += cnt;
+                }
+            }
+        }
+        base_mi += tot[0]; base_mo += tot[1];
+    }
+}
 
 // red table: sorted fact list -> one entry per node, node<<2 | multiin<<1 | multiout
 // (redSeq analogue, src/INandOut.c:396-412).  Facts of one node sort as (X|1)...(X|1)(X|2).
@@ -325,27 +388,38 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
     const u64 kmask = (1ull << K) - 1ull;
     const u64 i0 = g << 5;
     u32 lim = (n - i0) < 32 ? (u32)(n - i0) : 32u;
+    const u32 inrange = lim == 32 ? 0xFFFFFFFFu : ((1u << lim) - 1u);
     u32 mo = 0, mi = 0;
-#pragma unroll 8
+    // phase 1 (no divergence): which positions hold a node that may be in the red table
+    u32 cand = 0, spec = 0;
+#pragma unroll
     for (u32 t = 0; t < 32; t++) {
-        if (t >= lim) break;
         u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
-        if ((sb >> t) & kmask) {
-            // special module: multi-out iff listed in specialBranch (src/generateSP.c:612-624)
-            if (nbranch) {
-                u64 i = i0 + t;
-                u64 lo = lower_bound_dev<u64>(branch, 0, nbranch, i);
-                if (lo < nbranch && branch[lo] == i) mo |= 1u << t;
-            }
-        } else {
-            u64 node = win >> (64 - 2 * K);
-            u64 hb = node >> (2 * K - pb);
-            if ((rbits[hb >> 5] >> (hb & 31)) & 1u) {
-                u32 fl;
-                red_lookup(red, pidx, K, p, node, &fl);
-                mo |= (fl & 1u) << t;
-                mi |= ((fl >> 1) & 1u) << t;
-            }
+        u64 hb = (win >> (64 - 2 * K)) >> (2 * K - pb);
+        u32 bit = (rbits[hb >> 5] >> (hb & 31)) & 1u;
+        cand |= bit << t;
+        spec |= (((sb >> t) & kmask) ? 1u : 0u) << t;
+    }
+    cand &= inrange & ~spec;
+    spec &= inrange;
+    // phase 2: only the candidates pay for the table search
+    while (cand) {
+        u32 t = (u32)__ffs(cand) - 1u;
+        cand &= cand - 1u;
+        u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
+        u32 fl;
+        red_lookup(red, pidx, K, p, win >> (64 - 2 * K), &fl);
+        mo |= (fl & 1u) << t;
+        mi |= ((fl >> 1) & 1u) << t;
+    }
+    // special module: multi-out iff listed in specialBranch (src/generateSP.c:612-624)
+    if (nbranch) {
+        while (spec) {
+            u32 t = (u32)__ffs(spec) - 1u;
+            spec &= spec - 1u;
+            u64 i = i0 + t;
+            u64 lo = lower_bound_dev<u64>(branch, 0, nbranch, i);
+            if (lo < nbranch && branch[lo] == i) mo |= 1u << t;
         }
     }
     momask[g] = mo;
