@@ -49,7 +49,7 @@ struct debwt_ctx {
     // device buffers
     DevBuf text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, pidx, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
-        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew;
+        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list;
     u32 *h_over = nullptr;      // pinned mirror of rs_over
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
@@ -210,7 +210,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q, &c->pidx,
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
-                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew};
+                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -405,7 +405,7 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     ENSURE(c, c->pidx, ((size_t)(1ull << p) + 2) * 4);
     k_build_pidx<<<grid_for((1ull << p) + 1, 256), 256, 0, c->stream>>>(c->red.as<u64>(), R, c->K, p, c->pidx.as<u32>());
     k_special_rows<<<grid_for(c->NS, 256), 256, 0, c->stream>>>(c->sk, M, c->spkey.as<u64>(), c->NS, c->sprow.as<u64>());
-    HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, Q * 4 + 4, c->stream));
+    ENSURE(c, c->cursor, R * 4 + 64);
     ENSURE(c, c->blue, c->B * 8 + 64);
     if ((rc = sync_check(c))) return rc;
     if (c->h_scalars[6] != Q) { c->err = "multi-in count mismatch between fact list and red table"; return DEBWT_EINTERNAL; }
@@ -442,13 +442,27 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
         c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->red.as<u64>(), c->pidx.as<u32>(), c->pbits,
         c->rbits.as<u32>(), pb, c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(),
         c->mimask.as<u32>(), ngroups);
-    SpF f{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->red.as<u64>(), c->pidx.as<u32>(), c->pbits,
-          c->red_q.as<u32>(), c->momask.as<u32>(), c->mimask.as<u32>(), c->spsym.as<u8>(), c->bstart.as<u32>(),
-          c->cursor.as<u32>(), c->blue.as<u64>()};
-    if ((rc = cp_count(c, f, ngroups, cp_area(c, 0), 8))) return rc;
-    if ((rc = cp_emit(c, f, ngroups, cp_area(c, 0)))) return rc;
+    if (c->n >= (1ull << 32)) { c->err = "n >= 2^32 needs prefix-range passes"; return DEBWT_ERANGE; }
+    if (c->R)
+        k_init_rcursor<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red_q.as<u32>(), c->bstart.as<u32>(), c->R,
+                                                                  c->cursor.as<u32>());
+    ENSURE(c, c->mi_list, c->B * 8 + 64);
+    SpCountF fc{c->momask.as<u32>(), c->mimask.as<u32>()};
+    if ((rc = cp_count2(c, fc, ngroups, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
+    {
+        SpEmitArgs ea{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->momask.as<u32>(), c->mimask.as<u32>(),
+                      c->spsym.as<u8>(), c->mi_list.as<u64>()};
+        u32 nchunks; u64 chunk;
+        plan_chunks(ngroups, &nchunks, &chunk);
+        k_sp_emit<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ea, ngroups, chunk, cp_area(c, 0), cp_area(c, 1));
+        if (c->B)
+            k_blue_fill<<<grid_for(c->B, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+                c->mi_list.as<u64>(), c->B, c->text.as<u64>(), c->sepbits.as<u64>(), c->K, c->red.as<u64>(),
+                c->pidx.as<u32>(), c->pbits, c->cursor.as<u32>(), c->blue.as<u64>());
+    }
     if ((rc = sync_check(c))) return rc;
     c->S = c->h_scalars[8];
+    if (c->h_scalars[10] != c->B) { c->err = "multi-in positions differ from the block total"; return DEBWT_EINTERNAL; }
     u64 nwords = (c->S >> 4) + 3;
     ENSURE(c, c->spn, nwords * 8);
     k_pack_sp<<<grid_for(nwords, 256), 256, 0, c->stream>>>(c->spsym.as<u8>(), c->S, nwords, c->spn.as<u64>());

@@ -43,12 +43,13 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void cp_count2_kernel(F f, u64 n, u64 
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < n ? beg + chunk : n;
     u32 la = 0, lb = 0;
-    for (u64 i = beg + threadIdx.x; i < end; i += DEBWT_BLOCK * CP_VEC) {
+    // CP_VEC consecutive elements per thread: the classification stencil re-reads its neighbours
+    for (u64 i = beg + (u64)threadIdx.x * CP_VEC; i < end; i += DEBWT_BLOCK * CP_VEC) {
 #pragma unroll
         for (int v = 0; v < CP_VEC; v++) {
-            if (i + (u64)v * DEBWT_BLOCK < end) {
+            if (i + v < end) {
                 u32 a, b;
-                f.count2(i + (u64)v * DEBWT_BLOCK, &a, &b);
+                f.count2(i + v, &a, &b);
                 la += a; lb += b;
             }
         }
@@ -313,6 +314,14 @@ struct RedBlockF {
     __device__ u32 recount(u64 r) const { return count(r); }
     __device__ void emit(u64 r, u32 off, u32 c) const { red_q[r] = c ? off : 0xFFFFFFFFu; }
 };
+// fill cursor of every multi-in red entry = first blue slot of its block (redPoint analogue, src/INandOut.c:413)
+__global__ void k_init_rcursor(const u32 *__restrict__ red_q, const u32 *__restrict__ bstart, u64 R,
+                               u32 *__restrict__ rcursor) {
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    u32 q = red_q[r];
+    rcursor[r] = q == 0xFFFFFFFFu ? 0u : bstart[q];
+}
 // exclusive scan of block sizes -> first blue slot of each block (blueBound analogue)
 struct BlockStartF {
     const u32 *mi_freq; u32 *bstart;
@@ -426,43 +435,68 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
     mimask[g] = mi;
 }
 
-// pass 2 (over groups of 32 positions): spIndex = exclusive scan of the multi-out bits; SP symbols and blue
-// entries are written in position order
-struct SpF {
-    const u64 *text; const u64 *sepbits; u64 n; int K;
-    const u64 *red; const u32 *pidx; int p; const u32 *red_q;
+// pass 2 (over groups of 32 positions): spIndex = exclusive scan of the multi-out bits.  SP symbols are
+// written in position order; multi-in positions are compacted into a work list (position | spIndex << 32)
+struct SpCountF {
     const u32 *momask; const u32 *mimask;
-    u8 *spsym;                 // SP symbols 0..5
-    const u32 *bstart; u32 *cursor; u64 *blue;
-
-    __device__ u32 count(u64 g) const { return (u32)__popc(momask[g]); }
-    __device__ u32 recount(u64 g) const { return (u32)__popc(momask[g]); }
-    __device__ void emit(u64 g, u32 off, u32) const {
-        u32 mo = momask[g], mi = mimask[g];
+    __device__ void count2(u64 g, u32 *a, u32 *b) const { *a = (u32)__popc(momask[g]); *b = (u32)__popc(mimask[g]); }
+};
+struct SpEmitArgs {
+    const u64 *text; const u64 *sepbits; u64 n; int K;
+    const u32 *momask; const u32 *mimask;
+    u8 *spsym; u64 *mi_list;
+};
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngroups, u64 chunk,
+                                                          const u32 *__restrict__ off_mo,
+                                                          const u32 *__restrict__ off_mi) {
+    __shared__ u32 tmp[2 * DEBWT_WAVES];
+    u64 beg = (u64)blockIdx.x * chunk;
+    u64 end = beg + chunk < ngroups ? beg + chunk : ngroups;
+    u32 base_mo = off_mo[blockIdx.x], base_mi = off_mi[blockIdx.x];
+    for (u64 tile = beg; tile < end; tile += DEBWT_BLOCK) {
+        u64 g = tile + threadIdx.x;
+        u32 mo = 0, mi = 0;
+        if (g < end) { mo = a.momask[g]; mi = a.mimask[g]; }
+        u32 val[2] = {(u32)__popc(mo), (u32)__popc(mi)}, ex[2], tot[2];
+        block_scan_excl_vec<2>(val, ex, tot, tmp);
+        u32 off = base_mo + ex[0], omi = base_mi + ex[1];
         u32 all = mo | mi;
         while (all) {
             u32 t = (u32)__ffs(all) - 1u;
             all &= all - 1u;
             u64 i = (g << 5) + t;
-            if ((mi >> t) & 1u) {
-                u64 node = text_window(text, i) >> (64 - 2 * K);
-                u32 f2;
-                u32 r = red_lookup(red, pidx, K, p, node, &f2);
-                u32 q = red_q[r];
-                u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
-                u32 slot = atomicAdd(&cursor[q], 1u);
-                blue[(u64)bstart[q] + slot] = pred | ((u64)off << 4);      // src/generateSP.c:666-672
-            }
+            if ((mi >> t) & 1u) a.mi_list[omi++] = i | ((u64)off << 32);
             if ((mo >> t) & 1u) {
-                // the symbol K ahead; the separator itself when it follows the window (:626-660)
-                u64 j = i + (u64)K;
+                // the symbol K ahead; the separator itself when it follows the window (src/generateSP.c:626-660)
+                u64 j = i + (u64)a.K;
                 u8 sy;
-                if (sep_at(sepbits, j)) sy = (j == n - 1) ? 5 : 4; else sy = (u8)text_symbol(text, j);
-                spsym[off++] = sy;
+                if (sep_at(a.sepbits, j)) sy = (j == a.n - 1) ? 5 : 4; else sy = (u8)text_symbol(a.text, j);
+                a.spsym[off++] = sy;
             }
         }
+        base_mo += tot[0]; base_mi += tot[1];
     }
-};
+}
+
+// one thread per multi-in position: node -> red entry -> block, predecessor symbol, slot in the block
+// through the block's cursor (the reference's per-red-entry lock, src/generateSP.c:662-680)
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const u64 *__restrict__ mi_list, u64 B,
+                                                            const u64 *__restrict__ text,
+                                                            const u64 *__restrict__ sepbits, int K,
+                                                            const u64 *__restrict__ red, const u32 *__restrict__ pidx,
+                                                            int p, u32 *__restrict__ rcursor,
+                                                            u64 *__restrict__ blue) {
+    u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    u64 ent = mi_list[b];
+    u64 i = ent & 0xFFFFFFFFull, sp = ent >> 32;
+    u64 node = text_window(text, i) >> (64 - 2 * K);
+    u32 fl;
+    u32 r = red_lookup(red, pidx, K, p, node, &fl);
+    u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
+    u32 slot = atomicAdd(&rcursor[r], 1u);                                  // absolute slot: starts at the block start
+    blue[slot] = pred | (sp << 4);                                          // src/generateSP.c:666-672
+}
 
 // SP symbols -> 4 bits per symbol, 16 per word, symbol s at bits 60-4*(s&15): integer order of a
 // window = order of the symbol string under A<C<G<T<#<$
