@@ -53,61 +53,42 @@ def main():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--sort-algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     from debwt_amd import api, synth
+    from debwt_amd import dist as D
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rank, local_rank, world = D.env_world()
     assert world == args.gpus or (world == 1 and args.gpus == 1), "launch one process per GPU"
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    D.init(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    # every rank gets its own collection of the same shape (seed differs by rank)
-    if rank == 0:
-        recs = synth.make_workload(args.workload)
-    else:
-        recs = _workload_for_rank(synth, args.workload, rank)
+    # every rank builds its own collection of the same shape (independent objects)
+    recs = _workload_for_rank(synth, args.workload, rank)
     n = sum(len(r) for r in recs) + len(recs)
 
-    d = api.DeBWT(k=args.k, device=local_rank, sort_algo=args.sort_algo)
+    d = api.DeBWT(k=args.k, device=local_rank, sort_algo=args.sort_algo, tune=args.tune)
     d.load_records(recs)                      # text -> HBM before the timed region
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    acc = {"pass_ms": 0.0, "pass_launches": 0, "stage": {}, "timed": False}
+
+    def step():
+        d.build()                             # synchronous: returns after the context's stream drained
+        if acc["timed"]:
+            st_ = d.stats()
+            acc["pass_ms"] += st_["radix_pass_ms"]
+            acc["pass_launches"] += st_["radix_pass_launches"]
+            for key in ("ms_extract", "ms_sort", "ms_classify", "ms_sp", "ms_blue", "ms_assemble", "ms_total"):
+                acc["stage"][key] = acc["stage"].get(key, 0.0) + st_[key] / args.steps
 
     for _ in range(args.warmup):
-        d.build()
-    sync()
-    pass_ms, pass_launches, stage = 0.0, 0, {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        d.build()                             # synchronous: returns after the stream drained
-        st = d.stats()
-        pass_ms += st["radix_pass_ms"]
-        pass_launches += st["radix_pass_launches"]
-        for key in ("ms_extract", "ms_sort", "ms_classify", "ms_sp", "ms_blue", "ms_assemble", "ms_total"):
-            stage[key] = stage.get(key, 0.0) + st[key] / args.steps
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tot = torch.tensor([float(n)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_bases = float(tot.item())
-    else:
-        total_bases = float(n)
+        step()
+    acc["timed"] = True
+    dt = D.timed_steps(step, steps=args.steps, warmup=0, device_sync=torch.cuda.synchronize, tensor_device="cuda")
+    total_bases = D.sum_over_ranks(n, tensor_device="cuda")
+    pass_ms, pass_launches, stage = acc["pass_ms"], acc["pass_launches"], acc["stage"]
     st = d.stats()
 
     if rank == 0:
@@ -146,14 +127,13 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     d.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.finalize()
 
 
 def _workload_for_rank(synth, name, rank):
     """Same shape as make_workload(name), different seed."""
-    seed = synth.SEED_P + 7919 * rank
+    from debwt_amd import dist as D
+    seed = D.collection_seed(synth.SEED_P, rank)
     if name == "chr1_250M":
         return synth.pan_genome(250_000_000, 1, seed=seed)
     if name == "ecoli_4.6M":

@@ -56,9 +56,9 @@ class DeBWT:
         d = DeBWT(k=32); d.load_records(records); d.build(); words, hash_rows, dollar_row = d.fetch()
     or stage by stage: kmer_sort_rle(), classify(), sp_generate(), blue_sort(), bwt_assemble()."""
 
-    def __init__(self, k=32, device=0, sort_algo=0):
+    def __init__(self, k=32, device=0, sort_algo=0, tune=0):
         self._L = _lib.lib()
-        cfg = _lib.DebwtConfig(k=k, device=device, sort_algo=sort_algo, reserved=0)
+        cfg = _lib.DebwtConfig(k=k, device=device, sort_algo=sort_algo, reserved=tune)
         h = ctypes.c_void_p()
         rc = self._L.debwt_create(ctypes.byref(cfg), ctypes.byref(h))
         if rc:

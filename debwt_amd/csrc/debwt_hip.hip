@@ -430,7 +430,7 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     ENSURE(c, c->momask, ngroups * 4 + 64);
     ENSURE(c, c->mimask, ngroups * 4 + 64);
     // prefilter bitmap: 8 bins per prefix-index bin
-    int pb = c->pbits + 3;
+    int pb = c->pbits + ((c->cfg.reserved & 15) ? (c->cfg.reserved & 15) - 8 : 2);   // reserved: tuning knob (delta+8)
     if (pb > 2 * c->K) pb = 2 * c->K;
     if (pb < 5) pb = 5;
     size_t rb_bytes = ((size_t)1 << pb) / 8 + 64;
