@@ -49,7 +49,7 @@ struct debwt_ctx {
     // device buffers
     DevBuf text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, pidx, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
-        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list;
+        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab;
     u32 *h_over = nullptr;      // pinned mirror of rs_over
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
@@ -210,7 +210,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q, &c->pidx,
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
-                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list};
+                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -397,15 +397,7 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     RedBlockF fq{c->red.as<u64>(), c->red_q.as<u32>()};
     if ((rc = cp_count(c, fq, R, cp_area(c, 6), 6))) return rc;
     if ((rc = cp_emit(c, fq, R, cp_area(c, 6)))) return rc;
-    // prefix index: about two bins per red node, never finer than the node itself
-    int p = 8;
-    while (p < 26 && (1ull << p) < 2 * R) p++;
-    if (p > 2 * c->K) p = 2 * c->K;
-    c->pbits = p;
-    ENSURE(c, c->pidx, ((size_t)(1ull << p) + 2) * 4);
-    k_build_pidx<<<grid_for((1ull << p) + 1, 256), 256, 0, c->stream>>>(c->red.as<u64>(), R, c->K, p, c->pidx.as<u32>());
     k_special_rows<<<grid_for(c->NS, 256), 256, 0, c->stream>>>(c->sk, M, c->spkey.as<u64>(), c->NS, c->sprow.as<u64>());
-    ENSURE(c, c->cursor, R * 4 + 64);
     ENSURE(c, c->blue, c->B * 8 + 64);
     if ((rc = sync_check(c))) return rc;
     if (c->h_scalars[6] != Q) { c->err = "multi-in count mismatch between fact list and red table"; return DEBWT_EINTERNAL; }
@@ -429,23 +421,27 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     const u64 ngroups = (c->n + 31) >> 5;
     ENSURE(c, c->momask, ngroups * 4 + 64);
     ENSURE(c, c->mimask, ngroups * 4 + 64);
-    // prefilter bitmap: 8 bins per prefix-index bin
-    int pb = c->pbits + ((c->cfg.reserved & 15) ? (c->cfg.reserved & 15) - 8 : 2);   // reserved: tuning knob (delta+8)
-    if (pb > 2 * c->K) pb = 2 * c->K;
-    if (pb < 5) pb = 5;
-    size_t rb_bytes = ((size_t)1 << pb) / 8 + 64;
+    // node table: 2..4 slots per red node; prefilter: ~8 bits per red node (tuning knob: reserved = delta+8)
+    int hbits = 10;
+    while ((1ull << hbits) < 2 * c->R) hbits++;
+    int pb = hbits + ((c->cfg.reserved & 15) ? (c->cfg.reserved & 15) - 8 : 3);
+    if (pb < 10) pb = 10;
+    if (pb > 31 || hbits > 31) { c->err = "red table too large for 32-bit slots"; return DEBWT_ERANGE; }
+    c->pbits = hbits;
+    size_t rb_bytes = ((size_t)1 << pb) / 8 + 64, ht_slots = (size_t)1 << hbits;
     ENSURE(c, c->rbits, rb_bytes);
+    ENSURE(c, c->htab, ht_slots * 8);
+    ENSURE(c, c->cursor, ht_slots * 4);
     HIPCHK(c, hipMemsetAsync(c->rbits.p, 0, rb_bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->htab.p, 0, ht_slots * 8, c->stream));
     if (c->R)
-        k_build_rbits<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->K, pb, c->rbits.as<u32>());
+        k_build_hash<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->red_q.as<u32>(),
+                                                                c->bstart.as<u32>(), hbits, c->htab.as<u64>(),
+                                                                c->cursor.as<u32>(), pb, c->rbits.as<u32>());
     k_sp_flags<<<grid_for(ngroups, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-        c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->red.as<u64>(), c->pidx.as<u32>(), c->pbits,
-        c->rbits.as<u32>(), pb, c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(),
-        c->mimask.as<u32>(), ngroups);
+        c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<u64>(), hbits, c->rbits.as<u32>(), pb,
+        c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), ngroups);
     if (c->n >= (1ull << 32)) { c->err = "n >= 2^32 needs prefix-range passes"; return DEBWT_ERANGE; }
-    if (c->R)
-        k_init_rcursor<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red_q.as<u32>(), c->bstart.as<u32>(), c->R,
-                                                                  c->cursor.as<u32>());
     ENSURE(c, c->mi_list, c->B * 8 + 64);
     SpCountF fc{c->momask.as<u32>(), c->mimask.as<u32>()};
     if ((rc = cp_count2(c, fc, ngroups, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
@@ -457,8 +453,8 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
         k_sp_emit<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ea, ngroups, chunk, cp_area(c, 0), cp_area(c, 1));
         if (c->B)
             k_blue_fill<<<grid_for(c->B, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-                c->mi_list.as<u64>(), c->B, c->text.as<u64>(), c->sepbits.as<u64>(), c->K, c->red.as<u64>(),
-                c->pidx.as<u32>(), c->pbits, c->cursor.as<u32>(), c->blue.as<u64>());
+                c->mi_list.as<u64>(), c->B, c->text.as<u64>(), c->sepbits.as<u64>(), c->K, c->htab.as<u64>(),
+                c->pbits, c->cursor.as<u32>(), c->blue.as<u64>());
     }
     if ((rc = sync_check(c))) return rc;
     c->S = c->h_scalars[8];

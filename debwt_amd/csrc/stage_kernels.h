@@ -255,6 +255,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_emit_facts(FactEmitArgs a, u64 
             uint4 v = *reinterpret_cast<const uint4 *>(a.cf + e0);      // chunk and tile are multiples of 16
             w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
         } else {
+#pragma unroll
             for (u32 t = 0; t < 16; t++)
                 if (e0 + t < end) w[t >> 2] |= (u32)a.cf[e0 + t] << ((t & 3) * 8);
         }
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_emit_facts(FactEmitArgs a, u64 
         block_scan_excl_vec<2>(val, ex, tot, tmp);
         if (val[0] | val[1]) {
             u32 omi = base_mi + ex[0], omo = base_mo + ex[1];
-            for (u32 t = 0; t < 16; t++) {
+#pragma unroll
+            for (u32 t = 0; t < 16; t++) {                     // unrolled: w[] must stay in registers
                 u32 f = (w[t >> 2] >> ((t & 3) * 8)) & 0xFFu;
                 if (!f) continue;
                 u64 e = e0 + t;
@@ -314,14 +316,6 @@ struct RedBlockF {
     __device__ u32 recount(u64 r) const { return count(r); }
     __device__ void emit(u64 r, u32 off, u32 c) const { red_q[r] = c ? off : 0xFFFFFFFFu; }
 };
-// fill cursor of every multi-in red entry = first blue slot of its block (redPoint analogue, src/INandOut.c:413)
-__global__ void k_init_rcursor(const u32 *__restrict__ red_q, const u32 *__restrict__ bstart, u64 R,
-                               u32 *__restrict__ rcursor) {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    u32 q = red_q[r];
-    rcursor[r] = q == 0xFFFFFFFFu ? 0u : bstart[q];
-}
 // exclusive scan of block sizes -> first blue slot of each block (blueBound analogue)
 struct BlockStartF {
     const u32 *mi_freq; u32 *bstart;
@@ -336,29 +330,42 @@ struct LargeBlockF {
     __device__ void emit(u64 q, u32 off, u32 c) const { if (c) large_q[off] = (u32)q; }
 };
 
-// prefix index over the red table (blackTable analogue, src/generateSP.c:53-59, 2^p bins instead of 4^10)
-__global__ void k_build_pidx(const u64 *__restrict__ red, u64 R, int K, int p, u32 *__restrict__ pidx) {
-    u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (h > (1ull << p)) return;
-    u64 key = (h << (2 * K - p)) << 2;
-    pidx[h] = (h == (1ull << p)) ? (u32)R : (u32)lower_bound_dev<u64>(red, 0, R, key);
+// Node lookup for the text scan (the job of blackTable + BinarySearch_red, src/generateSP.c:53-59,542-566,
+// 725-737): an open-addressing table over the red nodes (slot = node<<2|flags, 0 = empty, load <= 1/2, linear
+// probing so a probe sequence stays inside one 128-byte line) behind a one-bit-per-bin prefilter that fits L2.
+// Both are indexed by multiplicative hashes of the node, so neighbouring text positions spread evenly.
+__device__ __forceinline__ u32 red_hash(u64 node, int bits) { return (u32)((node * 0x9E3779B97F4A7C15ull) >> (64 - bits)); }
+__device__ __forceinline__ u32 red_hash2(u64 node, int bits) { return (u32)((node * 0xC2B2AE3D27D4EB4Full) >> (64 - bits)); }
+
+__global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__restrict__ red_q,
+                             const u32 *__restrict__ bstart, int hbits, u64 *__restrict__ htab,
+                             u32 *__restrict__ hcursor, int pb, u32 *__restrict__ rbits) {
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const u64 v = red[r], node = v >> 2;
+    const u32 mask = (1u << hbits) - 1u;
+    u32 h = red_hash(node, hbits);
+    for (;;) {
+        u64 old = atomicCAS(&htab[h], 0ull, v);
+        if (old == 0ull) break;
+        h = (h + 1) & mask;
+    }
+    // fill cursor of a multi-in node = first blue slot of its block (redPoint analogue, src/INandOut.c:413)
+    if (v & 2ull) hcursor[h] = bstart[red_q[r]];
+    u32 hb = red_hash2(node, pb);
+    atomicOr(&rbits[hb >> 5], 1u << (hb & 31));
 }
 
-__device__ __forceinline__ u32 red_lookup(const u64 *__restrict__ red, const u32 *__restrict__ pidx, int K, int p,
-                                          u64 node, u32 *flags) {
-    u64 h = node >> (2 * K - p);
-    u32 lo = pidx[h], hi = pidx[h + 1];
-    while (lo < hi) {
-        u32 mid = (lo + hi) >> 1;
-        u64 v = red[mid] >> 2;
-        if (v < node) lo = mid + 1; else hi = mid;
+// returns the slot (or 0xFFFFFFFF) and the flags of `node`
+__device__ __forceinline__ u32 red_lookup(const u64 *__restrict__ htab, int hbits, u64 node, u32 *flags) {
+    const u32 mask = (1u << hbits) - 1u;
+    u32 h = red_hash(node, hbits);
+    for (;;) {
+        u64 v = htab[h];
+        if (v == 0ull) { *flags = 0; return 0xFFFFFFFFu; }
+        if ((v >> 2) == node) { *flags = (u32)(v & 3); return h; }
+        h = (h + 1) & mask;
     }
-    if (lo < pidx[h + 1]) {
-        u64 v = red[lo];
-        if ((v >> 2) == node) { *flags = (u32)(v & 3); return lo; }
-    }
-    *flags = 0;
-    return 0xFFFFFFFFu;
 }
 
 // rows of the special suffixes: rank among the node instances + own rank (src/INandOut.c:419-439)
@@ -372,20 +379,10 @@ __global__ void k_special_rows(const u64 *__restrict__ sk, u64 M, const u64 *__r
 // ---------------------------------------------------------------------------------------------------
 // SP code + blue entries (multiGenerateSP, src/generateSP.c:534-683)
 
-// prefilter bitmap over the top pb bits of the red nodes: most positions are not branching nodes and are
-// rejected by one read of an L2-resident table
-__global__ void k_build_rbits(const u64 *__restrict__ red, u64 R, int K, int pb, u32 *__restrict__ rbits) {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    u64 h = (red[r] >> 2) >> (2 * K - pb);
-    atomicOr(&rbits[h >> 5], 1u << (h & 31));
-}
-
 // pass 1: one lane = 32 consecutive positions = one text word (coalesced 8-byte loads); per position the
 // node is a shift of the 128-bit (w0,w1) pair; flags go out as two 32-bit masks per group
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict__ text, const u64 *__restrict__ sepbits,
-                                                           u64 n, int K, const u64 *__restrict__ red,
-                                                           const u32 *__restrict__ pidx, int p,
+                                                           u64 n, int K, const u64 *__restrict__ htab, int hbits,
                                                            const u32 *__restrict__ rbits, int pb,
                                                            const u64 *__restrict__ branch, u64 nbranch,
                                                            u32 *__restrict__ momask, u32 *__restrict__ mimask,
@@ -404,7 +401,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
 #pragma unroll
     for (u32 t = 0; t < 32; t++) {
         u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
-        u64 hb = (win >> (64 - 2 * K)) >> (2 * K - pb);
+        u32 hb = red_hash2(win >> (64 - 2 * K), pb);
         u32 bit = (rbits[hb >> 5] >> (hb & 31)) & 1u;
         cand |= bit << t;
         spec |= (((sb >> t) & kmask) ? 1u : 0u) << t;
@@ -417,7 +414,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
         cand &= cand - 1u;
         u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
         u32 fl;
-        red_lookup(red, pidx, K, p, win >> (64 - 2 * K), &fl);
+        red_lookup(htab, hbits, win >> (64 - 2 * K), &fl);
         mo |= (fl & 1u) << t;
         mi |= ((fl >> 1) & 1u) << t;
     }
@@ -483,18 +480,17 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const u64 *__restrict__ mi_list, u64 B,
                                                             const u64 *__restrict__ text,
                                                             const u64 *__restrict__ sepbits, int K,
-                                                            const u64 *__restrict__ red, const u32 *__restrict__ pidx,
-                                                            int p, u32 *__restrict__ rcursor,
-                                                            u64 *__restrict__ blue) {
+                                                            const u64 *__restrict__ htab, int hbits,
+                                                            u32 *__restrict__ hcursor, u64 *__restrict__ blue) {
     u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     u64 ent = mi_list[b];
     u64 i = ent & 0xFFFFFFFFull, sp = ent >> 32;
     u64 node = text_window(text, i) >> (64 - 2 * K);
     u32 fl;
-    u32 r = red_lookup(red, pidx, K, p, node, &fl);
+    u32 h = red_lookup(htab, hbits, node, &fl);
     u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
-    u32 slot = atomicAdd(&rcursor[r], 1u);                                  // absolute slot: starts at the block start
+    u32 slot = atomicAdd(&hcursor[h], 1u);                                  // absolute slot: starts at the block start
     blue[slot] = pred | (sp << 4);                                          // src/generateSP.c:666-672
 }
 
