@@ -49,7 +49,7 @@ struct debwt_ctx {
     // device buffers
     DevBuf text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, pidx, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
-        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab;
+        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work;
     u32 *h_over = nullptr;      // pinned mirror of rs_over
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
@@ -142,12 +142,13 @@ RadixWorkspace radix_ws(debwt_ctx *c) {
     return ws;
 }
 
-int sort_keys(debwt_ctx *c, u64 *a, u64 *b, u64 count, int key_bits, u64 **result, bool record_passes) {
+int sort_keys(debwt_ctx *c, u64 *a, u64 *b, u64 count, int key_bits, u64 **result, bool record_passes,
+              const TextKeySrc *text = nullptr) {
     RadixWorkspace ws = radix_ws(c);
     hipError_t e = hipSuccess;
     if (record_passes) {
         *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo, &c->ev_pass[0][0], 16,
-                                 &c->n_pass_events, &e);
+                                 &c->n_pass_events, &e, text);
         c->st.radix_pass_keys = count;
     } else {
         *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo, nullptr, 0, nullptr, &e);
@@ -210,7 +211,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q, &c->pidx,
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
-                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab};
+                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -308,10 +309,10 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const u64 n = c->n, M = c->M;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    k_extract_keys<<<grid_for(n, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-        c->text.as<u64>(), c->sepbits.as<u64>(), c->sep.as<u64>(), c->nrec, n, c->K, 0, c->keysA.as<u64>());
+    // the keys (node << 2 | pred) are read off the text inside the first radix pass: no unsorted key array
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    int rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), M, 2 * c->cfg.k, &c->sk, true);
+    TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K};
+    int rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), M, 2 * c->cfg.k, &c->sk, true, &ts);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     RleF f{c->sk, c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>()};
@@ -372,10 +373,15 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     // fact list = [multi-out facts | tail# facts | multi-in facts]
     u64 *facts = c->facts.as<u64>();
     {
-        FactEmitArgs fa{cc, c->K, cf, facts + Rmo + nrec, c->mi_j0.as<u32>(), c->mi_freq.as<u32>(), facts};
+        const u64 nslots = Q + Rmo;
+        ENSURE(c, c->fact_work, nslots * 16 + 64);
+        HIPCHK(c, hipMemsetAsync(c->fact_work.p, 0, nslots * 16 + 16, c->stream));
+        FactEmitArgs fa{cc, c->K, cf, facts + Rmo + nrec, c->mi_j0.as<u32>(), c->mi_freq.as<u32>(), facts,
+                        c->fact_work.as<uint4>()};
         u32 nchunks; u64 chunk;
         plan_chunks(D, &nchunks, &chunk);       // same chunks as the counting sweep (multiples of 1024 keys)
         if (D) k_emit_facts<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(fa, chunk, cp_area(c, 1), cp_area(c, 2));
+        if (nslots) k_eval_facts<<<grid_for(nslots, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(fa, nslots);
     }
     HIPCHK(c, hipMemcpyAsync(facts + Rmo, c->special.tail_facts.data(), nrec * 8, hipMemcpyHostToDevice, c->stream));
     u64 *sorted_facts = nullptr;

@@ -20,6 +20,15 @@ struct RadixWorkspace {
 };
 #define RS_OVER_CAP 4096
 
+// Optional key source for the FIRST pass: node keys (node << 2 | pred) computed on the fly from the 2-bit text,
+// one per position whose K-window holds no separator -- the key array is then never written out unsorted.
+struct TextKeySrc {
+    const u64 *text;      // packed text, reference layout
+    const u64 *sepbits;   // separator bitmap, bit i of word i>>6
+    u64 n;                // positions
+    int K;                // node length
+};
+
 size_t radix_workspace_bytes(u64 max_keys);
 size_t radix_over_bytes();
 
@@ -30,5 +39,8 @@ size_t radix_over_bytes();
 //           ("k-mer prefix bucketing"), then one kernel that finishes every bucket inside LDS.
 // pass_events (optional): max_pairs pairs of hipEvents; pair i is recorded on `stream` right before and
 // after the scatter kernel of pass i (no synchronisation); *npairs receives the number recorded.
+// text (optional): when given, the keys are taken from the text in the first pass (`a` is scratch, n = number of
+// valid positions); pass events are then recorded for the array-to-array passes only.
 u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, const RadixWorkspace &ws,
-                    int algo, hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err);
+                    int algo, hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err,
+                    const TextKeySrc *text = nullptr);

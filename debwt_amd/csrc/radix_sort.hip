@@ -14,24 +14,54 @@
 #include <vector>
 
 // ---------------------------------------------------------------------------------------------------
+// key sources: SRC 0 = key array, SRC 1 = node keys straight from the packed text (first pass only)
+
+template <int SRC>
+__device__ __forceinline__ bool rs_load_key(const u64 *__restrict__ in, const TextKeySrc &ts, u64 idx, u64 end,
+                                            u64 *key) {
+    if (SRC == 0) {
+        if (idx >= end) { *key = ~0ull; return false; }
+        *key = in[idx];
+        return true;
+    } else {
+        *key = ~0ull;
+        if (idx >= end) return false;
+        u64 sw = sep_window(ts.sepbits, idx);
+        if (sw & ((1ull << ts.K) - 1ull)) return false;                   // window holds a separator: no node
+        u64 node = text_window(ts.text, idx) >> (64 - 2 * ts.K);
+        u32 pred = idx ? text_symbol(ts.text, idx - 1) : 3u;              // 'T' stands at separators
+        *key = (node << 2) | pred;
+        return true;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // algo 1
 
-__global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict__ keys, u64 n, u64 chunk,
-                                                            int shift, u32 mask, u32 *__restrict__ counts,
+template <int SRC>
+__global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict__ keys, TextKeySrc ts, u64 n,
+                                                            u64 chunk, int shift, u32 mask, u32 *__restrict__ counts,
                                                             u32 nchunks) {
     __shared__ u32 h[RS_RADIX];
     h[threadIdx.x] = 0;
     __syncthreads();
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < n ? beg + chunk : n;
-    // chunk is a multiple of RS_TILE, so beg is 16-byte aligned: two keys per lane per load
-    for (u64 i = beg + 2ull * threadIdx.x; i < end; i += 2ull * RS_BLOCK) {
-        if (i + 1 < end) {
-            ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + i);
-            atomicAdd(&h[(u32)(v.x >> shift) & mask], 1u);
-            atomicAdd(&h[(u32)(v.y >> shift) & mask], 1u);
-        } else {
-            atomicAdd(&h[(u32)(keys[i] >> shift) & mask], 1u);
+    if (SRC == 0) {
+        // chunk is a multiple of RS_TILE, so beg is 16-byte aligned: two keys per lane per load
+        for (u64 i = beg + 2ull * threadIdx.x; i < end; i += 2ull * RS_BLOCK) {
+            if (i + 1 < end) {
+                ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + i);
+                atomicAdd(&h[(u32)(v.x >> shift) & mask], 1u);
+                atomicAdd(&h[(u32)(v.y >> shift) & mask], 1u);
+            } else {
+                atomicAdd(&h[(u32)(keys[i] >> shift) & mask], 1u);
+            }
+        }
+    } else {
+        for (u64 i = beg + threadIdx.x; i < end; i += RS_BLOCK) {
+            u64 k;
+            if (rs_load_key<1>(keys, ts, i, end, &k)) atomicAdd(&h[(u32)(k >> shift) & mask], 1u);
         }
     }
     __syncthreads();
@@ -68,9 +98,10 @@ __global__ __launch_bounds__(RS_RADIX) void rs_scan_tot_kernel(u32 *__restrict__
 // Rank one tile.  On return skeys holds the tile's keys grouped by digit (stable), lstart[d] the
 // first LDS slot of digit d, and the return value of each thread d is the tile's count of digit d.
 // `cnt` is the number of valid keys of the tile (invalid slots only at the very end of the input).
+template <int SRC = 0>
 __device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile, u64 end, int shift, u32 mask,
                                             u64 *skeys, u32 (*wavecnt)[RS_RADIX], u32 *lstart, u32 *scan_tmp,
-                                            u32 *tile_total) {
+                                            u32 *tile_total, const TextKeySrc &ts = TextKeySrc{}) {
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
 #pragma unroll
     for (u32 i = 0; i < DEBWT_WAVES; i++) wavecnt[i][tid] = 0;
@@ -79,15 +110,15 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile
     u32 rnk[RS_ITEMS];
     const u64 wbase = tile + (u64)w * (64u * RS_ITEMS);
     const u64 lt = (1ull << lane) - 1ull;
+    u32 vmask = 0;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         u64 idx = wbase + (u64)r * 64u + lane;
-        key[r] = idx < end ? in[idx] : ~0ull;
+        if (rs_load_key<SRC>(in, ts, idx, end, &key[r])) vmask |= 1u << r;
     }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
-        u64 idx = wbase + (u64)r * 64u + lane;
-        bool valid = idx < end;
+        bool valid = (vmask >> r) & 1u;
         u32 d = (u32)(key[r] >> shift) & mask;
         u64 m = __ballot(valid);
 #pragma unroll
@@ -110,8 +141,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
-        u64 idx = wbase + (u64)r * 64u + lane;
-        if (idx < end) {
+        if ((vmask >> r) & 1u) {
             u32 d = (u32)(key[r] >> shift) & mask;
             skeys[lstart[d] + wavecnt[w][d] + rnk[r]] = key[r];
         }
@@ -120,8 +150,10 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile
     return total;
 }
 
-__global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out,
-                                                               u64 n, u64 chunk, int shift, u32 mask,
+template <int SRC>
+__global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts,
+                                                               u64 *__restrict__ out, u64 n, u64 chunk, int shift,
+                                                               u32 mask,
                                                                const u32 *__restrict__ offsets,
                                                                const u32 *__restrict__ digit_base, u32 nchunks) {
     __shared__ u64 skeys[RS_TILE];
@@ -135,7 +167,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
     u64 end = beg + chunk < n ? beg + chunk : n;
     for (u64 tile = beg; tile < end; tile += RS_TILE) {
         u32 tot;
-        u32 mine = rs_rank_tile(in, tile, end, shift, mask, skeys, wavecnt, lstart, scan_tmp, &tot);
+        u32 mine = rs_rank_tile<SRC>(in, tile, end, shift, mask, skeys, wavecnt, lstart, scan_tmp, &tot, ts);
         for (u32 j = tid; j < tot; j += RS_BLOCK) {
             u64 k = skeys[j];
             u32 d = (u32)(k >> shift) & mask;
@@ -298,44 +330,57 @@ static void rs_plan(u64 n, u32 *nchunks, u64 *chunk) {
 size_t radix_over_bytes() { return 16 + (size_t)RS_OVER_CAP * 16 + 16; }
 
 static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
-                   hipEvent_t *pass_events, int max_pairs, int *npairs) {
-    // stable LSD passes over bits [lo_bit, hi_bit), 8 bits per pass starting at lo_bit
-    u32 nchunks; u64 chunk;
-    rs_plan(n, &nchunks, &chunk);
+                   hipEvent_t *pass_events, int max_pairs, int *npairs, const TextKeySrc *text = nullptr) {
+    // stable LSD passes over bits [lo_bit, hi_bit), 8 bits per pass starting at lo_bit.  With `text` the first
+    // pass reads node keys from the text (its index space is the ts->n positions) and writes them to `a`.
     u64 *src = a, *dst = b;
-    int p = 0;
+    int p = 0, ev_idx = 0;
+    TextKeySrc none{};
     for (int shift = lo_bit; shift < hi_bit; shift += 8, p++) {
         int bits = hi_bit - shift < 8 ? hi_bit - shift : 8;
         u32 mask = (1u << bits) - 1u;
-        bool ev = pass_events && p < max_pairs;
+        const bool from_text = text && p == 0;
+        u32 nchunks; u64 chunk;
+        rs_plan(from_text ? text->n : n, &nchunks, &chunk);
         u32 *digit_tot = ws.counts + (size_t)RS_RADIX * RS_MAXCHUNKS;
-        rs_hist_kernel<<<nchunks, RS_BLOCK, 0, stream>>>(src, n, chunk, shift, mask, ws.counts, nchunks);
+        if (from_text) {
+            rs_hist_kernel<1><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, text->n, chunk, shift, mask, ws.counts, nchunks);
+            rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
+            rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
+            rs_scatter_kernel<1><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, a, text->n, chunk, shift, mask,
+                                                                   ws.counts, digit_tot, nchunks);
+            src = a; dst = b;
+            continue;
+        }
+        bool ev = pass_events && ev_idx < max_pairs;
+        rs_hist_kernel<0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, n, chunk, shift, mask, ws.counts, nchunks);
         rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
         rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
-        if (ev) (void)hipEventRecord(pass_events[2 * p], stream);
-        rs_scatter_kernel<<<nchunks, RS_BLOCK, 0, stream>>>(src, dst, n, chunk, shift, mask, ws.counts, digit_tot, nchunks);
-        if (ev) { (void)hipEventRecord(pass_events[2 * p + 1], stream); if (npairs) *npairs = p + 1; }
+        if (ev) (void)hipEventRecord(pass_events[2 * ev_idx], stream);
+        rs_scatter_kernel<0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, n, chunk, shift, mask, ws.counts,
+                                                               digit_tot, nchunks);
+        if (ev) { (void)hipEventRecord(pass_events[2 * ev_idx + 1], stream); ev_idx++; if (npairs) *npairs = ev_idx; }
         u64 *t = src; src = dst; dst = t;
     }
     return src;
 }
 
 u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, const RadixWorkspace &ws, int algo,
-                    hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err) {
+                    hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err, const TextKeySrc *text) {
     *err = hipSuccess;
     if (npairs) *npairs = 0;
-    if (n < 2 || key_bits <= 0) return a;
     if (key_bits > 64) key_bits = 64;
+    if (!text && (n < 2 || key_bits <= 0)) return a;
     // hybrid: T top digits in HBM so that a bucket holds <= ~16 keys on average, the rest in LDS
     int T = 0;
     while ((n >> (8 * T)) > 16 && T < 4) T++;
     if (algo != 3 || T == 0 || key_bits - 8 * T < 1 || !ws.over || !ws.h_over) {
-        u64 *r = rs_lsd(stream, a, b, n, 0, key_bits, ws, pass_events, max_pairs, npairs);
+        u64 *r = rs_lsd(stream, a, b, n, 0, key_bits, ws, pass_events, max_pairs, npairs, text);
         *err = hipGetLastError();
         return r;
     }
     const int pshift = key_bits - 8 * T;
-    u64 *src = rs_lsd(stream, a, b, n, pshift, key_bits, ws, pass_events, max_pairs, npairs);
+    u64 *src = rs_lsd(stream, a, b, n, pshift, key_bits, ws, pass_events, max_pairs, npairs, text);
     u64 *other = src == a ? b : a;
     (void)hipMemsetAsync(ws.over, 0, 16, stream);
     u32 ntiles = (u32)((n + RL_H - 1) / RL_H);

@@ -240,7 +240,30 @@ struct FactEmitArgs {
     const u8 *cf;
     u64 *mi_fact; u32 *mi_j0; u32 *mi_freq;
     u64 *mo_fact;
+    uint4 *work;              // one slot per fact, the item sits in the slot of its first fact, others stay 0
 };
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_eval_facts(FactEmitArgs a, u64 nslots) {
+    u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    uint4 it = a.work[s];
+    if (it.w == 0) return;
+    u64 e = it.x;
+    if (it.w & 1u) {
+        u32 fr;
+        eval_multi_in(a.c, e, &fr);
+        a.mi_fact[it.y] = ((a.c.dk[e] >> 2) << 2) | 2ull;
+        a.mi_j0[it.y] = a.c.dstart[e];
+        a.mi_freq[it.y] = fr;
+    }
+    u32 cnt = it.w >> 1;
+    if (cnt) {
+        u64 facts[4];
+        eval_multi_out(a.c, a.K, e, facts);
+#pragma unroll
+        for (u32 m = 0; m < 4; m++)
+            if (m < cnt) a.mo_fact[it.z + m] = facts[m];
+    }
+}
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_emit_facts(FactEmitArgs a, u64 chunk, const u32 *__restrict__ off_mi,
                                                              const u32 *__restrict__ off_mo) {
     __shared__ u32 tmp[2 * DEBWT_WAVES];
@@ -268,26 +291,15 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_emit_facts(FactEmitArgs a, u64 
         }
         block_scan_excl_vec<2>(val, ex, tot, tmp);
         if (val[0] | val[1]) {
+            // work items only: the look-ahead evaluation runs one item per thread in k_eval_facts
             u32 omi = base_mi + ex[0], omo = base_mo + ex[1];
 #pragma unroll
             for (u32 t = 0; t < 16; t++) {                     // unrolled: w[] must stay in registers
                 u32 f = (w[t >> 2] >> ((t & 3) * 8)) & 0xFFu;
-                if (!f) continue;
-                u64 e = e0 + t;
-                if (f & 1u) {
-                    u32 fr;
-                    eval_multi_in(a.c, e, &fr);
-                    a.mi_fact[omi] = ((a.c.dk[e] >> 2) << 2) | 2ull;
-                    a.mi_j0[omi] = a.c.dstart[e];
-                    a.mi_freq[omi] = fr;
-                    omi++;
-                }
-                u32 cnt = f >> 1;
-                if (cnt) {
-                    u64 facts[4];
-                    eval_multi_out(a.c, a.K, e, facts);
-                    for (u32 m = 0; m < cnt; m++) a.mo_fact[omo + m] = facts[m];
-                    omo += cnt;
+                if (f) {
+                    a.work[omi + omo] = make_uint4((u32)(e0 + t), omi, omo, f);
+                    omi += f & 1u;
+                    omo += f >> 1;
                 }
             }
         }
