@@ -151,7 +151,7 @@ int sort_keys(debwt_ctx *c, u64 *a, u64 *b, u64 count, int key_bits, u64 **resul
                                  &c->n_pass_events, &e, text);
         c->st.radix_pass_keys = count;
     } else {
-        *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo, nullptr, 0, nullptr, &e);
+        *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo | 16, nullptr, 0, nullptr, &e);
     }
     if (e != hipSuccess) { c->err = std::string("radix sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
     return DEBWT_OK;

@@ -38,7 +38,9 @@ __device__ __forceinline__ bool rs_load_key(const u64 *__restrict__ in, const Te
 // ---------------------------------------------------------------------------------------------------
 // algo 1
 
-template <int SRC>
+// AUX = 1 instantiates the same kernels under a second name for the small auxiliary sorts (fact lists, '#' rows),
+// so that profiler averages of the key-sort passes are not diluted by them
+template <int SRC, int AUX>
 __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict__ keys, TextKeySrc ts, u64 n,
                                                             u64 chunk, int shift, u32 mask, u32 *__restrict__ counts,
                                                             u32 nchunks) {
@@ -150,7 +152,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile
     return total;
 }
 
-template <int SRC>
+template <int SRC, int AUX>
 __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts,
                                                                u64 *__restrict__ out, u64 n, u64 chunk, int shift,
                                                                u32 mask,
@@ -330,7 +332,8 @@ static void rs_plan(u64 n, u32 *nchunks, u64 *chunk) {
 size_t radix_over_bytes() { return 16 + (size_t)RS_OVER_CAP * 16 + 16; }
 
 static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
-                   hipEvent_t *pass_events, int max_pairs, int *npairs, const TextKeySrc *text = nullptr) {
+                   hipEvent_t *pass_events, int max_pairs, int *npairs, const TextKeySrc *text = nullptr,
+                   bool aux = false) {
     // stable LSD passes over bits [lo_bit, hi_bit), 8 bits per pass starting at lo_bit.  With `text` the first
     // pass reads node keys from the text (its index space is the ts->n positions) and writes them to `a`.
     u64 *src = a, *dst = b;
@@ -344,21 +347,24 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
         rs_plan(from_text ? text->n : n, &nchunks, &chunk);
         u32 *digit_tot = ws.counts + (size_t)RS_RADIX * RS_MAXCHUNKS;
         if (from_text) {
-            rs_hist_kernel<1><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, text->n, chunk, shift, mask, ws.counts, nchunks);
+            rs_hist_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, text->n, chunk, shift, mask, ws.counts, nchunks);
             rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
             rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
-            rs_scatter_kernel<1><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, a, text->n, chunk, shift, mask,
+            rs_scatter_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, a, text->n, chunk, shift, mask,
                                                                    ws.counts, digit_tot, nchunks);
             src = a; dst = b;
             continue;
         }
         bool ev = pass_events && ev_idx < max_pairs;
-        rs_hist_kernel<0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, n, chunk, shift, mask, ws.counts, nchunks);
+        if (aux) rs_hist_kernel<0, 1><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, n, chunk, shift, mask, ws.counts, nchunks);
+        else rs_hist_kernel<0, 0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, n, chunk, shift, mask, ws.counts, nchunks);
         rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
         rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
         if (ev) (void)hipEventRecord(pass_events[2 * ev_idx], stream);
-        rs_scatter_kernel<0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, n, chunk, shift, mask, ws.counts,
-                                                               digit_tot, nchunks);
+        if (aux) rs_scatter_kernel<0, 1><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, n, chunk, shift, mask,
+                                                                          ws.counts, digit_tot, nchunks);
+        else rs_scatter_kernel<0, 0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, n, chunk, shift, mask,
+                                                                      ws.counts, digit_tot, nchunks);
         if (ev) { (void)hipEventRecord(pass_events[2 * ev_idx + 1], stream); ev_idx++; if (npairs) *npairs = ev_idx; }
         u64 *t = src; src = dst; dst = t;
     }
@@ -369,18 +375,20 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
                     hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err, const TextKeySrc *text) {
     *err = hipSuccess;
     if (npairs) *npairs = 0;
+    const bool aux = (algo & 16) != 0;       // bit 4: auxiliary sort
+    algo &= 15;
     if (key_bits > 64) key_bits = 64;
     if (!text && (n < 2 || key_bits <= 0)) return a;
     // hybrid: T top digits in HBM so that a bucket holds <= ~16 keys on average, the rest in LDS
     int T = 0;
     while ((n >> (8 * T)) > 16 && T < 4) T++;
     if (algo != 3 || T == 0 || key_bits - 8 * T < 1 || !ws.over || !ws.h_over) {
-        u64 *r = rs_lsd(stream, a, b, n, 0, key_bits, ws, pass_events, max_pairs, npairs, text);
+        u64 *r = rs_lsd(stream, a, b, n, 0, key_bits, ws, pass_events, max_pairs, npairs, text, aux);
         *err = hipGetLastError();
         return r;
     }
     const int pshift = key_bits - 8 * T;
-    u64 *src = rs_lsd(stream, a, b, n, pshift, key_bits, ws, pass_events, max_pairs, npairs, text);
+    u64 *src = rs_lsd(stream, a, b, n, pshift, key_bits, ws, pass_events, max_pairs, npairs, text, aux);
     u64 *other = src == a ? b : a;
     (void)hipMemsetAsync(ws.over, 0, 16, stream);
     u32 ntiles = (u32)((n + RL_H - 1) / RL_H);
