@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--sort-algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="N>1: 'replicas' = one independent collection per GPU (default); 'sharded' = ONE "
+                         "collection of N x the per-GPU size built by all GPUs as k-mer-prefix shards")
     args = ap.parse_args()
 
     import torch
@@ -65,8 +68,16 @@ def main():
     torch.cuda.set_device(local_rank)
     D.init(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    # every rank builds its own collection of the same shape (independent objects)
-    recs = _workload_for_rank(synth, args.workload, rank)
+    sharded_mode = args.mode == "sharded" and world > 1
+    if sharded_mode:
+        # ONE collection, `world` records of the per-GPU size, the same text on every rank
+        from debwt_amd import sharded as SH
+        recs = []
+        for r in range(world):
+            recs += _workload_for_rank(synth, args.workload, r)
+    else:
+        # every rank builds its own collection of the same shape (independent objects)
+        recs = _workload_for_rank(synth, args.workload, rank)
     n = sum(len(r) for r in recs) + len(recs)
 
     d = api.DeBWT(k=args.k, device=local_rank, sort_algo=args.sort_algo, tune=args.tune)
@@ -75,7 +86,10 @@ def main():
     acc = {"pass_ms": 0.0, "pass_launches": 0, "stage": {}, "timed": False}
 
     def step():
-        d.build()                             # synchronous: returns after the context's stream drained
+        if sharded_mode:
+            SH.build_sharded(d, torch.device("cuda", local_rank))     # collectives inside; result stays in HBM
+        else:
+            d.build()                         # synchronous: returns after the context's stream drained
         if acc["timed"]:
             st_ = d.stats()
             acc["pass_ms"] += st_["radix_pass_ms"]
@@ -87,7 +101,7 @@ def main():
         step()
     acc["timed"] = True
     dt = D.timed_steps(step, steps=args.steps, warmup=0, device_sync=torch.cuda.synchronize, tensor_device="cuda")
-    total_bases = D.sum_over_ranks(n, tensor_device="cuda")
+    total_bases = float(n) if sharded_mode else D.sum_over_ranks(n, tensor_device="cuda")
     pass_ms, pass_launches, stage = acc["pass_ms"], acc["pass_launches"], acc["stage"]
     st = d.stats()
 
@@ -111,7 +125,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload} (BASELINE configs[1]: chr1-sized synthetic, repeat families)",
                        "k": args.k, "bases_per_gpu": n, "records_per_gpu": len(recs),
-                       "parallelism": f"{args.gpus} independent collections, one per GPU"},
+                       "parallelism": (f"one collection of {world} records built by {world} k-mer-prefix shards"
+                                       if sharded_mode else f"{args.gpus} independent collections, one per GPU")},
             "roofline": {"bound": "hbm", "kernel": "rs_scatter_kernel (one 8-bit radix pass over the keys)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

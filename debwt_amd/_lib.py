@@ -34,6 +34,8 @@ SYMBOLS = [
     "debwt_load_ascii", "debwt_kmer_sort_rle", "debwt_classify", "debwt_sp_generate", "debwt_blue_sort",
     "debwt_bwt_assemble", "debwt_build", "debwt_fetch_bwt", "debwt_bwt_device_ptr", "debwt_get_stats",
     "debwt_fetch_array", "debwt_kmer_count_sorted", "debwt_radix_sort_u64", "debwt_verify_inverse",
+    "debwt_shard_begin", "debwt_shard_histogram", "debwt_shard_set_range", "debwt_shard_classify_local",
+    "debwt_shard_facts_export", "debwt_shard_classify_global", "debwt_shard_info", "debwt_shard_fetch",
 ]
 
 
@@ -88,5 +90,21 @@ def lib():
     L.debwt_verify_inverse.restype = ctypes.c_int
     L.debwt_verify_inverse.argtypes = [u64p, ctypes.c_uint64, u64p, ctypes.c_uint64, ctypes.c_uint64,
                                        ctypes.POINTER(ctypes.c_uint8)]
+    L.debwt_shard_begin.restype = ctypes.c_int
+    L.debwt_shard_begin.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.debwt_shard_histogram.restype = ctypes.c_int
+    L.debwt_shard_histogram.argtypes = [vp, u64p]
+    L.debwt_shard_set_range.restype = ctypes.c_int
+    L.debwt_shard_set_range.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64]
+    L.debwt_shard_classify_local.restype = ctypes.c_int
+    L.debwt_shard_classify_local.argtypes = [vp, u64p, u64p, u64p]
+    L.debwt_shard_facts_export.restype = ctypes.c_int
+    L.debwt_shard_facts_export.argtypes = [vp, vp, ctypes.c_uint64]
+    L.debwt_shard_classify_global.restype = ctypes.c_int
+    L.debwt_shard_classify_global.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
+    L.debwt_shard_info.restype = ctypes.c_int
+    L.debwt_shard_info.argtypes = [vp, u64p, u64p, u64p]
+    L.debwt_shard_fetch.restype = ctypes.c_int
+    L.debwt_shard_fetch.argtypes = [vp, u64p, u64p, u64p]
     _lib = L
     return L

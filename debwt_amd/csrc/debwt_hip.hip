@@ -49,12 +49,22 @@ struct debwt_ctx {
     // device buffers
     DevBuf text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, pidx, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
-        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work;
+        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist;
     u32 *h_over = nullptr;      // pinned mirror of rs_over
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
     int pbits = 8;
     u64 D = 0, Q = 0, Rmo = 0, R = 0, B = 0, S = 0, nlarge = 0, nfacts = 0;
+    // k-mer-prefix shard of a multi-GPU build (world == 1: the whole key space)
+    int shard_rank = 0, shard_world = 1;
+    u64 Mfull = 0;              // node instances of the whole text
+    u64 key_lo = 0, key_hi = 0; // this shard's key range [lo, hi); hi == 0: unbounded
+    u64 Mbase = 0;              // node instances in the shards before this one
+    u64 qbase = 0;              // multi-in blocks in the shards before this one
+    u64 Btotal = 0;             // multi-in positions of the whole text
+    u64 s0 = 0, s1 = 0;         // special suffixes [s0, s1) fall into this shard's node range
+    bool facts_ready = false;
+    u64 n_hash_local = 0;
 
     hipEvent_t ev[8]{};         // stage boundaries
     hipEvent_t ev_pass[16][2]{};
@@ -211,7 +221,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q, &c->pidx,
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
-                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work};
+                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -238,7 +248,8 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->h_text = packed;
     c->h_sep.assign(sep, sep + nrec);
-    c->n = n; c->nrec = nrec; c->M = M; c->NS = nrec * (uint64_t)K;
+    c->n = n; c->nrec = nrec; c->M = M; c->Mfull = M; c->NS = nrec * (uint64_t)K;
+    c->shard_rank = 0; c->shard_world = 1; c->key_lo = c->key_hi = 0; c->Mbase = 0; c->qbase = 0;
     size_t tw = (size_t)((n + 63) >> 5) + 2, bw = (size_t)(n >> 6) + 3;
     ENSURE(c, c->text, tw * 8);
     ENSURE(c, c->sepbits, bw * 8);
@@ -311,7 +322,7 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     // the keys (node << 2 | pred) are read off the text inside the first radix pass: no unsorted key array
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K};
+    TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, c->key_lo, c->key_hi};
     int rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), M, 2 * c->cfg.k, &c->sk, true, &ts);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -342,10 +353,9 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
 // ---------------------------------------------------------------------------------------------------
 // stage 2: classification                                                                      (a-8)
 
-extern "C" int debwt_classify(debwt_ctx *c) {
-    if (!c) return DEBWT_EINVAL;
-    if (c->stage < ST_SORTED) return DEBWT_ESTATE;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
+// local half: classification of this shard's distinct keys -> its fact lists [multi-out | multi-in] and its
+// block table (mi_j0, mi_freq, bstart)
+static int classify_local(debwt_ctx *c) {
     const u64 M = c->M, D = c->D, nrec = c->nrec;
     int rc;
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
@@ -358,37 +368,23 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     c->Q = c->h_scalars[1];
     c->Rmo = c->h_scalars[2];
     const u64 Q = c->Q, Rmo = c->Rmo;
-    const u64 nf = Rmo + nrec + Q;
-    c->nfacts = nf;
-    ENSURE(c, c->facts, nf * 8 + 64);
-    ENSURE(c, c->facts_tmp, nf * 8 + 64);
-    ENSURE(c, c->rs_skew, (nf / 2048 + 2) * 4);
-    ENSURE(c, c->red, nf * 8 + 64);
-    ENSURE(c, c->red_q, nf * 4 + 64);
+    ENSURE(c, c->facts, (Rmo + Q) * 8 + 64);
     ENSURE(c, c->mi_j0, Q * 4 + 64);
     ENSURE(c, c->mi_freq, Q * 4 + 64);
     ENSURE(c, c->bstart, Q * 4 + 64);
-    ENSURE(c, c->cursor, Q * 4 + 64);
     ENSURE(c, c->large_q, Q * 4 + 64);
-    // fact list = [multi-out facts | tail# facts | multi-in facts]
     u64 *facts = c->facts.as<u64>();
     {
         const u64 nslots = Q + Rmo;
         ENSURE(c, c->fact_work, nslots * 16 + 64);
         HIPCHK(c, hipMemsetAsync(c->fact_work.p, 0, nslots * 16 + 16, c->stream));
-        FactEmitArgs fa{cc, c->K, cf, facts + Rmo + nrec, c->mi_j0.as<u32>(), c->mi_freq.as<u32>(), facts,
+        FactEmitArgs fa{cc, c->K, cf, facts + Rmo, c->mi_j0.as<u32>(), c->mi_freq.as<u32>(), facts,
                         c->fact_work.as<uint4>()};
         u32 nchunks; u64 chunk;
         plan_chunks(D, &nchunks, &chunk);       // same chunks as the counting sweep (multiples of 1024 keys)
         if (D) k_emit_facts<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(fa, chunk, cp_area(c, 1), cp_area(c, 2));
         if (nslots) k_eval_facts<<<grid_for(nslots, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(fa, nslots);
     }
-    HIPCHK(c, hipMemcpyAsync(facts + Rmo, c->special.tail_facts.data(), nrec * 8, hipMemcpyHostToDevice, c->stream));
-    u64 *sorted_facts = nullptr;
-    if ((rc = sort_keys(c, facts, c->facts_tmp.as<u64>(), nf, 2 * c->cfg.k, &sorted_facts, false))) return rc;
-    RedUniqueF fr{sorted_facts, nf, c->red.as<u64>()};
-    if ((rc = cp_count(c, fr, nf, cp_area(c, 3), 3))) return rc;
-    if ((rc = cp_emit(c, fr, nf, cp_area(c, 3)))) return rc;
     BlockStartF fb{c->mi_freq.as<u32>(), c->bstart.as<u32>()};
     if ((rc = cp_count(c, fb, Q, cp_area(c, 4), 4))) return rc;
     if ((rc = cp_emit(c, fb, Q, cp_area(c, 4)))) return rc;
@@ -396,21 +392,73 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     if ((rc = cp_count(c, fl, Q, cp_area(c, 5), 5))) return rc;
     if ((rc = cp_emit(c, fl, Q, cp_area(c, 5)))) return rc;
     if ((rc = sync_check(c))) return rc;
-    c->R = c->h_scalars[3];
     c->B = c->h_scalars[4];
     c->nlarge = c->h_scalars[5];
+    c->facts_ready = true;
+    return DEBWT_OK;
+}
+
+// global half: the red table from the facts of ALL shards (d_facts: device, nfacts words, any order) plus the
+// tail# facts; identical on every shard
+static int classify_global(debwt_ctx *c, const u64 *d_facts, u64 nfacts, u64 qbase, u64 btotal) {
+    const u64 nrec = c->nrec, Q = c->Q;
+    int rc;
+    const u64 nf = nfacts + nrec;
+    c->nfacts = nf;
+    c->qbase = qbase;
+    c->Btotal = btotal;
+    ENSURE(c, c->facts_all, nf * 8 + 64);
+    ENSURE(c, c->facts_tmp, nf * 8 + 64);
+    ENSURE(c, c->rs_skew, (nf / 2048 + 2) * 4);
+    ENSURE(c, c->red, nf * 8 + 64);
+    ENSURE(c, c->red_q, nf * 4 + 64);
+    u64 *all = c->facts_all.as<u64>();
+    if (nfacts) HIPCHK(c, hipMemcpyAsync(all, d_facts, nfacts * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(all + nfacts, c->special.tail_facts.data(), nrec * 8, hipMemcpyHostToDevice, c->stream));
+    u64 *sorted_facts = nullptr;
+    if ((rc = sort_keys(c, all, c->facts_tmp.as<u64>(), nf, 2 * c->cfg.k, &sorted_facts, false))) return rc;
+    RedUniqueF fr{sorted_facts, nf, c->red.as<u64>()};
+    if ((rc = cp_count(c, fr, nf, cp_area(c, 3), 3))) return rc;
+    if ((rc = cp_emit(c, fr, nf, cp_area(c, 3)))) return rc;
+    if ((rc = sync_check(c))) return rc;
+    c->R = c->h_scalars[3];
     const u64 R = c->R;
     RedBlockF fq{c->red.as<u64>(), c->red_q.as<u32>()};
     if ((rc = cp_count(c, fq, R, cp_area(c, 6), 6))) return rc;
     if ((rc = cp_emit(c, fq, R, cp_area(c, 6)))) return rc;
-    k_special_rows<<<grid_for(c->NS, 256), 256, 0, c->stream>>>(c->sk, M, c->spkey.as<u64>(), c->NS, c->sprow.as<u64>());
+    // special suffixes whose key lies in this shard's node range, and their rows among the shard's instances
+    {
+        const std::vector<uint64_t> &key = c->special.key;          // ascending (suffix order implies key order)
+        u64 s0 = 0, s1 = c->NS;
+        if (c->shard_world > 1) {
+            s0 = std::lower_bound(key.begin(), key.end(), c->key_lo >> 2) - key.begin();
+            s1 = c->key_hi ? (u64)(std::lower_bound(key.begin(), key.end(), c->key_hi >> 2) - key.begin()) : c->NS;
+        }
+        c->s0 = s0; c->s1 = s1;
+        if (s1 > s0)
+            k_special_rows<<<grid_for(s1 - s0, 256), 256, 0, c->stream>>>(c->sk, c->M, c->spkey.as<u64>() + s0, s1 - s0,
+                                                                        c->sprow.as<u64>() + s0);
+    }
     ENSURE(c, c->blue, c->B * 8 + 64);
     if ((rc = sync_check(c))) return rc;
-    if (c->h_scalars[6] != Q) { c->err = "multi-in count mismatch between fact list and red table"; return DEBWT_EINTERNAL; }
+    if (c->shard_world == 1 && c->h_scalars[6] != Q) {
+        c->err = "multi-in count mismatch between fact list and red table";
+        return DEBWT_EINTERNAL;
+    }
     c->st.red_capacity = R; c->st.blue_capacity = c->B; c->st.blue_bound_num = Q; c->st.case3num = 2 * Q;
     c->st.blue_large_blocks = c->nlarge;
     c->stage = ST_CLASSIFIED;
     return DEBWT_OK;
+}
+
+extern "C" int debwt_classify(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_SORTED) return DEBWT_ESTATE;
+    if (c->shard_world > 1) { c->err = "sharded context: use debwt_shard_classify_local/_global"; return DEBWT_ESTATE; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = classify_local(c);
+    if (rc) return rc;
+    return classify_global(c, c->facts.as<u64>(), c->Rmo + c->Q, 0, c->B);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -442,13 +490,14 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->htab.p, 0, ht_slots * 8, c->stream));
     if (c->R)
         k_build_hash<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->red_q.as<u32>(),
-                                                                c->bstart.as<u32>(), hbits, c->htab.as<u64>(),
-                                                                c->cursor.as<u32>(), pb, c->rbits.as<u32>());
+                                                                c->bstart.as<u32>(), (u32)c->qbase, (u32)c->Q, hbits,
+                                                                c->htab.as<u64>(), c->cursor.as<u32>(), pb,
+                                                                c->rbits.as<u32>());
     k_sp_flags<<<grid_for(ngroups, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
         c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<u64>(), hbits, c->rbits.as<u32>(), pb,
         c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), ngroups);
     if (c->n >= (1ull << 32)) { c->err = "n >= 2^32 needs prefix-range passes"; return DEBWT_ERANGE; }
-    ENSURE(c, c->mi_list, c->B * 8 + 64);
+    ENSURE(c, c->mi_list, c->Btotal * 8 + 64);
     SpCountF fc{c->momask.as<u32>(), c->mimask.as<u32>()};
     if ((rc = cp_count2(c, fc, ngroups, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
     {
@@ -457,14 +506,14 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
         u32 nchunks; u64 chunk;
         plan_chunks(ngroups, &nchunks, &chunk);
         k_sp_emit<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ea, ngroups, chunk, cp_area(c, 0), cp_area(c, 1));
-        if (c->B)
-            k_blue_fill<<<grid_for(c->B, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-                c->mi_list.as<u64>(), c->B, c->text.as<u64>(), c->sepbits.as<u64>(), c->K, c->htab.as<u64>(),
+        if (c->Btotal)
+            k_blue_fill<<<grid_for(c->Btotal, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+                c->mi_list.as<u64>(), c->Btotal, c->text.as<u64>(), c->sepbits.as<u64>(), c->K, c->htab.as<u64>(),
                 c->pbits, c->cursor.as<u32>(), c->blue.as<u64>());
     }
     if ((rc = sync_check(c))) return rc;
     c->S = c->h_scalars[8];
-    if (c->h_scalars[10] != c->B) { c->err = "multi-in positions differ from the block total"; return DEBWT_EINTERNAL; }
+    if (c->h_scalars[10] != c->Btotal) { c->err = "multi-in positions differ from the block total"; return DEBWT_EINTERNAL; }
     u64 nwords = (c->S >> 4) + 3;
     ENSURE(c, c->spn, nwords * 8);
     k_pack_sp<<<grid_for(nwords, 256), 256, 0, c->stream>>>(c->spsym.as<u8>(), c->S, nwords, c->spn.as<u64>());
@@ -537,11 +586,15 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
 // ---------------------------------------------------------------------------------------------------
 // stage 5: assembly                                                                            (a-6)
 
+// rows of this shard: its node instances with its special suffixes merged in (the whole BWT when not sharded)
+static u64 shard_rows(const debwt_ctx *c) { return c->M + (c->s1 - c->s0); }
+
 static int run_assemble(debwt_ctx *c, u8 *rowsym) {
-    u64 nw = (c->n + 31) >> 5;
+    const u64 rows = shard_rows(c);
+    u64 nw = (rows + 31) >> 5;
     k_assemble<<<grid_for(nw, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-        c->mchar.as<u8>(), c->M, c->sprow.as<u64>(), c->spchr.as<u8>(), c->NS, c->n, c->bwt.as<u64>(),
-        c->hmask.as<u32>(), c->dollar.as<u64>(), rowsym);
+        c->mchar.as<u8>(), c->M, c->sprow.as<u64>() + c->s0, c->spchr.as<u8>() + c->s0, c->s1 - c->s0, rows,
+        c->bwt.as<u64>(), c->hmask.as<u32>(), c->dollar.as<u64>(), rowsym);
     return DEBWT_OK;
 }
 
@@ -553,13 +606,14 @@ extern "C" int debwt_bwt_assemble(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     HIPCHK(c, hipMemsetAsync(c->dollar.p, 0xFF, 8, c->stream));
     run_assemble(c, nullptr);
-    u64 nw = (c->n + 31) >> 5;
+    u64 nw = (shard_rows(c) + 31) >> 5;
     HashRowsF fh{c->hmask.as<u32>(), c->hash_rows.as<u64>()};
     if ((rc = cp_count(c, fh, nw, cp_area(c, 0), 9))) return rc;
     if ((rc = cp_emit(c, fh, nw, cp_area(c, 0)))) return rc;
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     if ((rc = sync_check(c))) return rc;
-    if (c->h_scalars[9] != c->nrec - 1) {
+    c->n_hash_local = c->h_scalars[9];
+    if (c->shard_world == 1 && c->h_scalars[9] != c->nrec - 1) {
         c->err = "number of '#' rows differs from records-1";
         return DEBWT_EINTERNAL;
     }
@@ -595,6 +649,7 @@ extern "C" int debwt_build(debwt_ctx *c) {
 extern "C" int debwt_fetch_bwt(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row) {
     if (!c || !bwt || !dollar_row || (c->nrec > 1 && !hash_rows)) return DEBWT_EINVAL;
     if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
+    if (c->shard_world > 1) { c->err = "sharded context: use debwt_shard_fetch"; return DEBWT_ESTATE; }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipMemcpyAsync(bwt, c->bwt.p, (size_t)((c->n + 31) >> 5) * 8, hipMemcpyDeviceToHost, c->stream));
     if (c->nrec > 1)
@@ -607,6 +662,103 @@ extern "C" int debwt_bwt_device_ptr(debwt_ctx *c, const uint64_t **d_words) {
     if (!c || !d_words) return DEBWT_EINVAL;
     if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
     *d_words = c->bwt.as<uint64_t>();
+    return DEBWT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k-mer-prefix sharding of one build over several GPUs.  Every shard holds the whole 2-bit text;
+// shard r sorts and classifies the keys of its prefix range, owns their contiguous BWT rows and their blocks.
+// Host orchestration and the collectives live in debwt_amd/sharded.py.
+
+extern "C" int debwt_shard_begin(debwt_ctx *c, int rank, int world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    c->shard_rank = rank; c->shard_world = world;
+    c->key_lo = c->key_hi = 0; c->M = c->Mfull; c->Mbase = 0; c->qbase = 0; c->s0 = 0; c->s1 = c->NS;
+    c->stage = ST_LOADED;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_shard_histogram(debwt_ctx *c, uint64_t *hist4096) {
+    if (!c || !hist4096) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    ENSURE(c, c->shard_hist, SHARD_BINS * 8);
+    HIPCHK(c, hipMemsetAsync(c->shard_hist.p, 0, SHARD_BINS * 8, c->stream));
+    // this shard counts the positions [n*r/w, n*(r+1)/w): the census itself is data-parallel over the text
+    u64 p0 = c->n / c->shard_world * c->shard_rank;
+    u64 p1 = c->shard_rank + 1 == c->shard_world ? c->n : c->n / c->shard_world * (c->shard_rank + 1);
+    k_prefix_hist<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), p0, p1, c->K,
+                                                        c->shard_hist.as<u64>());
+    HIPCHK(c, hipMemcpyAsync(hist4096, c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
+    return sync_check(c);
+}
+
+extern "C" int debwt_shard_set_range(debwt_ctx *c, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_keys, uint64_t m_base) {
+    if (!c || bin_lo > bin_hi || bin_hi > SHARD_BINS) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    if (m_keys > c->Mfull) return DEBWT_EINVAL;
+    const int kb = 2 * c->cfg.k;                       // key bits; a bin is the top 12 of them
+    c->key_lo = (u64)bin_lo << (kb - 12);
+    c->key_hi = bin_hi == SHARD_BINS ? 0ull : ((u64)bin_hi << (kb - 12));   // 0: no upper bound (last shard)
+    c->M = m_keys; c->Mbase = m_base;
+    c->stage = ST_LOADED;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_shard_classify_local(debwt_ctx *c, uint64_t *nfacts, uint64_t *nblocks, uint64_t *blue_rows) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_SORTED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = classify_local(c);
+    if (rc) return rc;
+    if (nfacts) *nfacts = c->Rmo + c->Q;
+    if (nblocks) *nblocks = c->Q;
+    if (blue_rows) *blue_rows = c->B;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_shard_facts_export(debwt_ctx *c, uint64_t *d_dst, uint64_t capacity) {
+    if (!c || !d_dst) return DEBWT_EINVAL;
+    if (!c->facts_ready || capacity < c->Rmo + c->Q) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->Rmo + c->Q)
+        HIPCHK(c, hipMemcpyAsync(d_dst, c->facts.p, (c->Rmo + c->Q) * 8, hipMemcpyDeviceToDevice, c->stream));
+    return sync_check(c);
+}
+
+extern "C" int debwt_shard_classify_global(debwt_ctx *c, const uint64_t *d_facts, uint64_t nfacts, uint64_t qbase,
+                                           uint64_t blue_total) {
+    if (!c || (!d_facts && nfacts)) return DEBWT_EINVAL;
+    if (c->stage < ST_SORTED || !c->facts_ready) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return classify_global(c, (const u64 *)d_facts, nfacts, qbase, blue_total);
+}
+
+extern "C" int debwt_shard_info(debwt_ctx *c, uint64_t *row_base, uint64_t *rows, uint64_t *hash_rows) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_CLASSIFIED) return DEBWT_ESTATE;
+    if (row_base) *row_base = c->Mbase + c->s0;
+    if (rows) *rows = shard_rows(c);
+    if (hash_rows) *hash_rows = c->n_hash_local;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_shard_fetch(debwt_ctx *c, uint64_t *words, uint64_t *hash_rows, uint64_t *dollar_row) {
+    // words: ceil(rows/32), row j of the shard at bit 2*(31-(j&31)) of word j>>5; hash_rows / dollar_row are
+    // GLOBAL rows (dollar_row = ~0 when the '$' row is not in this shard)
+    if (!c || !words || !dollar_row) return DEBWT_EINVAL;
+    if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const u64 rows = shard_rows(c), base = c->Mbase + c->s0;
+    HIPCHK(c, hipMemcpyAsync(words, c->bwt.p, (size_t)((rows + 31) >> 5) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (c->n_hash_local && hash_rows)
+        HIPCHK(c, hipMemcpyAsync(hash_rows, c->hash_rows.p, c->n_hash_local * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dollar_row, c->dollar.p, 8, hipMemcpyDeviceToHost, c->stream));
+    int rc = sync_check(c);
+    if (rc) return rc;
+    for (u64 i = 0; i < c->n_hash_local && hash_rows; i++) hash_rows[i] += base;
+    if (*dollar_row != ~0ull) *dollar_row += base;
     return DEBWT_OK;
 }
 

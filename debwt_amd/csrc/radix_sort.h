@@ -27,6 +27,7 @@ struct TextKeySrc {
     const u64 *sepbits;   // separator bitmap, bit i of word i>>6
     u64 n;                // positions
     int K;                // node length
+    u64 key_lo, key_hi;   // only keys in [key_lo, key_hi) are produced (a k-mer-prefix shard); hi = 0: no upper bound
 };
 
 size_t radix_workspace_bytes(u64 max_keys);

@@ -30,7 +30,9 @@ __device__ __forceinline__ bool rs_load_key(const u64 *__restrict__ in, const Te
         if (sw & ((1ull << ts.K) - 1ull)) return false;                   // window holds a separator: no node
         u64 node = text_window(ts.text, idx) >> (64 - 2 * ts.K);
         u32 pred = idx ? text_symbol(ts.text, idx - 1) : 3u;              // 'T' stands at separators
-        *key = (node << 2) | pred;
+        u64 k = (node << 2) | pred;
+        if (k < ts.key_lo || (ts.key_hi && k >= ts.key_hi)) return false;  // not this shard's prefix range
+        *key = k;
         return true;
     }
 }

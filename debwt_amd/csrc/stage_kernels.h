@@ -136,6 +136,26 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_extract_keys(const u64 *__restr
     keys[i - rho * (u64)L] = key;
 }
 
+// k-mer prefix census for the shard splitters (the reference balances its sort threads on a cumulative
+// 4^12-bin histogram the same way, src/mySort.c:98-110): node keys of positions [p0, p1) by their top 12 bits
+#define SHARD_BINS 4096
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_prefix_hist(const u64 *__restrict__ text,
+                                                              const u64 *__restrict__ sepbits, u64 p0, u64 p1, int K,
+                                                              u64 *__restrict__ hist) {
+    __shared__ u32 h[SHARD_BINS];
+    for (u32 b = threadIdx.x; b < SHARD_BINS; b += DEBWT_BLOCK) h[b] = 0;
+    __syncthreads();
+    const u64 kmask = (1ull << K) - 1ull;
+    for (u64 i = p0 + (u64)blockIdx.x * DEBWT_BLOCK + threadIdx.x; i < p1; i += (u64)gridDim.x * DEBWT_BLOCK) {
+        if (sep_window(sepbits, i) & kmask) continue;
+        u64 node = text_window(text, i) >> (64 - 2 * K);
+        atomicAdd(&h[(u32)(node >> (2 * K - 12))], 1u);          // top 12 bits of the key = top 12 bits of the node
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < SHARD_BINS; b += DEBWT_BLOCK)
+        if (h[b]) atomicAdd(&hist[b], (u64)h[b]);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // run-length encoding of the sorted keys (kmerInfo analogue, src/mySort.c:193-195) + case-2 symbols
 
@@ -349,9 +369,10 @@ struct LargeBlockF {
 __device__ __forceinline__ u32 red_hash(u64 node, int bits) { return (u32)((node * 0x9E3779B97F4A7C15ull) >> (64 - bits)); }
 __device__ __forceinline__ u32 red_hash2(u64 node, int bits) { return (u32)((node * 0xC2B2AE3D27D4EB4Full) >> (64 - bits)); }
 
+#define HCURSOR_SKIP 0xFFFFFFFFu   // multi-in node whose block lives on another shard
 __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__restrict__ red_q,
-                             const u32 *__restrict__ bstart, int hbits, u64 *__restrict__ htab,
-                             u32 *__restrict__ hcursor, int pb, u32 *__restrict__ rbits) {
+                             const u32 *__restrict__ bstart, u32 qbase, u32 Qlocal, int hbits,
+                             u64 *__restrict__ htab, u32 *__restrict__ hcursor, int pb, u32 *__restrict__ rbits) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const u64 v = red[r], node = v >> 2;
@@ -363,7 +384,10 @@ __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__re
         h = (h + 1) & mask;
     }
     // fill cursor of a multi-in node = first blue slot of its block (redPoint analogue, src/INandOut.c:413)
-    if (v & 2ull) hcursor[h] = bstart[red_q[r]];
+    if (v & 2ull) {
+        u32 q = red_q[r] - qbase;                                // wraps for blocks before this shard
+        hcursor[h] = q < Qlocal ? bstart[q] : HCURSOR_SKIP;
+    }
     u32 hb = red_hash2(node, pb);
     atomicOr(&rbits[hb >> 5], 1u << (hb & 31));
 }
@@ -501,6 +525,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const u64 *__restrict
     u64 node = text_window(text, i) >> (64 - 2 * K);
     u32 fl;
     u32 h = red_lookup(htab, hbits, node, &fl);
+    if (hcursor[h] == HCURSOR_SKIP) return;                                 // block owned by another shard
     u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
     u32 slot = atomicAdd(&hcursor[h], 1u);                                  // absolute slot: starts at the block start
     blue[slot] = pred | (sp << 4);                                          // src/generateSP.c:666-672

@@ -109,6 +109,33 @@ int debwt_bwt_device_ptr(debwt_ctx *ctx, const uint64_t **d_words);
 
 int debwt_get_stats(const debwt_ctx *ctx, debwt_stats *out);
 
+/* ---- one build over several GPUs: k-mer-prefix shards ----------------------------------
+ * The reference has no distributed path; these entry points extend the stage sequence above for the case
+ * that one text is built by `world` contexts (one per GPU, each holding the whole 2-bit text).  Shard r sorts
+ * and classifies the keys of one prefix range, owns the BWT rows and the multi-in blocks of those nodes.
+ * Order per shard:  load -> shard_begin -> shard_histogram -> [all-reduce] -> shard_set_range ->
+ * kmer_sort_rle -> shard_classify_local -> shard_facts_export -> [all-gather of the fact lists] ->
+ * shard_classify_global -> sp_generate -> blue_sort -> bwt_assemble -> shard_fetch -> [concatenate by row].
+ * The collectives (bracketed) are the caller's (debwt_amd/sharded.py uses torch.distributed: RCCL or gloo). */
+int debwt_shard_begin(debwt_ctx *ctx, int rank, int world);
+/* counts of this shard's slice of text positions by the top 12 bits of their key: 4096 words (host) */
+int debwt_shard_histogram(debwt_ctx *ctx, uint64_t *hist4096);
+/* this shard takes the keys whose top 12 bits lie in [bin_lo, bin_hi): m_keys of them (from the all-reduced
+ * histogram), m_base keys in the shards before it */
+int debwt_shard_set_range(debwt_ctx *ctx, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_keys, uint64_t m_base);
+int debwt_shard_classify_local(debwt_ctx *ctx, uint64_t *nfacts, uint64_t *nblocks, uint64_t *blue_rows);
+/* copies the shard's nfacts fact words (node<<2 | 1 multi-out, | 2 multi-in) to a DEVICE buffer */
+int debwt_shard_facts_export(debwt_ctx *ctx, uint64_t *d_dst, uint64_t capacity);
+/* d_facts: DEVICE buffer with the facts of all shards (any order); qbase: blocks owned by the shards before
+ * this one; blue_total: sum of blue_rows over all shards */
+int debwt_shard_classify_global(debwt_ctx *ctx, const uint64_t *d_facts, uint64_t nfacts, uint64_t qbase,
+                                uint64_t blue_total);
+/* first global row of the shard, its row count, and (after assemble) its number of '#' rows */
+int debwt_shard_info(debwt_ctx *ctx, uint64_t *row_base, uint64_t *rows, uint64_t *hash_rows);
+/* shard result to host: ceil(rows/32) words packed from the shard's first row; GLOBAL '#' rows; the GLOBAL '$'
+ * row or ~0 when it is not in this shard */
+int debwt_shard_fetch(debwt_ctx *ctx, uint64_t *words, uint64_t *hash_rows, uint64_t *dollar_row);
+
 /* ---- intermediates, for stage-by-stage parity ---------------------------------- */
 typedef enum {
     DEBWT_ARR_SORTED_KEYS = 1, /* u64 x n_main: (node<<2|pred) ascending                              */
