@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--sort-algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # gloo: ranks may share one GPU (tests)
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="N>1: 'replicas' = one independent collection per GPU (default); 'sharded' = ONE "
                          "collection of N x the per-GPU size built by all GPUs as k-mer-prefix shards")
@@ -65,8 +66,11 @@ def main():
 
     rank, local_rank, world = D.env_world()
     assert world == args.gpus or (world == 1 and args.gpus == 1), "launch one process per GPU"
+    if args.backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    D.init(backend="nccl", device_id=torch.device("cuda", local_rank))
+    D.init(backend=args.backend, device_id=torch.device("cuda", local_rank))
+    tdev = "cuda" if args.backend == "nccl" else "cpu"
 
     sharded_mode = args.mode == "sharded" and world > 1
     if sharded_mode:
@@ -100,8 +104,8 @@ def main():
     for _ in range(args.warmup):
         step()
     acc["timed"] = True
-    dt = D.timed_steps(step, steps=args.steps, warmup=0, device_sync=torch.cuda.synchronize, tensor_device="cuda")
-    total_bases = float(n) if sharded_mode else D.sum_over_ranks(n, tensor_device="cuda")
+    dt = D.timed_steps(step, steps=args.steps, warmup=0, device_sync=torch.cuda.synchronize, tensor_device=tdev)
+    total_bases = float(n) if sharded_mode else D.sum_over_ranks(n, tensor_device=tdev)
     pass_ms, pass_launches, stage = acc["pass_ms"], acc["pass_launches"], acc["stage"]
     st = d.stats()
 
