@@ -16,7 +16,7 @@ struct RadixWorkspace {
     u32 *counts;        // [RS_RADIX][RS_MAXCHUNKS + 1] digit-major chunk histograms / offsets + digit totals
     u32 *over;          // hybrid path: [0] = number of oversize tiles, then RS_OVER_CAP (start,len) u64 pairs at +16 B
     u32 *h_over;        // pinned host mirror of `over` (same size)
-    u32 *skew_list;     // hybrid path: ids of tiles finished by the LDS LSD kernel (one u32 per tile)
+    u32 *skew_list;     // hybrid path: one byte per 4096-key tile, set when a 1024-key wave tile did not fit
 };
 #define RS_OVER_CAP 4096
 

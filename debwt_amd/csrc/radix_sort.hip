@@ -185,38 +185,28 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
 // ---------------------------------------------------------------------------------------------------
 // hybrid: local finish of prefix buckets in LDS
 
-#define RL_H (RS_TILE * 7 / 8) // tile stride: tile j starts at the first bucket boundary at or after j*RL_H
-#define RL_CAP RS_TILE      // keys a workgroup can finish in LDS
+#define RL_CAP RS_TILE                 // keys a 256-thread workgroup finishes (4096)
+#define RL_H (RL_CAP * 7 / 8)          // its tile stride: tile j starts at the first bucket boundary >= j*RL_H
+#define RLW_CAP 1024                   // keys a single wave finishes (16 per lane, no barriers at all)
+#define RLW_H (RLW_CAP * 7 / 8)
 
-// first index i >= x (0 < x < n) where the bucket prefix changes (or n); one wave, all lanes return it
-__device__ __forceinline__ u64 rl_boundary(const u64 *__restrict__ keys, u64 n, u64 x, int pshift) {
+// first index i >= x (0 < x < n) where the bucket prefix changes (or n); one wave, all lanes return it.
+// `reach`: how far a boundary may lie for the tile to fit; beyond it the run's end is found by bisection.
+__device__ __forceinline__ u64 rl_boundary(const u64 *__restrict__ keys, u64 n, u64 x, int pshift, u32 reach) {
     const u32 lane = threadIdx.x & 63u;
     const u64 p = keys[x - 1] >> pshift;
-    for (u64 base = x; base < x + (RL_CAP - RL_H); base += 64) {
+    for (u64 base = x; base < x + reach; base += 64) {
         u64 i = base + lane;
         bool diff = i >= n || (keys[i] >> pshift) != p;
         u64 mk = __ballot(diff);
         if (mk) return base + (u64)__ffsll((long long)mk) - 1;
     }
-    u64 lo = x + (RL_CAP - RL_H), hi = n;         // a run that overflows the tile: bisect for its end
+    u64 lo = x + reach, hi = n;                     // a run that overflows the tile: bisect for its end
     while (lo < hi) {
         u64 mid = (lo + hi) >> 1;
         if ((keys[mid] >> pshift) <= p) lo = mid + 1; else hi = mid;
     }
     return lo;
-}
-
-// keys are ordered by their top (key_bits - pshift) bits.  Tile j = [B(j*RL_H), B((j+1)*RL_H)) with B(x) the
-// first bucket boundary >= x, so tiles are disjoint and bucket-aligned, and hold < RL_CAP keys unless a bucket
-// overshoots a tile start by more than RL_CAP - RL_H.  A tile is finished by one workgroup: a bitonic network
-// over RL_CAP keys held 16 per thread in registers (blocked layout: 42 of the 78 steps never leave the thread,
-// 33 are wave shuffles, 3 go through LDS) -- its cost does not depend on the key distribution, so runs of equal
-// k-mers (repeat families) cost the same as unique ones.  A tile that does not fit is queued for the HBM path.
-__device__ __forceinline__ void rl_tile_bounds(const u64 *__restrict__ keys, u64 n, int pshift, u64 j, u64 *sb) {
-    const u32 tid = threadIdx.x;
-    const u64 x0 = j * RL_H, x1 = x0 + RL_H;
-    if ((tid >> 6) == 0) { u64 v = x0 == 0 ? 0 : rl_boundary(keys, n, x0, pshift); if (tid == 0) sb[0] = v; }
-    if ((tid >> 6) == 1) { u64 v = x1 >= n ? n : rl_boundary(keys, n, x1, pshift); if (tid == 64) sb[1] = v; }
 }
 
 #define RL_PAD(x) ((x) + ((x) >> 4))          // one spare word per 16: blocked 128-byte reads hit distinct banks
@@ -227,21 +217,47 @@ __device__ __forceinline__ void rl_cex(u64 &a, u64 &b, bool up) {      // (a,b) 
     a = lo; b = hi;
 }
 
-__global__ __launch_bounds__(RS_BLOCK) void rs_local_kernel(u64 *__restrict__ keys, u64 n, int pshift,
-                                                             u32 *__restrict__ over) {
-    constexpr int KPT = RL_CAP / RS_BLOCK;        // 16 keys per thread
-    constexpr int LOGN = 12;                      // RL_CAP = 4096
-    static_assert(RL_CAP == 4096 && KPT == 16, "network below is laid out for 4096 keys, 16 per thread");
-    __shared__ u64 A[RL_CAP + RL_CAP / 16];
+// keys are ordered by their top (key_bits - pshift) bits.  Tile j = [B(j*H), B((j+1)*H)) with B(x) the first
+// bucket boundary >= x, so tiles are disjoint and bucket-aligned, and hold <= CAP keys unless a bucket overshoots
+// a tile start by more than CAP - H.  A tile is finished by NT threads: a bitonic network over CAP = 16*NT keys
+// held 16 per thread in registers (blocked layout: steps at distance < 16 never leave the thread, distances
+// 16..512 are wave shuffles, only the 256-thread version has 3 steps through LDS) -- its cost does not depend
+// on the key distribution, so runs of equal k-mers (repeat families) cost the same as unique ones.
+//   NT = 64  (first, over all tiles): a tile that does not fit marks the 4096-key tiles that cover it;
+//   NT = 256 (second, marked tiles only; sorting an already sorted stretch again is harmless): a tile that
+//             does not fit is queued for the HBM path.
+template <int NT>
+__global__ __launch_bounds__(NT) void rs_local_kernel(u64 *__restrict__ keys, u64 n, int pshift,
+                                                       u32 *__restrict__ over, u8 *__restrict__ mark) {
+    constexpr int KPT = 16;
+    constexpr u32 CAP = NT * KPT;
+    constexpr u32 H = CAP * 7 / 8;
+    constexpr int LOGN = NT == 64 ? 10 : 12;
+    static_assert(NT == 64 || NT == 256, "wave or 4-wave workgroup");
+    __shared__ u64 A[CAP + CAP / 16];
     __shared__ u64 sb[2];
     const u32 tid = threadIdx.x;
-    rl_tile_bounds(keys, n, pshift, blockIdx.x, sb);
+    if (NT == 256 && !mark[blockIdx.x]) return;
+    const u64 x0 = (u64)blockIdx.x * H, x1 = x0 + H;
+    if (NT == 64) {
+        u64 v0 = x0 == 0 ? 0 : rl_boundary(keys, n, x0, pshift, CAP - H);
+        u64 v1 = x1 >= n ? n : rl_boundary(keys, n, x1, pshift, CAP - H);
+        if (tid == 0) { sb[0] = v0; sb[1] = v1; }
+    } else {
+        if ((tid >> 6) == 0) { u64 v = x0 == 0 ? 0 : rl_boundary(keys, n, x0, pshift, CAP - H); if (tid == 0) sb[0] = v; }
+        if ((tid >> 6) == 1) { u64 v = x1 >= n ? n : rl_boundary(keys, n, x1, pshift, CAP - H); if (tid == 64) sb[1] = v; }
+    }
     __syncthreads();
     const u64 s = sb[0], e = sb[1];
     if (s >= e) return;
     const u64 cnt64 = e - s;
-    if (cnt64 > RL_CAP) {
-        if (tid == 0) {
+    if (cnt64 > CAP) {
+        if (NT == 64) {
+            // hand the stretch to the 4096-key tiles that can overlap it
+            u64 t0 = s / RL_H, t1 = (e - 1) / RL_H;
+            if (t0 > 0) t0--;
+            for (u64 t = t0 + tid; t <= t1; t += NT) mark[t] = 1;
+        } else if (tid == 0) {
             u32 idx = atomicAdd(&over[0], 1u);
             if (idx < RS_OVER_CAP) {
                 u64 *list = reinterpret_cast<u64 *>(over + 4);
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_local_kernel(u64 *__restrict__ ke
         return;
     }
     const u32 cnt = (u32)cnt64;
-    for (u32 i = tid; i < RL_CAP; i += RS_BLOCK) A[RL_PAD(i)] = i < cnt ? keys[s + i] : ~0ull;
+    for (u32 i = tid; i < CAP; i += NT) A[RL_PAD(i)] = i < cnt ? keys[s + i] : ~0ull;
     __syncthreads();
     u64 k[KPT];
 #pragma unroll
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_local_kernel(u64 *__restrict__ ke
 #pragma unroll
     for (int r = 0; r < KPT; r++) A[RL_PAD(tid * KPT + r)] = k[r];
     __syncthreads();
-    for (u32 i = tid; i < cnt; i += RS_BLOCK) keys[s + i] = A[RL_PAD(i)];
+    for (u32 i = tid; i < cnt; i += NT) keys[s + i] = A[RL_PAD(i)];
 }
 
 // oversize tiles: gather their keys into one contiguous scratch array / copy the sorted result back
@@ -393,8 +409,11 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
     u64 *src = rs_lsd(stream, a, b, n, pshift, key_bits, ws, pass_events, max_pairs, npairs, text, aux);
     u64 *other = src == a ? b : a;
     (void)hipMemsetAsync(ws.over, 0, 16, stream);
-    u32 ntiles = (u32)((n + RL_H - 1) / RL_H);
-    rs_local_kernel<<<ntiles, RS_BLOCK, 0, stream>>>(src, n, pshift, ws.over);
+    u32 ntiles = (u32)((n + RL_H - 1) / RL_H), nwtiles = (u32)((n + RLW_H - 1) / RLW_H);
+    u8 *mark = reinterpret_cast<u8 *>(ws.skew_list);          // one byte per 4096-key tile
+    (void)hipMemsetAsync(mark, 0, ntiles + 1, stream);
+    rs_local_kernel<64><<<nwtiles, 64, 0, stream>>>(src, n, pshift, ws.over, mark);
+    rs_local_kernel<256><<<ntiles, 256, 0, stream>>>(src, n, pshift, ws.over, mark);
     (void)hipMemcpyAsync(ws.h_over, ws.over, 16, hipMemcpyDeviceToHost, stream);
     if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;
     u32 nover = ws.h_over[0];
