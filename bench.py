@@ -55,9 +55,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # gloo: ranks may share one GPU (tests)
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+    ap.add_argument("--mode", choices=["replicas", "sharded", "sharded-scan"], default="replicas",
                     help="N>1: 'replicas' = one independent collection per GPU (default); 'sharded' = ONE "
-                         "collection of N x the per-GPU size built by all GPUs as k-mer-prefix shards")
+                         "collection of N x the per-GPU size built by all GPUs as k-mer-prefix shards with the "
+                         "key and blue-entry all_to_all exchanges; 'sharded-scan' = the same shards, every GPU "
+                         "scanning the whole text instead of exchanging")
     args = ap.parse_args()
 
     import torch
@@ -72,7 +74,8 @@ def main():
     D.init(backend=args.backend, device_id=torch.device("cuda", local_rank))
     tdev = "cuda" if args.backend == "nccl" else "cpu"
 
-    sharded_mode = args.mode == "sharded" and world > 1
+    sharded_mode = args.mode.startswith("sharded") and world > 1
+    shard_feed = "scan" if args.mode == "sharded-scan" else "exchange"
     if sharded_mode:
         # ONE collection, `world` records of the per-GPU size, the same text on every rank
         from debwt_amd import sharded as SH
@@ -91,7 +94,7 @@ def main():
 
     def step():
         if sharded_mode:
-            SH.build_sharded(d, torch.device("cuda", local_rank))     # collectives inside; result stays in HBM
+            SH.build_sharded(d, torch.device("cuda", local_rank), mode=shard_feed)   # collectives inside
         else:
             d.build()                         # synchronous: returns after the context's stream drained
         if acc["timed"]:

@@ -36,6 +36,8 @@ SYMBOLS = [
     "debwt_fetch_array", "debwt_kmer_count_sorted", "debwt_radix_sort_u64", "debwt_verify_inverse",
     "debwt_shard_begin", "debwt_shard_histogram", "debwt_shard_set_range", "debwt_shard_classify_local",
     "debwt_shard_facts_export", "debwt_shard_classify_global", "debwt_shard_info", "debwt_shard_fetch",
+    "debwt_shard_partition_keys", "debwt_shard_import_keys", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
+    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place",
 ]
 
 
@@ -102,6 +104,21 @@ def lib():
     L.debwt_shard_facts_export.argtypes = [vp, vp, ctypes.c_uint64]
     L.debwt_shard_classify_global.restype = ctypes.c_int
     L.debwt_shard_classify_global.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
+    u8p, u32p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32)
+    L.debwt_shard_partition_keys.restype = ctypes.c_int
+    L.debwt_shard_partition_keys.argtypes = [vp, u8p, vp, ctypes.c_uint64, u64p]
+    L.debwt_shard_import_keys.restype = ctypes.c_int
+    L.debwt_shard_import_keys.argtypes = [vp, vp, ctypes.c_uint64]
+    L.debwt_shard_sp_flags.restype = ctypes.c_int
+    L.debwt_shard_sp_flags.argtypes = [vp, u64p, u64p]
+    L.debwt_shard_sp_emit.restype = ctypes.c_int
+    L.debwt_shard_sp_emit.argtypes = [vp, ctypes.c_uint64, vp, ctypes.c_uint64]
+    L.debwt_shard_sp_import.restype = ctypes.c_int
+    L.debwt_shard_sp_import.argtypes = [vp, vp, ctypes.c_uint64]
+    L.debwt_shard_blue_route.restype = ctypes.c_int
+    L.debwt_shard_blue_route.argtypes = [vp, u32p, vp, ctypes.c_uint64, u64p]
+    L.debwt_shard_blue_place.restype = ctypes.c_int
+    L.debwt_shard_blue_place.argtypes = [vp, vp, ctypes.c_uint64]
     L.debwt_shard_info.restype = ctypes.c_int
     L.debwt_shard_info.argtypes = [vp, u64p, u64p, u64p]
     L.debwt_shard_fetch.restype = ctypes.c_int

@@ -49,7 +49,7 @@ struct debwt_ctx {
     // device buffers
     DevBuf text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, pidx, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
-        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist;
+        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist, dest_tab, hq, qbounds, qcursor;
     u32 *h_over = nullptr;      // pinned mirror of rs_over
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
@@ -65,6 +65,10 @@ struct debwt_ctx {
     u64 s0 = 0, s1 = 0;         // special suffixes [s0, s1) fall into this shard's node range
     bool facts_ready = false;
     u64 n_hash_local = 0;
+    bool keys_imported = false; // sharded exchange mode: this shard's keys arrived by alltoallv (keysA)
+    u64 g0 = 0, g1 = 0;         // text slice of this shard for the SP stage, in 32-position groups
+    u64 S_local = 0, B_slice = 0, sp_off = 0;
+    int hbits = 10;
 
     hipEvent_t ev[8]{};         // stage boundaries
     hipEvent_t ev_pass[16][2]{};
@@ -221,7 +225,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q, &c->pidx,
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
-                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist};
+                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->hq, &c->qbounds, &c->qcursor};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -250,6 +254,7 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     c->h_sep.assign(sep, sep + nrec);
     c->n = n; c->nrec = nrec; c->M = M; c->Mfull = M; c->NS = nrec * (uint64_t)K;
     c->shard_rank = 0; c->shard_world = 1; c->key_lo = c->key_hi = 0; c->Mbase = 0; c->qbase = 0;
+    c->keys_imported = false;
     size_t tw = (size_t)((n + 63) >> 5) + 2, bw = (size_t)(n >> 6) + 3;
     ENSURE(c, c->text, tw * 8);
     ENSURE(c, c->sepbits, bw * 8);
@@ -323,7 +328,9 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
     // the keys (node << 2 | pred) are read off the text inside the first radix pass: no unsorted key array
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, c->key_lo, c->key_hi};
-    int rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), M, 2 * c->cfg.k, &c->sk, true, &ts);
+    // exchange mode of a sharded build: the shard's keys are already in keysA (alltoallv), sort them from there
+    int rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), M, 2 * c->cfg.k, &c->sk, true,
+                       c->keys_imported ? nullptr : &ts);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     RleF f{c->sk, c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>()};
@@ -464,12 +471,14 @@ extern "C" int debwt_classify(debwt_ctx *c) {
 // ---------------------------------------------------------------------------------------------------
 // stage 3: SP code and blue entries                                                            (a-4)
 
-extern "C" int debwt_sp_generate(debwt_ctx *c) {
-    if (!c) return DEBWT_EINVAL;
-    if (c->stage < ST_CLASSIFIED) return DEBWT_ESTATE;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
+// SP stage in three steps so that a sharded build can cut it at the exchanges:
+//   sp_flags   node table + flags of the text groups [g0, g1) + their multi-out / multi-in counts
+//   sp_emit    SP symbols of the slice at their global offset, work list of the slice's multi-in positions
+//   sp_finish  4-bit packed SP code of the WHOLE text (after the slices' symbols were all-gathered)
+static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
     int rc;
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    if (c->n >= (1ull << 32)) { c->err = "n >= 2^32 needs prefix-range passes"; return DEBWT_ERANGE; }
     // S <= n; the SP symbol buffer is sized for the worst case once
     ENSURE(c, c->spsym, c->n + 64);
     const u64 ngroups = (c->n + 31) >> 5;
@@ -481,45 +490,71 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     int pb = hbits + ((c->cfg.reserved & 15) ? (c->cfg.reserved & 15) - 8 : 3);
     if (pb < 10) pb = 10;
     if (pb > 31 || hbits > 31) { c->err = "red table too large for 32-bit slots"; return DEBWT_ERANGE; }
-    c->pbits = hbits;
+    c->hbits = hbits;
     size_t rb_bytes = ((size_t)1 << pb) / 8 + 64, ht_slots = (size_t)1 << hbits;
     ENSURE(c, c->rbits, rb_bytes);
     ENSURE(c, c->htab, ht_slots * 8);
     ENSURE(c, c->cursor, ht_slots * 4);
+    ENSURE(c, c->hq, ht_slots * 4);
     HIPCHK(c, hipMemsetAsync(c->rbits.p, 0, rb_bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(c->htab.p, 0, ht_slots * 8, c->stream));
     if (c->R)
         k_build_hash<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->red_q.as<u32>(),
                                                                 c->bstart.as<u32>(), (u32)c->qbase, (u32)c->Q, hbits,
-                                                                c->htab.as<u64>(), c->cursor.as<u32>(), pb,
-                                                                c->rbits.as<u32>());
-    k_sp_flags<<<grid_for(ngroups, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-        c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<u64>(), hbits, c->rbits.as<u32>(), pb,
-        c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), ngroups);
-    if (c->n >= (1ull << 32)) { c->err = "n >= 2^32 needs prefix-range passes"; return DEBWT_ERANGE; }
-    ENSURE(c, c->mi_list, c->Btotal * 8 + 64);
-    SpCountF fc{c->momask.as<u32>(), c->mimask.as<u32>()};
-    if ((rc = cp_count2(c, fc, ngroups, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
-    {
-        SpEmitArgs ea{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->momask.as<u32>(), c->mimask.as<u32>(),
-                      c->spsym.as<u8>(), c->mi_list.as<u64>()};
-        u32 nchunks; u64 chunk;
-        plan_chunks(ngroups, &nchunks, &chunk);
-        k_sp_emit<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ea, ngroups, chunk, cp_area(c, 0), cp_area(c, 1));
-        if (c->Btotal)
-            k_blue_fill<<<grid_for(c->Btotal, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-                c->mi_list.as<u64>(), c->Btotal, c->text.as<u64>(), c->sepbits.as<u64>(), c->K, c->htab.as<u64>(),
-                c->pbits, c->cursor.as<u32>(), c->blue.as<u64>());
-    }
+                                                                c->htab.as<u64>(), c->cursor.as<u32>(), c->hq.as<u32>(),
+                                                                pb, c->rbits.as<u32>());
+    c->g0 = g0; c->g1 = g1;
+    const u64 ng = g1 - g0;
+    if (ng)
+        k_sp_flags<<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+            c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<u64>(), hbits, c->rbits.as<u32>(), pb,
+            c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1);
+    SpCountF fc{c->momask.as<u32>() + g0, c->mimask.as<u32>() + g0};
+    if ((rc = cp_count2(c, fc, ng, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
     if ((rc = sync_check(c))) return rc;
-    c->S = c->h_scalars[8];
-    if (c->h_scalars[10] != c->Btotal) { c->err = "multi-in positions differ from the block total"; return DEBWT_EINTERNAL; }
-    u64 nwords = (c->S >> 4) + 3;
+    c->S_local = c->h_scalars[8];
+    c->B_slice = c->h_scalars[10];
+    return DEBWT_OK;
+}
+
+static int sp_emit(debwt_ctx *c, u64 sp_off) {
+    const u64 ng = c->g1 - c->g0;
+    c->sp_off = sp_off;
+    ENSURE(c, c->mi_list, c->B_slice * 8 + 64);
+    if (ng) {
+        SpEmitArgs ea{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->momask.as<u32>(), c->mimask.as<u32>(),
+                      c->spsym.as<u8>(), c->mi_list.as<u64>(), c->g0, (u32)sp_off};
+        u32 nchunks; u64 chunk;
+        plan_chunks(ng, &nchunks, &chunk);
+        k_sp_emit<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ea, ng, chunk, cp_area(c, 0), cp_area(c, 1));
+    }
+    return DEBWT_OK;
+}
+
+static int sp_finish(debwt_ctx *c, u64 S) {
+    c->S = S;
+    u64 nwords = (S >> 4) + 3;
     ENSURE(c, c->spn, nwords * 8);
-    k_pack_sp<<<grid_for(nwords, 256), 256, 0, c->stream>>>(c->spsym.as<u8>(), c->S, nwords, c->spn.as<u64>());
-    c->st.sp_len = c->S;
+    k_pack_sp<<<grid_for(nwords, 256), 256, 0, c->stream>>>(c->spsym.as<u8>(), S, nwords, c->spn.as<u64>());
+    c->st.sp_len = S;
     c->stage = ST_SP;
     return DEBWT_OK;
+}
+
+extern "C" int debwt_sp_generate(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_CLASSIFIED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc;
+    // the whole text on this context (also every shard of a "replicated scan" sharded build)
+    if ((rc = sp_flags(c, 0, (c->n + 31) >> 5))) return rc;
+    if (c->B_slice != c->Btotal) { c->err = "multi-in positions differ from the block total"; return DEBWT_EINTERNAL; }
+    if ((rc = sp_emit(c, 0))) return rc;
+    if (c->B_slice)
+        k_blue_fill<<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+            c->mi_list.as<u64>(), c->B_slice, c->text.as<u64>(), c->sepbits.as<u64>(), c->K, c->htab.as<u64>(),
+            c->hbits, c->cursor.as<u32>(), c->blue.as<u64>());
+    return sp_finish(c, c->S_local);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -673,7 +708,7 @@ extern "C" int debwt_bwt_device_ptr(debwt_ctx *c, const uint64_t **d_words) {
 extern "C" int debwt_shard_begin(debwt_ctx *c, int rank, int world) {
     if (!c || world < 1 || rank < 0 || rank >= world) return DEBWT_EINVAL;
     if (c->stage < ST_LOADED) return DEBWT_ESTATE;
-    c->shard_rank = rank; c->shard_world = world;
+    c->shard_rank = rank; c->shard_world = world; c->keys_imported = false;
     c->key_lo = c->key_hi = 0; c->M = c->Mfull; c->Mbase = 0; c->qbase = 0; c->s0 = 0; c->s1 = c->NS;
     c->stage = ST_LOADED;
     return DEBWT_OK;
@@ -733,6 +768,117 @@ extern "C" int debwt_shard_classify_global(debwt_ctx *c, const uint64_t *d_facts
     if (c->stage < ST_SORTED || !c->facts_ready) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     return classify_global(c, (const u64 *)d_facts, nfacts, qbase, blue_total);
+}
+
+// ---- exchange mode: keys and blue entries travel by alltoallv, every shard scans only its text slice ----------
+
+static void shard_slice(const debwt_ctx *c, u64 *p0, u64 *p1) {
+    // slices are cut at multiples of 32 positions so that the SP stage can work on whole text words
+    u64 per = ((c->n / c->shard_world) >> 5) << 5;
+    *p0 = per * c->shard_rank;
+    *p1 = c->shard_rank + 1 == c->shard_world ? c->n : per * (c->shard_rank + 1);
+}
+
+extern "C" int debwt_shard_partition_keys(debwt_ctx *c, const uint8_t *shard_of_bin, uint64_t *d_out, uint64_t capacity,
+                                          uint64_t *offs) {
+    // keys of this shard's text slice, grouped by destination shard (bucket exchange)
+    if (!c || !shard_of_bin || !d_out || !offs) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    u64 p0, p1;
+    shard_slice(c, &p0, &p1);
+    if (capacity < p1 - p0) return DEBWT_EINVAL;
+    ENSURE(c, c->dest_tab, SHARD_BINS);
+    HIPCHK(c, hipMemcpyAsync(c->dest_tab.p, shard_of_bin, SHARD_BINS, hipMemcpyHostToDevice, c->stream));
+    TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, 0, 0, p0};
+    RsDigit dg{};
+    dg.mode = 1; dg.tab = c->dest_tab.as<u8>(); dg.tshift = 2 * c->cfg.k - 12;
+    hipError_t e = radix_partition_by_shard(c->stream, nullptr, &ts, p1 - p0, (u64 *)d_out, dg, (u32)c->shard_world,
+                                            radix_ws(c), (u64 *)offs);
+    if (e != hipSuccess) { c->err = hipGetErrorString(e); return DEBWT_EDEVICE; }
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_shard_import_keys(debwt_ctx *c, const uint64_t *d_keys, uint64_t count) {
+    if (!c || (!d_keys && count)) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED || count != c->M) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (count) HIPCHK(c, hipMemcpyAsync(c->keysA.p, d_keys, count * 8, hipMemcpyDeviceToDevice, c->stream));
+    c->keys_imported = true;
+    return sync_check(c);
+}
+
+extern "C" int debwt_shard_sp_flags(debwt_ctx *c, uint64_t *sp_symbols, uint64_t *mi_positions) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_CLASSIFIED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    u64 p0, p1;
+    shard_slice(c, &p0, &p1);
+    int rc = sp_flags(c, p0 >> 5, (p1 + 31) >> 5);
+    if (rc) return rc;
+    if (sp_symbols) *sp_symbols = c->S_local;
+    if (mi_positions) *mi_positions = c->B_slice;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_shard_sp_emit(debwt_ctx *c, uint64_t sp_offset, uint8_t *d_dst, uint64_t capacity) {
+    // SP symbols of the slice at global offset sp_offset; a copy of them goes to the DEVICE buffer d_dst
+    if (!c || !d_dst) return DEBWT_EINVAL;
+    if (c->stage < ST_CLASSIFIED || capacity < c->S_local) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = sp_emit(c, sp_offset);
+    if (rc) return rc;
+    if (c->S_local)
+        HIPCHK(c, hipMemcpyAsync(d_dst, c->spsym.as<u8>() + sp_offset, c->S_local, hipMemcpyDeviceToDevice, c->stream));
+    return sync_check(c);
+}
+
+extern "C" int debwt_shard_sp_import(debwt_ctx *c, const uint8_t *d_src, uint64_t sp_total) {
+    // the SP symbols of the whole text (slices concatenated in rank order), DEVICE buffer
+    if (!c || (!d_src && sp_total)) return DEBWT_EINVAL;
+    if (c->stage < ST_CLASSIFIED || sp_total > c->n) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (sp_total) HIPCHK(c, hipMemcpyAsync(c->spsym.p, d_src, sp_total, hipMemcpyDeviceToDevice, c->stream));
+    int rc = sp_finish(c, sp_total);
+    if (rc) return rc;
+    return sync_check(c);
+}
+
+extern "C" int debwt_shard_blue_route(debwt_ctx *c, const uint32_t *first_block_of_shard, uint64_t *d_out,
+                                      uint64_t capacity, uint64_t *offs) {
+    // blue entries of this shard's text slice, grouped by the shard that owns their block
+    if (!c || !first_block_of_shard || !d_out || !offs) return DEBWT_EINVAL;
+    if (c->stage < ST_CLASSIFIED || capacity < c->B_slice) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const u32 w = (u32)c->shard_world;
+    ENSURE(c, c->qbounds, (w + 1) * 4);
+    HIPCHK(c, hipMemcpyAsync(c->qbounds.p, first_block_of_shard, (w + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    for (u32 i = 0; i <= w; i++) offs[i] = 0;
+    if (!c->B_slice) return sync_check(c);
+    ENSURE(c, c->facts_tmp, c->B_slice * 8 + 64);
+    u64 *tmp = c->facts_tmp.as<u64>();
+    k_blue_route<<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+        c->mi_list.as<u64>(), c->B_slice, c->text.as<u64>(), c->sepbits.as<u64>(), c->K, c->htab.as<u64>(), c->hbits,
+        c->hq.as<u32>(), tmp);
+    RsDigit dg{};
+    dg.mode = 2; dg.bounds = c->qbounds.as<u32>(); dg.nb = w;
+    hipError_t e = radix_partition_by_shard(c->stream, tmp, nullptr, c->B_slice, (u64 *)d_out, dg, w, radix_ws(c), (u64 *)offs);
+    if (e != hipSuccess) { c->err = hipGetErrorString(e); return DEBWT_EDEVICE; }
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_shard_blue_place(debwt_ctx *c, const uint64_t *d_entries, uint64_t count) {
+    if (!c || (!d_entries && count)) return DEBWT_EINVAL;
+    if (c->stage < ST_SP) return DEBWT_ESTATE;
+    if (count != c->B) { c->err = "received blue entries differ from the rows of the owned blocks"; return DEBWT_EINTERNAL; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    ENSURE(c, c->qcursor, c->Q * 4 + 64);
+    if (c->Q) HIPCHK(c, hipMemcpyAsync(c->qcursor.p, c->bstart.p, c->Q * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (count)
+        k_blue_place<<<grid_for(count, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>((const u64 *)d_entries, count,
+                                                                                 (u32)c->qbase, (u32)c->Q,
+                                                                                 c->qcursor.as<u32>(), c->blue.as<u64>());
+    return sync_check(c);
 }
 
 extern "C" int debwt_shard_info(debwt_ctx *c, uint64_t *row_base, uint64_t *rows, uint64_t *hash_rows) {

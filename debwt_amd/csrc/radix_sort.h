@@ -28,10 +28,21 @@ struct TextKeySrc {
     u64 n;                // positions
     int K;                // node length
     u64 key_lo, key_hi;   // only keys in [key_lo, key_hi) are produced (a k-mer-prefix shard); hi = 0: no upper bound
+    u64 pos0;             // item i of a pass is text position pos0 + i
+};
+
+// bucket function of a pass (see rs_digit)
+struct RsDigit {
+    int shift; u32 mask;          // mode 0
+    int mode;
+    const u8 *tab; int tshift;    // mode 1: tab[key >> tshift]
+    const u32 *bounds; u32 nb;    // mode 2: owner of block id key >> 36
 };
 
 size_t radix_workspace_bytes(u64 max_keys);
 size_t radix_over_bytes();
+hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const TextKeySrc *text, u64 count, u64 *dst,
+                                    const RsDigit &dg, u32 nshards, const RadixWorkspace &ws, u64 *offs_host);
 
 // Sorts `n` keys ascending on their low `key_bits` bits.  a: input; b: scratch of n words.
 // Returns the buffer (a or b) that holds the result.  All work is enqueued on `stream`.

@@ -16,6 +16,17 @@
 // ---------------------------------------------------------------------------------------------------
 // key sources: SRC 0 = key array, SRC 1 = node keys straight from the packed text (first pass only)
 
+// what a pass buckets by: mode 0 = an 8-bit digit of the key; mode 1 = the shard that owns the key's 12-bit
+// prefix bin (k-mer bucket exchange); mode 2 = the shard that owns the block id carried in bits 36.. of a blue
+// entry (bounds[i] = first block of shard i)
+__device__ __forceinline__ u32 rs_digit(const RsDigit &g, u64 k) {
+    if (g.mode == 0) return (u32)(k >> g.shift) & g.mask;
+    if (g.mode == 1) return g.tab[(k >> g.tshift) & 4095u];   // masked: lanes without a key carry ~0
+    u32 q = (u32)(k >> 36), lo = 0, hi = g.nb;
+    while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (g.bounds[mid] <= q) lo = mid; else hi = mid; }
+    return lo;
+}
+
 template <int SRC>
 __device__ __forceinline__ bool rs_load_key(const u64 *__restrict__ in, const TextKeySrc &ts, u64 idx, u64 end,
                                             u64 *key) {
@@ -26,6 +37,7 @@ __device__ __forceinline__ bool rs_load_key(const u64 *__restrict__ in, const Te
     } else {
         *key = ~0ull;
         if (idx >= end) return false;
+        idx += ts.pos0;                                                   // slice of the text (shard exchange)
         u64 sw = sep_window(ts.sepbits, idx);
         if (sw & ((1ull << ts.K) - 1ull)) return false;                   // window holds a separator: no node
         u64 node = text_window(ts.text, idx) >> (64 - 2 * ts.K);
@@ -44,7 +56,7 @@ __device__ __forceinline__ bool rs_load_key(const u64 *__restrict__ in, const Te
 // so that profiler averages of the key-sort passes are not diluted by them
 template <int SRC, int AUX>
 __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict__ keys, TextKeySrc ts, u64 n,
-                                                            u64 chunk, int shift, u32 mask, u32 *__restrict__ counts,
+                                                            u64 chunk, RsDigit dg, u32 *__restrict__ counts,
                                                             u32 nchunks) {
     __shared__ u32 h[RS_RADIX];
     h[threadIdx.x] = 0;
@@ -56,16 +68,16 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict
         for (u64 i = beg + 2ull * threadIdx.x; i < end; i += 2ull * RS_BLOCK) {
             if (i + 1 < end) {
                 ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + i);
-                atomicAdd(&h[(u32)(v.x >> shift) & mask], 1u);
-                atomicAdd(&h[(u32)(v.y >> shift) & mask], 1u);
+                atomicAdd(&h[rs_digit(dg, v.x)], 1u);
+                atomicAdd(&h[rs_digit(dg, v.y)], 1u);
             } else {
-                atomicAdd(&h[(u32)(keys[i] >> shift) & mask], 1u);
+                atomicAdd(&h[rs_digit(dg, keys[i])], 1u);
             }
         }
     } else {
         for (u64 i = beg + threadIdx.x; i < end; i += RS_BLOCK) {
             u64 k;
-            if (rs_load_key<1>(keys, ts, i, end, &k)) atomicAdd(&h[(u32)(k >> shift) & mask], 1u);
+            if (rs_load_key<1>(keys, ts, i, end, &k)) atomicAdd(&h[rs_digit(dg, k)], 1u);
         }
     }
     __syncthreads();
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(RS_RADIX) void rs_scan_tot_kernel(u32 *__restrict__
 // first LDS slot of digit d, and the return value of each thread d is the tile's count of digit d.
 // `cnt` is the number of valid keys of the tile (invalid slots only at the very end of the input).
 template <int SRC = 0>
-__device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile, u64 end, int shift, u32 mask,
+__device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile, u64 end, const RsDigit &dg,
                                             u64 *skeys, u32 (*wavecnt)[RS_RADIX], u32 *lstart, u32 *scan_tmp,
                                             u32 *tile_total, const TextKeySrc &ts = TextKeySrc{}) {
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -123,7 +135,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         bool valid = (vmask >> r) & 1u;
-        u32 d = (u32)(key[r] >> shift) & mask;
+        u32 d = rs_digit(dg, key[r]);
         u64 m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -146,7 +158,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         if ((vmask >> r) & 1u) {
-            u32 d = (u32)(key[r] >> shift) & mask;
+            u32 d = rs_digit(dg, key[r]);
             skeys[lstart[d] + wavecnt[w][d] + rnk[r]] = key[r];
         }
     }
@@ -156,8 +168,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile
 
 template <int SRC, int AUX>
 __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts,
-                                                               u64 *__restrict__ out, u64 n, u64 chunk, int shift,
-                                                               u32 mask,
+                                                               u64 *__restrict__ out, u64 n, u64 chunk, RsDigit dg,
                                                                const u32 *__restrict__ offsets,
                                                                const u32 *__restrict__ digit_base, u32 nchunks) {
     __shared__ u64 skeys[RS_TILE];
@@ -171,10 +182,10 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
     u64 end = beg + chunk < n ? beg + chunk : n;
     for (u64 tile = beg; tile < end; tile += RS_TILE) {
         u32 tot;
-        u32 mine = rs_rank_tile<SRC>(in, tile, end, shift, mask, skeys, wavecnt, lstart, scan_tmp, &tot, ts);
+        u32 mine = rs_rank_tile<SRC>(in, tile, end, dg, skeys, wavecnt, lstart, scan_tmp, &tot, ts);
         for (u32 j = tid; j < tot; j += RS_BLOCK) {
             u64 k = skeys[j];
-            u32 d = (u32)(k >> shift) & mask;
+            u32 d = rs_digit(dg, k);
             out[(u64)run[d] + (j - lstart[d])] = k;
         }
         __syncthreads();
@@ -359,30 +370,31 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
     TextKeySrc none{};
     for (int shift = lo_bit; shift < hi_bit; shift += 8, p++) {
         int bits = hi_bit - shift < 8 ? hi_bit - shift : 8;
-        u32 mask = (1u << bits) - 1u;
+        RsDigit dg{};
+        dg.shift = shift; dg.mask = (1u << bits) - 1u;
         const bool from_text = text && p == 0;
         u32 nchunks; u64 chunk;
         rs_plan(from_text ? text->n : n, &nchunks, &chunk);
         u32 *digit_tot = ws.counts + (size_t)RS_RADIX * RS_MAXCHUNKS;
         if (from_text) {
-            rs_hist_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, text->n, chunk, shift, mask, ws.counts, nchunks);
+            rs_hist_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, text->n, chunk, dg, ws.counts, nchunks);
             rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
             rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
-            rs_scatter_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, a, text->n, chunk, shift, mask,
-                                                                   ws.counts, digit_tot, nchunks);
+            rs_scatter_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts,
+                                                                   digit_tot, nchunks);
             src = a; dst = b;
             continue;
         }
         bool ev = pass_events && ev_idx < max_pairs;
-        if (aux) rs_hist_kernel<0, 1><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, n, chunk, shift, mask, ws.counts, nchunks);
-        else rs_hist_kernel<0, 0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, n, chunk, shift, mask, ws.counts, nchunks);
+        if (aux) rs_hist_kernel<0, 1><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, n, chunk, dg, ws.counts, nchunks);
+        else rs_hist_kernel<0, 0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, n, chunk, dg, ws.counts, nchunks);
         rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
         rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
         if (ev) (void)hipEventRecord(pass_events[2 * ev_idx], stream);
-        if (aux) rs_scatter_kernel<0, 1><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, n, chunk, shift, mask,
-                                                                          ws.counts, digit_tot, nchunks);
-        else rs_scatter_kernel<0, 0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, n, chunk, shift, mask,
-                                                                      ws.counts, digit_tot, nchunks);
+        if (aux) rs_scatter_kernel<0, 1><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts,
+                                                                          digit_tot, nchunks);
+        else rs_scatter_kernel<0, 0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts,
+                                                                      digit_tot, nchunks);
         if (ev) { (void)hipEventRecord(pass_events[2 * ev_idx + 1], stream); ev_idx++; if (npairs) *npairs = ev_idx; }
         u64 *t = src; src = dst; dst = t;
     }
@@ -452,4 +464,32 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
     }
     *err = hipGetLastError();
     return src;
+}
+
+// One bucketing pass by destination shard: `count` source items (text positions [text->pos0, +count) when `text`
+// is given, else the keys in `src`) -> `dst` grouped by shard; offs_host[0..nshards] receives the group offsets.
+hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const TextKeySrc *text, u64 count, u64 *dst,
+                                    const RsDigit &dg, u32 nshards, const RadixWorkspace &ws, u64 *offs_host) {
+    TextKeySrc none{};
+    u32 nchunks; u64 chunk;
+    rs_plan(count, &nchunks, &chunk);
+    u32 *digit_tot = ws.counts + (size_t)RS_RADIX * RS_MAXCHUNKS;
+    if (text) {
+        TextKeySrc ts = *text;
+        rs_hist_kernel<1, 1><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, ts, count, chunk, dg, ws.counts, nchunks);
+    } else {
+        rs_hist_kernel<0, 1><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, count, chunk, dg, ws.counts, nchunks);
+    }
+    rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
+    rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
+    if (text) rs_scatter_kernel<1, 1><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    else rs_scatter_kernel<0, 1><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    u32 tot[RS_RADIX];
+    hipError_t e = hipMemcpyAsync(tot, digit_tot, sizeof tot, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    // digit_tot holds exclusive offsets; the last group ends at the number of valid items
+    for (u32 i = 0; i < nshards; i++) offs_host[i] = tot[i];
+    offs_host[nshards] = nshards < RS_RADIX ? tot[nshards] : 0;   // first empty digit starts where the data ends
+    return hipGetLastError();
 }

@@ -372,7 +372,8 @@ __device__ __forceinline__ u32 red_hash2(u64 node, int bits) { return (u32)((nod
 #define HCURSOR_SKIP 0xFFFFFFFFu   // multi-in node whose block lives on another shard
 __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__restrict__ red_q,
                              const u32 *__restrict__ bstart, u32 qbase, u32 Qlocal, int hbits,
-                             u64 *__restrict__ htab, u32 *__restrict__ hcursor, int pb, u32 *__restrict__ rbits) {
+                             u64 *__restrict__ htab, u32 *__restrict__ hcursor, u32 *__restrict__ hq, int pb,
+                             u32 *__restrict__ rbits) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const u64 v = red[r], node = v >> 2;
@@ -387,6 +388,7 @@ __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__re
     if (v & 2ull) {
         u32 q = red_q[r] - qbase;                                // wraps for blocks before this shard
         hcursor[h] = q < Qlocal ? bstart[q] : HCURSOR_SKIP;
+        hq[h] = red_q[r];                                        // global block id (blue-entry exchange)
     }
     u32 hb = red_hash2(node, pb);
     atomicOr(&rbits[hb >> 5], 1u << (hb & 31));
@@ -422,9 +424,9 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
                                                            const u32 *__restrict__ rbits, int pb,
                                                            const u64 *__restrict__ branch, u64 nbranch,
                                                            u32 *__restrict__ momask, u32 *__restrict__ mimask,
-                                                           u64 ngroups) {
-    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngroups) return;
+                                                           u64 g0, u64 g1) {
+    u64 g = g0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= g1) return;
     const u64 w0 = text[g], w1 = text[g + 1];
     const u64 sb = sep_window(sepbits, g << 5);
     const u64 kmask = (1ull << K) - 1ull;
@@ -478,6 +480,8 @@ struct SpEmitArgs {
     const u64 *text; const u64 *sepbits; u64 n; int K;
     const u32 *momask; const u32 *mimask;
     u8 *spsym; u64 *mi_list;
+    u64 g0;                    // first group of the slice (the scan arrays are indexed relative to it)
+    u32 sp_base;               // SP symbols emitted by the slices before this one
 };
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngroups, u64 chunk,
                                                           const u32 *__restrict__ off_mo,
@@ -485,11 +489,12 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
     __shared__ u32 tmp[2 * DEBWT_WAVES];
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < ngroups ? beg + chunk : ngroups;
-    u32 base_mo = off_mo[blockIdx.x], base_mi = off_mi[blockIdx.x];
+    u32 base_mo = off_mo[blockIdx.x] + a.sp_base, base_mi = off_mi[blockIdx.x];
     for (u64 tile = beg; tile < end; tile += DEBWT_BLOCK) {
         u64 g = tile + threadIdx.x;
         u32 mo = 0, mi = 0;
-        if (g < end) { mo = a.momask[g]; mi = a.mimask[g]; }
+        if (g < end) { mo = a.momask[a.g0 + g]; mi = a.mimask[a.g0 + g]; }
+        g += a.g0;
         u32 val[2] = {(u32)__popc(mo), (u32)__popc(mi)}, ex[2], tot[2];
         block_scan_excl_vec<2>(val, ex, tot, tmp);
         u32 off = base_mo + ex[0], omi = base_mi + ex[1];
@@ -529,6 +534,36 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const u64 *__restrict
     u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
     u32 slot = atomicAdd(&hcursor[h], 1u);                                  // absolute slot: starts at the block start
     blue[slot] = pred | (sp << 4);                                          // src/generateSP.c:666-672
+}
+
+// sharded build: a multi-in position of this shard's text slice -> (global block id << 36 | spIndex << 4 | pred),
+// to be sent to the shard that owns the block; and the owner's placement of the entries it received
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route(const u64 *__restrict__ mi_list, u64 B,
+                                                             const u64 *__restrict__ text,
+                                                             const u64 *__restrict__ sepbits, int K,
+                                                             const u64 *__restrict__ htab, int hbits,
+                                                             const u32 *__restrict__ hq, u64 *__restrict__ out) {
+    u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    u64 ent = mi_list[b];
+    u64 i = ent & 0xFFFFFFFFull, sp = ent >> 32;
+    u64 node = text_window(text, i) >> (64 - 2 * K);
+    u32 fl;
+    u32 h = red_lookup(htab, hbits, node, &fl);
+    u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
+    u64 q = h == 0xFFFFFFFFu ? 0xFFFFFFFull : (u64)hq[h];
+    out[b] = (q << 36) | (sp << 4) | pred;
+}
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_place(const u64 *__restrict__ ent, u64 count, u32 qbase,
+                                                             u32 Qlocal, u32 *__restrict__ qcursor,
+                                                             u64 *__restrict__ blue) {
+    u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    u64 e = ent[b];
+    u32 q = (u32)(e >> 36) - qbase;
+    if (q >= Qlocal) return;                                                // misrouted entry: never index outside
+    u32 slot = atomicAdd(&qcursor[q], 1u);
+    blue[slot] = e & 0xFFFFFFFFFull;                                        // pred | spIndex << 4
 }
 
 // SP symbols -> 4 bits per symbol, 16 per word, symbol s at bits 60-4*(s&15): integer order of a

@@ -130,6 +130,24 @@ int debwt_shard_facts_export(debwt_ctx *ctx, uint64_t *d_dst, uint64_t capacity)
  * this one; blue_total: sum of blue_rows over all shards */
 int debwt_shard_classify_global(debwt_ctx *ctx, const uint64_t *d_facts, uint64_t nfacts, uint64_t qbase,
                                 uint64_t blue_total);
+/* Exchange mode (scales with the GPU count: every shard scans only its 1/world slice of the text):
+ *   shard_partition_keys -> [alltoallv of 8-byte keys, the k-mer bucket exchange] -> shard_import_keys ->
+ *   kmer_sort_rle -> classify_local/_global as above -> shard_sp_flags -> [all-gather of the slice SP lengths]
+ *   -> shard_sp_emit -> [all-gather of the slice SP symbols] -> shard_sp_import -> shard_blue_route ->
+ *   [alltoallv of 8-byte blue entries] -> shard_blue_place -> blue_sort -> bwt_assemble.
+ * shard_of_bin: 4096 bytes (host), shard owning each 12-bit prefix bin; d_out: DEVICE buffer of `capacity`
+ * words; offs: world+1 host words, group i = d_out[offs[i] .. offs[i+1]). */
+int debwt_shard_partition_keys(debwt_ctx *ctx, const uint8_t *shard_of_bin, uint64_t *d_out, uint64_t capacity,
+                               uint64_t *offs);
+int debwt_shard_import_keys(debwt_ctx *ctx, const uint64_t *d_keys, uint64_t count);
+int debwt_shard_sp_flags(debwt_ctx *ctx, uint64_t *sp_symbols, uint64_t *mi_positions);
+int debwt_shard_sp_emit(debwt_ctx *ctx, uint64_t sp_offset, uint8_t *d_dst, uint64_t capacity);
+int debwt_shard_sp_import(debwt_ctx *ctx, const uint8_t *d_src, uint64_t sp_total);
+/* first_block_of_shard: world+1 host words (exclusive scan of the shards' block counts) */
+int debwt_shard_blue_route(debwt_ctx *ctx, const uint32_t *first_block_of_shard, uint64_t *d_out, uint64_t capacity,
+                           uint64_t *offs);
+int debwt_shard_blue_place(debwt_ctx *ctx, const uint64_t *d_entries, uint64_t count);
+
 /* first global row of the shard, its row count, and (after assemble) its number of '#' rows */
 int debwt_shard_info(debwt_ctx *ctx, uint64_t *row_base, uint64_t *rows, uint64_t *hash_rows);
 /* shard result to host: ceil(rows/32) words packed from the shard's first row; GLOBAL '#' rows; the GLOBAL '$'
