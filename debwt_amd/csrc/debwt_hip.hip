@@ -533,9 +533,9 @@ static int sp_emit(debwt_ctx *c, u64 sp_off) {
 
 static int sp_finish(debwt_ctx *c, u64 S) {
     c->S = S;
-    u64 nwords = (S >> 4) + 3;
-    ENSURE(c, c->spn, nwords * 8);
-    k_pack_sp<<<grid_for(nwords, 256), 256, 0, c->stream>>>(c->spsym.as<u8>(), S, nwords, c->spn.as<u64>());
+    u64 ntriples = (S >> 6) + 3;                 // 64 symbols = 3 words; two spare groups of zeros behind the end
+    ENSURE(c, c->spn, ntriples * 24);
+    k_pack_sp<<<grid_for(ntriples, 256), 256, 0, c->stream>>>(c->spsym.as<u8>(), S, ntriples, c->spn.as<u64>());
     c->st.sp_len = S;
     c->stage = ST_SP;
     return DEBWT_OK;

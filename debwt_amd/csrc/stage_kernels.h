@@ -566,27 +566,34 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_place(const u64 *__restric
     blue[slot] = e & 0xFFFFFFFFFull;                                        // pred | spIndex << 4
 }
 
-// SP symbols -> 4 bits per symbol, 16 per word, symbol s at bits 60-4*(s&15): integer order of a
-// window = order of the symbol string under A<C<G<T<#<$
-__global__ void k_pack_sp(const u8 *__restrict__ spsym, u64 S, u64 nwords, u64 *__restrict__ spn) {
-    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwords) return;
-    u64 v = 0;
-    u64 base = w << 4;
-    for (u32 t = 0; t < 16; t++) {
-        u64 s = base + t;
-        u64 c = s < S ? (u64)spsym[s] : 0ull;
-        v |= c << (60 - 4 * t);
+// SP symbols -> 3 bits per symbol in one MSB-first bit stream (symbol s at stream bits [3s, 3s+3)); a window
+// is the 63 bits = 21 symbols that start at a symbol: integer order of windows = order of the symbol strings
+// under A<C<G<T<#<$ (codes 0..5).  One thread packs 64 symbols = 3 words.
+#define SP_WIN 21
+__global__ void k_pack_sp(const u8 *__restrict__ spsym, u64 S, u64 ntriples, u64 *__restrict__ spn) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntriples) return;
+    u64 w[3] = {0, 0, 0};
+    u64 base = t << 6;
+#pragma unroll
+    for (u32 j = 0; j < 64; j++) {
+        u64 sidx = base + j;
+        u64 c = sidx < S ? (u64)spsym[sidx] : 0ull;
+        const u32 bit = 3 * j;                 // position in the 192-bit group, MSB first
+        const u32 wi = bit >> 6, off = bit & 63;
+        if (off <= 61) w[wi] |= c << (61 - off);
+        else { w[wi] |= c >> (off - 61); w[wi + 1] |= c << (125 - off); }
     }
-    spn[w] = v;
+    spn[3 * t] = w[0]; spn[3 * t + 1] = w[1]; spn[3 * t + 2] = w[2];
 }
 
 __device__ __forceinline__ u64 sp_window(const u64 *__restrict__ spn, u64 s) {
-    u64 w = s >> 4;
-    u32 sh = (u32)(s & 15) << 2;
+    u64 b = 3 * s;
+    u64 w = b >> 6;
+    u32 sh = (u32)(b & 63);
     u64 a = spn[w];
-    if (sh == 0) return a;
-    return (a << sh) | (spn[w + 1] >> (64 - sh));
+    u64 v = sh ? ((a << sh) | (spn[w + 1] >> (64 - sh))) : a;
+    return v >> 1;                              // 21 symbols
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -595,11 +602,11 @@ __device__ __forceinline__ u64 sp_window(const u64 *__restrict__ spn, u64 s) {
 // a < b by SP suffix beyond the first window (entries are distinct SP positions of one node: the
 // suffixes differ before the unique '$' that ends the SP code)
 __device__ __forceinline__ bool sp_less_deep(const u64 *__restrict__ spn, u64 S, u64 ea, u64 eb) {
-    u64 a = (ea >> 4) + 16, b = (eb >> 4) + 16;
+    u64 a = (ea >> 4) + SP_WIN, b = (eb >> 4) + SP_WIN;
     while (a < S && b < S) {
         u64 wa = sp_window(spn, a), wb = sp_window(spn, b);
         if (wa != wb) return wa < wb;
-        a += 16; b += 16;
+        a += SP_WIN; b += SP_WIN;
     }
     return a > b;   // not reached on consistent input
 }
@@ -607,7 +614,7 @@ __device__ __forceinline__ bool sp_less_deep(const u64 *__restrict__ spn, u64 S,
 #define BLUE_WAVE_CAP 512   // largest block sorted by a single-wave workgroup
 
 // Block sort by level-wise refinement (the data-parallel form of myQsort + cmpSP, src/sortBlue.c:109-280):
-// round d orders the still-tied entries by their d-th 16-symbol SP window; entries whose tie group has
+// round d orders the still-tied entries by their d-th 21-symbol SP window; entries whose tie group has
 // become a single row, or whose group carries a single BWT symbol (the reference's early-out,
 // src/sortBlue.c:192-219), leave the game.  One SP gather per unresolved entry per round -- not per
 // comparison.  A workgroup of NT threads holds the block in LDS; each round is a bitonic network on
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             for (u32 x = tid; x < m; x += NT) {
                 u32 g = sg[x];
                 bool unresolved = gcnt[g] > 1 && (gmsk[g] & (gmsk[g] - 1));
-                u64 pos = (se[x] >> 4) + (depth << 4);
+                u64 pos = (se[x] >> 4) + depth * SP_WIN;
                 sw[x] = (unresolved && pos < S) ? sp_window(spn, pos) : 0ull;
             }
             __syncthreads();
@@ -763,7 +770,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             }
             if (any) { flag = 1; atomicMax(&smax, any); }
             __syncthreads();
-            active = flag != 0 && ((depth + 1) << 4) < S + 16;
+            active = flag != 0 && (depth + 1) * SP_WIN < S + SP_WIN;
             maxg = smax;
             __syncthreads();
         }
