@@ -48,12 +48,11 @@ struct debwt_ctx {
 
     // device buffers
     DevBuf text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
-        red, red_q, pidx, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
-        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist, dest_tab, hq, qbounds, qcursor;
+        red, red_q, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
+        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist, dest_tab, qbounds, qcursor;
     u32 *h_over = nullptr;      // pinned mirror of rs_over
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
-    int pbits = 8;
     u64 D = 0, Q = 0, Rmo = 0, R = 0, B = 0, S = 0, nlarge = 0, nfacts = 0;
     // k-mer-prefix shard of a multi-GPU build (world == 1: the whole key space)
     int shard_rank = 0, shard_world = 1;
@@ -222,10 +221,10 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->text, &c->sepbits, &c->sep, &c->keysA, &c->keysB, &c->rs_counts, &c->cp_counts, &c->dk,
-                     &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q, &c->pidx,
+                     &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q,
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
-                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->hq, &c->qbounds, &c->qcursor};
+                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -343,7 +342,6 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
     c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     const SpecialTables &sp = c->special;
     ENSURE(c, c->branch, sp.branch.size() * 8 + 64);
-    ENSURE(c, c->facts_tmp, c->nrec * 8 + 64);
     HIPCHK(c, hipMemcpyAsync(c->head_keys.p, sp.head_keys.data(), c->nrec * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->spkey.p, sp.key.data(), c->NS * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->spchr.p, sp.chr.data(), c->NS, hipMemcpyHostToDevice, c->stream));
@@ -493,21 +491,18 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
     c->hbits = hbits;
     size_t rb_bytes = ((size_t)1 << pb) / 8 + 64, ht_slots = (size_t)1 << hbits;
     ENSURE(c, c->rbits, rb_bytes);
-    ENSURE(c, c->htab, ht_slots * 8);
-    ENSURE(c, c->cursor, ht_slots * 4);
-    ENSURE(c, c->hq, ht_slots * 4);
+    ENSURE(c, c->htab, ht_slots * sizeof(HSlot));
     HIPCHK(c, hipMemsetAsync(c->rbits.p, 0, rb_bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->htab.p, 0, ht_slots * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->htab.p, 0, ht_slots * sizeof(HSlot), c->stream));
     if (c->R)
         k_build_hash<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->red_q.as<u32>(),
                                                                 c->bstart.as<u32>(), (u32)c->qbase, (u32)c->Q, hbits,
-                                                                c->htab.as<u64>(), c->cursor.as<u32>(), c->hq.as<u32>(),
-                                                                pb, c->rbits.as<u32>());
+                                                                c->htab.as<HSlot>(), pb, c->rbits.as<u32>());
     c->g0 = g0; c->g1 = g1;
     const u64 ng = g1 - g0;
     if (ng)
         k_sp_flags<<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-            c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<u64>(), hbits, c->rbits.as<u32>(), pb,
+            c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), hbits, c->rbits.as<u32>(), pb,
             c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1);
     SpCountF fc{c->momask.as<u32>() + g0, c->mimask.as<u32>() + g0};
     if ((rc = cp_count2(c, fc, ng, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
@@ -520,10 +515,10 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
 static int sp_emit(debwt_ctx *c, u64 sp_off) {
     const u64 ng = c->g1 - c->g0;
     c->sp_off = sp_off;
-    ENSURE(c, c->mi_list, c->B_slice * 8 + 64);
+    ENSURE(c, c->mi_list, c->B_slice * 16 + 64);
     if (ng) {
         SpEmitArgs ea{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->momask.as<u32>(), c->mimask.as<u32>(),
-                      c->spsym.as<u8>(), c->mi_list.as<u64>(), c->g0, (u32)sp_off};
+                      c->spsym.as<u8>(), c->mi_list.as<ulonglong2>(), c->g0, (u32)sp_off};
         u32 nchunks; u64 chunk;
         plan_chunks(ng, &nchunks, &chunk);
         k_sp_emit<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ea, ng, chunk, cp_area(c, 0), cp_area(c, 1));
@@ -552,8 +547,7 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     if ((rc = sp_emit(c, 0))) return rc;
     if (c->B_slice)
         k_blue_fill<<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-            c->mi_list.as<u64>(), c->B_slice, c->text.as<u64>(), c->sepbits.as<u64>(), c->K, c->htab.as<u64>(),
-            c->hbits, c->cursor.as<u32>(), c->blue.as<u64>());
+            c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, c->blue.as<u64>());
     return sp_finish(c, c->S_local);
 }
 
@@ -858,8 +852,7 @@ extern "C" int debwt_shard_blue_route(debwt_ctx *c, const uint32_t *first_block_
     ENSURE(c, c->facts_tmp, c->B_slice * 8 + 64);
     u64 *tmp = c->facts_tmp.as<u64>();
     k_blue_route<<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-        c->mi_list.as<u64>(), c->B_slice, c->text.as<u64>(), c->sepbits.as<u64>(), c->K, c->htab.as<u64>(), c->hbits,
-        c->hq.as<u32>(), tmp);
+        c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, tmp);
     RsDigit dg{};
     dg.mode = 2; dg.bounds = c->qbounds.as<u32>(); dg.nb = w;
     hipError_t e = radix_partition_by_shard(c->stream, tmp, nullptr, c->B_slice, (u64 *)d_out, dg, w, radix_ws(c), (u64 *)offs);

@@ -111,27 +111,32 @@ __global__ __launch_bounds__(RS_RADIX) void rs_scan_tot_kernel(u32 *__restrict__
     tot[threadIdx.x] = block_scan_excl(v, tmp, &t);
 }
 
-// Rank one tile.  On return skeys holds the tile's keys grouped by digit (stable), lstart[d] the
-// first LDS slot of digit d, and the return value of each thread d is the tile's count of digit d.
-// `cnt` is the number of valid keys of the tile (invalid slots only at the very end of the input).
-template <int SRC = 0>
-__device__ __forceinline__ u32 rs_rank_tile(const u64 *__restrict__ in, u64 tile, u64 end, const RsDigit &dg,
-                                            u64 *skeys, u32 (*wavecnt)[RS_RADIX], u32 *lstart, u32 *scan_tmp,
-                                            u32 *tile_total, const TextKeySrc &ts = TextKeySrc{}) {
-    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-#pragma unroll
-    for (u32 i = 0; i < DEBWT_WAVES; i++) wavecnt[i][tid] = 0;
-    __syncthreads();
-    u64 key[RS_ITEMS];
-    u32 rnk[RS_ITEMS];
+// Tile = RS_TILE items, wave-striped: wave w owns items [w*64*RS_ITEMS, ...), round r of it the 64 consecutive
+// items at r*64 (one coalesced 512-byte load per round).
+template <int SRC>
+__device__ __forceinline__ u32 rs_load_tile(const u64 *__restrict__ in, const TextKeySrc &ts, u64 tile, u64 end,
+                                            u64 (&key)[RS_ITEMS]) {
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const u64 wbase = tile + (u64)w * (64u * RS_ITEMS);
-    const u64 lt = (1ull << lane) - 1ull;
     u32 vmask = 0;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         u64 idx = wbase + (u64)r * 64u + lane;
         if (rs_load_key<SRC>(in, ts, idx, end, &key[r])) vmask |= 1u << r;
     }
+    return vmask;
+}
+
+// Rank one loaded tile.  On return skeys holds the tile's keys grouped by digit (stable), lstart[d] the first
+// LDS slot of digit d, and the return value of each thread d is the tile's count of digit d.
+__device__ __forceinline__ u32 rs_rank_loaded(const u64 (&key)[RS_ITEMS], u32 vmask, const RsDigit &dg, u64 *skeys,
+                                              u32 (*wavecnt)[RS_RADIX], u32 *lstart, u32 *scan_tmp, u32 *tile_total) {
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+#pragma unroll
+    for (u32 i = 0; i < DEBWT_WAVES; i++) wavecnt[i][tid] = 0;
+    __syncthreads();
+    u32 rnk[RS_ITEMS];
+    const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         bool valid = (vmask >> r) & 1u;
@@ -180,9 +185,15 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
     run[tid] = offsets[(u64)tid * nchunks + blockIdx.x] + digit_base[tid];
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < n ? beg + chunk : n;
+    u64 key[RS_ITEMS];
+    u32 vmask = rs_load_tile<SRC>(in, ts, beg, end, key);
     for (u64 tile = beg; tile < end; tile += RS_TILE) {
         u32 tot;
-        u32 mine = rs_rank_tile<SRC>(in, tile, end, dg, skeys, wavecnt, lstart, scan_tmp, &tot, ts);
+        u32 mine = rs_rank_loaded(key, vmask, dg, skeys, wavecnt, lstart, scan_tmp, &tot);
+#ifdef RS_PREFETCH
+        // the next tile's loads are in flight while this tile's runs are stored
+        if (tile + RS_TILE < end) vmask = rs_load_tile<SRC>(in, ts, tile + RS_TILE, end, key);
+#endif
         for (u32 j = tid; j < tot; j += RS_BLOCK) {
             u64 k = skeys[j];
             u32 d = rs_digit(dg, k);
@@ -190,6 +201,9 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
         }
         __syncthreads();
         run[tid] += mine;
+#ifndef RS_PREFETCH
+        if (tile + RS_TILE < end) vmask = rs_load_tile<SRC>(in, ts, tile + RS_TILE, end, key);
+#endif
     }
 }
 

@@ -363,43 +363,48 @@ struct LargeBlockF {
 };
 
 // Node lookup for the text scan (the job of blackTable + BinarySearch_red, src/generateSP.c:53-59,542-566,
-// 725-737): an open-addressing table over the red nodes (slot = node<<2|flags, 0 = empty, load <= 1/2, linear
-// probing so a probe sequence stays inside one 128-byte line) behind a one-bit-per-bin prefilter that fits L2.
-// Both are indexed by multiplicative hashes of the node, so neighbouring text positions spread evenly.
+// 725-737): an open-addressing table over the red nodes (load <= 1/2, linear probing so a probe sequence stays
+// inside one 128-byte line) behind a one-bit-per-bin prefilter that fits L2.  A slot carries everything the blue
+// fill needs -- key, the block's fill cursor, its global block id -- so one line serves probe and cursor.
+// Both tables are indexed by multiplicative hashes of the node, so neighbouring text positions spread evenly.
+struct __attribute__((aligned(16))) HSlot {
+    u64 key;    // node<<2 | multiin<<1 | multiout; 0 = empty
+    u32 cur;    // next free blue slot of the node's block (absolute), HCURSOR_SKIP when another shard owns it
+    u32 q;      // global block id
+};
+#define HCURSOR_SKIP 0xFFFFFFFFu
 __device__ __forceinline__ u32 red_hash(u64 node, int bits) { return (u32)((node * 0x9E3779B97F4A7C15ull) >> (64 - bits)); }
 __device__ __forceinline__ u32 red_hash2(u64 node, int bits) { return (u32)((node * 0xC2B2AE3D27D4EB4Full) >> (64 - bits)); }
 
-#define HCURSOR_SKIP 0xFFFFFFFFu   // multi-in node whose block lives on another shard
 __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__restrict__ red_q,
                              const u32 *__restrict__ bstart, u32 qbase, u32 Qlocal, int hbits,
-                             u64 *__restrict__ htab, u32 *__restrict__ hcursor, u32 *__restrict__ hq, int pb,
-                             u32 *__restrict__ rbits) {
+                             HSlot *__restrict__ htab, int pb, u32 *__restrict__ rbits) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const u64 v = red[r], node = v >> 2;
     const u32 mask = (1u << hbits) - 1u;
     u32 h = red_hash(node, hbits);
     for (;;) {
-        u64 old = atomicCAS(&htab[h], 0ull, v);
+        u64 old = atomicCAS(&htab[h].key, 0ull, v);
         if (old == 0ull) break;
         h = (h + 1) & mask;
     }
     // fill cursor of a multi-in node = first blue slot of its block (redPoint analogue, src/INandOut.c:413)
     if (v & 2ull) {
         u32 q = red_q[r] - qbase;                                // wraps for blocks before this shard
-        hcursor[h] = q < Qlocal ? bstart[q] : HCURSOR_SKIP;
-        hq[h] = red_q[r];                                        // global block id (blue-entry exchange)
+        htab[h].cur = q < Qlocal ? bstart[q] : HCURSOR_SKIP;
+        htab[h].q = red_q[r];                                    // global block id (blue-entry exchange)
     }
     u32 hb = red_hash2(node, pb);
     atomicOr(&rbits[hb >> 5], 1u << (hb & 31));
 }
 
 // returns the slot (or 0xFFFFFFFF) and the flags of `node`
-__device__ __forceinline__ u32 red_lookup(const u64 *__restrict__ htab, int hbits, u64 node, u32 *flags) {
+__device__ __forceinline__ u32 red_lookup(const HSlot *__restrict__ htab, int hbits, u64 node, u32 *flags) {
     const u32 mask = (1u << hbits) - 1u;
     u32 h = red_hash(node, hbits);
     for (;;) {
-        u64 v = htab[h];
+        u64 v = htab[h].key;
         if (v == 0ull) { *flags = 0; return 0xFFFFFFFFu; }
         if ((v >> 2) == node) { *flags = (u32)(v & 3); return h; }
         h = (h + 1) & mask;
@@ -420,7 +425,7 @@ __global__ void k_special_rows(const u64 *__restrict__ sk, u64 M, const u64 *__r
 // pass 1: one lane = 32 consecutive positions = one text word (coalesced 8-byte loads); per position the
 // node is a shift of the 128-bit (w0,w1) pair; flags go out as two 32-bit masks per group
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict__ text, const u64 *__restrict__ sepbits,
-                                                           u64 n, int K, const u64 *__restrict__ htab, int hbits,
+                                                           u64 n, int K, const HSlot *__restrict__ htab, int hbits,
                                                            const u32 *__restrict__ rbits, int pb,
                                                            const u64 *__restrict__ branch, u64 nbranch,
                                                            u32 *__restrict__ momask, u32 *__restrict__ mimask,
@@ -471,7 +476,8 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
 }
 
 // pass 2 (over groups of 32 positions): spIndex = exclusive scan of the multi-out bits.  SP symbols are
-// written in position order; multi-in positions are compacted into a work list (position | spIndex << 32)
+// written in position order; multi-in positions are compacted into a work list of 16-byte items
+// (node, spIndex << 4 | pred): the blue fill never touches the text again
 struct SpCountF {
     const u32 *momask; const u32 *mimask;
     __device__ void count2(u64 g, u32 *a, u32 *b) const { *a = (u32)__popc(momask[g]); *b = (u32)__popc(mimask[g]); }
@@ -479,7 +485,7 @@ struct SpCountF {
 struct SpEmitArgs {
     const u64 *text; const u64 *sepbits; u64 n; int K;
     const u32 *momask; const u32 *mimask;
-    u8 *spsym; u64 *mi_list;
+    u8 *spsym; ulonglong2 *mi_list;
     u64 g0;                    // first group of the slice (the scan arrays are indexed relative to it)
     u32 sp_base;               // SP symbols emitted by the slices before this one
 };
@@ -499,11 +505,23 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
         block_scan_excl_vec<2>(val, ex, tot, tmp);
         u32 off = base_mo + ex[0], omi = base_mi + ex[1];
         u32 all = mo | mi;
+        u64 w0 = 0, w1 = 0, wp = 0, sbp = 0;
+        if (mi) {                                              // the group's text words, the word and separators before it
+            w0 = a.text[g]; w1 = a.text[g + 1];
+            if (g) { wp = a.text[g - 1]; sbp = sep_window(a.sepbits, (g << 5) - 1); }
+        }
         while (all) {
             u32 t = (u32)__ffs(all) - 1u;
             all &= all - 1u;
             u64 i = (g << 5) + t;
-            if ((mi >> t) & 1u) a.mi_list[omi++] = i | ((u64)off << 32);
+            if ((mi >> t) & 1u) {
+                u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
+                u64 pred;                                      // src/generateSP.c:584-605
+                if (i == 0) pred = 5;
+                else if ((sbp >> t) & 1ull) pred = 4;          // bit t of sbp = position i-1
+                else pred = t ? ((w0 >> (2 * (32 - t))) & 3ull) : (wp & 3ull);
+                a.mi_list[omi++] = make_ulonglong2(win >> (64 - 2 * a.K), ((u64)off << 4) | pred);
+            }
             if ((mo >> t) & 1u) {
                 // the symbol K ahead; the separator itself when it follows the window (src/generateSP.c:626-660)
                 u64 j = i + (u64)a.K;
@@ -516,43 +534,33 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
     }
 }
 
-// one thread per multi-in position: node -> red entry -> block, predecessor symbol, slot in the block
-// through the block's cursor (the reference's per-red-entry lock, src/generateSP.c:662-680)
-__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const u64 *__restrict__ mi_list, u64 B,
-                                                            const u64 *__restrict__ text,
-                                                            const u64 *__restrict__ sepbits, int K,
-                                                            const u64 *__restrict__ htab, int hbits,
-                                                            u32 *__restrict__ hcursor, u64 *__restrict__ blue) {
+// one thread per multi-in position: node -> table slot -> slot in the block through the block's cursor, which
+// lives in the same table line (the reference's per-red-entry lock, src/generateSP.c:662-680)
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const ulonglong2 *__restrict__ mi_list, u64 B,
+                                                            HSlot *__restrict__ htab, int hbits,
+                                                            u64 *__restrict__ blue) {
     u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    u64 ent = mi_list[b];
-    u64 i = ent & 0xFFFFFFFFull, sp = ent >> 32;
-    u64 node = text_window(text, i) >> (64 - 2 * K);
+    ulonglong2 it = mi_list[b];
     u32 fl;
-    u32 h = red_lookup(htab, hbits, node, &fl);
-    if (hcursor[h] == HCURSOR_SKIP) return;                                 // block owned by another shard
-    u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
-    u32 slot = atomicAdd(&hcursor[h], 1u);                                  // absolute slot: starts at the block start
-    blue[slot] = pred | (sp << 4);                                          // src/generateSP.c:666-672
+    u32 h = red_lookup(htab, hbits, it.x, &fl);
+    if (h == 0xFFFFFFFFu || htab[h].cur == HCURSOR_SKIP) return;           // block owned by another shard
+    u32 slot = atomicAdd(&htab[h].cur, 1u);                                 // absolute slot: starts at the block start
+    blue[slot] = it.y;                                                      // pred | spIndex << 4 (:666-672)
 }
 
 // sharded build: a multi-in position of this shard's text slice -> (global block id << 36 | spIndex << 4 | pred),
 // to be sent to the shard that owns the block; and the owner's placement of the entries it received
-__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route(const u64 *__restrict__ mi_list, u64 B,
-                                                             const u64 *__restrict__ text,
-                                                             const u64 *__restrict__ sepbits, int K,
-                                                             const u64 *__restrict__ htab, int hbits,
-                                                             const u32 *__restrict__ hq, u64 *__restrict__ out) {
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route(const ulonglong2 *__restrict__ mi_list, u64 B,
+                                                             const HSlot *__restrict__ htab, int hbits,
+                                                             u64 *__restrict__ out) {
     u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    u64 ent = mi_list[b];
-    u64 i = ent & 0xFFFFFFFFull, sp = ent >> 32;
-    u64 node = text_window(text, i) >> (64 - 2 * K);
+    ulonglong2 it = mi_list[b];
     u32 fl;
-    u32 h = red_lookup(htab, hbits, node, &fl);
-    u64 pred = (i == 0) ? 5ull : (sep_at(sepbits, i - 1) ? 4ull : (u64)text_symbol(text, i - 1));
-    u64 q = h == 0xFFFFFFFFu ? 0xFFFFFFFull : (u64)hq[h];
-    out[b] = (q << 36) | (sp << 4) | pred;
+    u32 h = red_lookup(htab, hbits, it.x, &fl);
+    u64 q = h == 0xFFFFFFFFu ? 0xFFFFFFFull : (u64)htab[h].q;
+    out[b] = (q << 36) | it.y;
 }
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_place(const u64 *__restrict__ ent, u64 count, u32 qbase,
                                                              u32 Qlocal, u32 *__restrict__ qcursor,
@@ -614,7 +622,7 @@ __device__ __forceinline__ bool sp_less_deep(const u64 *__restrict__ spn, u64 S,
 #define BLUE_WAVE_CAP 512   // largest block sorted by a single-wave workgroup
 
 // Block sort by level-wise refinement (the data-parallel form of myQsort + cmpSP, src/sortBlue.c:109-280):
-// round d orders the still-tied entries by their d-th 21-symbol SP window; entries whose tie group has
+// round d orders the still-tied entries by their d-th pair of 21-symbol SP windows (42 symbols); entries whose tie group has
 // become a single row, or whose group carries a single BWT symbol (the reference's early-out,
 // src/sortBlue.c:192-219), leave the game.  One SP gather per unresolved entry per round -- not per
 // comparison.  A workgroup of NT threads holds the block in LDS; each round is a bitonic network on
@@ -625,7 +633,8 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                                                      u32 Q, u32 lo_excl, const u64 *__restrict__ spn, u64 S,
                                                      u8 *__restrict__ mchar) {
     __shared__ u64 se[CAP];     // entries
-    __shared__ u64 sw[CAP];     // current window
+    __shared__ u64 sw[CAP];     // current window, first 21 symbols
+    __shared__ u64 sx[CAP];     //                 next 21 symbols
     __shared__ u32 sg[CAP];     // tie group = index of its first row
     __shared__ u32 gcnt[CAP];   // rows per group   (also scratch for the boundary scan)
     __shared__ u32 gmsk[CAP];   // BWT symbols present per group
@@ -647,7 +656,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             if (x < m) {
                 u64 e = blue[b0 + x];
                 se[x] = e; sg[x] = 0; mask |= 1u << (e & 15);
-            } else { se[x] = ~0ull; sg[x] = 0xFFFFFFFFu; sw[x] = ~0ull; }
+            } else { se[x] = ~0ull; sg[x] = 0xFFFFFFFFu; sw[x] = ~0ull; sx[x] = ~0ull; }
             gcnt[x] = m; gmsk[x] = 0x3u;                      // round 0: one group, unresolved
         }
         __syncthreads();
@@ -660,8 +669,10 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             for (u32 x = tid; x < m; x += NT) {
                 u32 g = sg[x];
                 bool unresolved = gcnt[g] > 1 && (gmsk[g] & (gmsk[g] - 1));
-                u64 pos = (se[x] >> 4) + depth * SP_WIN;
-                sw[x] = (unresolved && pos < S) ? sp_window(spn, pos) : 0ull;
+                u64 pos = (se[x] >> 4) + depth * (2 * SP_WIN);
+                bool live = unresolved && pos < S;
+                sw[x] = live ? sp_window(spn, pos) : 0ull;
+                sx[x] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
             }
             __syncthreads();
             // 2. order every unresolved group by window: small groups by counting ranks inside the group
@@ -669,7 +680,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             if (maxg <= 32) {
                 constexpr int EPT = CAP / NT;
                 u32 npos[EPT];
-                u64 ne[EPT], nw[EPT];
+                u64 ne[EPT], nw[EPT], nx[EPT];
 #pragma unroll
                 for (int c = 0; c < EPT; c++) {
                     u32 x = tid + (u32)c * NT;
@@ -678,20 +689,21 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                         u32 g = sg[x];
                         u32 cnt = gcnt[g];
                         if (cnt > 1 && (gmsk[g] & (gmsk[g] - 1))) {
-                            u64 wx = sw[x];
+                            u64 wx = sw[x], xx = sx[x];
                             u32 rank = 0;
                             for (u32 y = g; y < g + cnt; y++) {
-                                u64 wy = sw[y];
-                                rank += (wy < wx || (wy == wx && y < x)) ? 1u : 0u;
+                                u64 wy = sw[y], xy = sx[y];
+                                bool less = wy != wx ? wy < wx : (xy != xx ? xy < xx : y < x);
+                                rank += less ? 1u : 0u;
                             }
-                            npos[c] = g + rank; ne[c] = se[x]; nw[c] = wx;
+                            npos[c] = g + rank; ne[c] = se[x]; nw[c] = wx; nx[c] = xx;
                         }
                     }
                 }
                 __syncthreads();
 #pragma unroll
                 for (int c = 0; c < EPT; c++)
-                    if (npos[c] != 0xFFFFFFFFu) { se[npos[c]] = ne[c]; sw[npos[c]] = nw[c]; }
+                    if (npos[c] != 0xFFFFFFFFu) { se[npos[c]] = ne[c]; sw[npos[c]] = nw[c]; sx[npos[c]] = nx[c]; }
                 __syncthreads();
             } else {
                 for (u32 kk = 2; kk <= P; kk <<= 1) {
@@ -700,13 +712,14 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                             u32 i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
                             u32 l = i | jj;
                             u32 gi = sg[i], gl = sg[l];
-                            u64 wi = sw[i], wl = sw[l];
-                            bool l_less = gl != gi ? gl < gi : wl < wi;
-                            bool i_less = gl != gi ? gi < gl : wi < wl;
+                            u64 wi = sw[i], wl = sw[l], xi = sx[i], xl = sx[l];
+                            bool l_less = gl != gi ? gl < gi : (wl != wi ? wl < wi : xl < xi);
+                            bool i_less = gl != gi ? gi < gl : (wl != wi ? wi < wl : xi < xl);
                             bool up = (i & kk) == 0;
                             if (up ? l_less : i_less) {
                                 u64 ei = se[i], el = se[l];
-                                sg[i] = gl; sg[l] = gi; sw[i] = wl; sw[l] = wi; se[i] = el; se[l] = ei;
+                                sg[i] = gl; sg[l] = gi; sw[i] = wl; sw[l] = wi; sx[i] = xl; sx[l] = xi;
+                                se[i] = el; se[l] = ei;
                             }
                         }
                         __syncthreads();
@@ -722,7 +735,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                 for (u32 c = 0; c < (CAP / NT > 0 ? CAP / NT : 1); c++) {
                     if (c < C) {
                         u32 x = xb + c;
-                        bool bnd = x == 0 || sg[x] != sg[x - 1] || sw[x] != sw[x - 1];
+                        bool bnd = x == 0 || sg[x] != sg[x - 1] || sw[x] != sw[x - 1] || sx[x] != sx[x - 1];
                         if (bnd) run = x + 1;
                         loc[c] = run;
                     }
@@ -770,7 +783,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             }
             if (any) { flag = 1; atomicMax(&smax, any); }
             __syncthreads();
-            active = flag != 0 && (depth + 1) * SP_WIN < S + SP_WIN;
+            active = flag != 0 && (depth + 1) * (2 * SP_WIN) < S + 2 * SP_WIN;
             maxg = smax;
             __syncthreads();
         }
