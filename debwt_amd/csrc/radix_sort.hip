@@ -19,8 +19,16 @@
 // what a pass buckets by: mode 0 = an 8-bit digit of the key; mode 1 = the shard that owns the key's 12-bit
 // prefix bin (k-mer bucket exchange); mode 2 = the shard that owns the block id carried in bits 36.. of a blue
 // entry (bounds[i] = first block of shard i)
+// FIXED0: the pass is known at compile time to bucket by a key digit (the key-sort kernels)
+template <int FIXED0>
 __device__ __forceinline__ u32 rs_digit(const RsDigit &g, u64 k) {
-    if (g.mode == 0) return (u32)(k >> g.shift) & g.mask;
+    if (FIXED0 || g.mode == 0) {
+        // 32-bit funnel shift instead of a 64-bit one (a digit never needs more than 32 bits of the key);
+        // branch-free in the (uniform) shift
+        const u32 lo = (u32)k, hi = (u32)(k >> 32);
+        const bool up = g.shift >= 32;
+        return __builtin_amdgcn_alignbit(up ? 0u : hi, up ? hi : lo, (u32)g.shift & 31u) & g.mask;
+    }
     if (g.mode == 1) return g.tab[(k >> g.tshift) & 4095u];   // masked: lanes without a key carry ~0
     u32 q = (u32)(k >> 36), lo = 0, hi = g.nb;
     while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (g.bounds[mid] <= q) lo = mid; else hi = mid; }
@@ -49,6 +57,41 @@ __device__ __forceinline__ bool rs_load_key(const u64 *__restrict__ in, const Te
     }
 }
 
+// Text pass: the tile's text and separator words are staged in LDS once (RS_TILE positions = RS_TILE/32 text words
+// and RS_TILE/64 bitmap words, plus the word before for the predecessor symbol and the words behind for the
+// windows), so a key costs LDS reads instead of five same-address global loads per lane.
+#define RS_STEXT (RS_TILE / 32 + 3)
+#define RS_SSEP (RS_TILE / 64 + 2)
+struct TextStage {
+    u64 *stext, *ssep;    // LDS
+    u64 tpos, spos;       // text position of stext[0] bit 63.. / of ssep[0] bit 0
+};
+// stages the words for positions [p0, p0 + RS_TILE); ends with a barrier (and starts with one: the previous
+// tile's readers are done)
+__device__ __forceinline__ void rs_stage_text(const TextKeySrc &ts, u64 p0, TextStage &st) {
+    const u64 wfirst = p0 ? (p0 - 1) >> 5 : 0, sfirst = p0 >> 6;
+    const u64 wlim = ((ts.n + 63) >> 5) + 2, slim = (ts.n >> 6) + 3;      // words the two buffers hold
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < RS_STEXT; j += blockDim.x) st.stext[j] = wfirst + j < wlim ? ts.text[wfirst + j] : 0ull;
+    for (u32 j = threadIdx.x; j < RS_SSEP; j += blockDim.x) st.ssep[j] = sfirst + j < slim ? ts.sepbits[sfirst + j] : 0ull;
+    st.tpos = wfirst << 5; st.spos = sfirst << 6;
+    __syncthreads();
+}
+// key of tile item idx (text position ts.pos0 + idx) from the staged words
+__device__ __forceinline__ bool rs_staged_key(const TextKeySrc &ts, const TextStage &st, u64 idx, u64 end, u64 *key) {
+    *key = ~0ull;
+    if (idx >= end) return false;
+    idx += ts.pos0;
+    u64 sw = sep_window(st.ssep, idx - st.spos);
+    if (sw & ((1ull << ts.K) - 1ull)) return false;                       // window holds a separator: no node
+    u64 node = text_window(st.stext, idx - st.tpos) >> (64 - 2 * ts.K);
+    u32 pred = idx ? text_symbol(st.stext, idx - 1 - st.tpos) : 3u;       // 'T' stands at separators
+    u64 k = (node << 2) | pred;
+    if (k < ts.key_lo || (ts.key_hi && k >= ts.key_hi)) return false;     // not this shard's prefix range
+    *key = k;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // algo 1
 
@@ -68,16 +111,23 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict
         for (u64 i = beg + 2ull * threadIdx.x; i < end; i += 2ull * RS_BLOCK) {
             if (i + 1 < end) {
                 ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + i);
-                atomicAdd(&h[rs_digit(dg, v.x)], 1u);
-                atomicAdd(&h[rs_digit(dg, v.y)], 1u);
+                atomicAdd(&h[rs_digit<!AUX>(dg, v.x)], 1u);
+                atomicAdd(&h[rs_digit<!AUX>(dg, v.y)], 1u);
             } else {
-                atomicAdd(&h[rs_digit(dg, keys[i])], 1u);
+                atomicAdd(&h[rs_digit<!AUX>(dg, keys[i])], 1u);
             }
         }
     } else {
-        for (u64 i = beg + threadIdx.x; i < end; i += RS_BLOCK) {
-            u64 k;
-            if (rs_load_key<1>(keys, ts, i, end, &k)) atomicAdd(&h[rs_digit(dg, k)], 1u);
+        __shared__ u64 stext[RS_STEXT], ssep[RS_SSEP];
+        TextStage st{stext, ssep, 0, 0};
+        for (u64 tile = beg; tile < end; tile += RS_TILE) {
+            rs_stage_text(ts, ts.pos0 + tile, st);
+#pragma unroll 4
+            for (u32 r = 0; r < RS_ITEMS; r++) {
+                u64 k;
+                if (rs_staged_key(ts, st, tile + (u64)r * RS_BLOCK + threadIdx.x, end, &k))
+                    atomicAdd(&h[rs_digit<!AUX>(dg, k)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -111,106 +161,215 @@ __global__ __launch_bounds__(RS_RADIX) void rs_scan_tot_kernel(u32 *__restrict__
     tot[threadIdx.x] = block_scan_excl(v, tmp, &t);
 }
 
-// Tile = RS_TILE items, wave-striped: wave w owns items [w*64*RS_ITEMS, ...), round r of it the 64 consecutive
-// items at r*64 (one coalesced 512-byte load per round).
+// ---- scatter pass -----------------------------------------------------------------------------------
+// A workgroup of SC_NT threads ranks a tile of RS_TILE keys per iteration.  Tile layout: wave w owns items
+// [w*64*SC_ITEMS, ...), round r of it the 64 consecutive items at r*64 (one coalesced 512-byte load per round).
+//
+// What bounds the pass is not the ranking but the write pattern: a tile holds ~16 keys per digit, so writing each
+// digit's run straight out means 128-byte pieces at arbitrary alignment, every output line is completed by two
+// tiles ~20 us apart, and the partial lines of all resident workgroups (256 digits each) overflow L2 -- measured
+// 1.27 ms against 0.79 ms for the same kernel storing sequentially.  So the runs are write-combined in LDS: per
+// digit a carry of < 16 keys (one 128-byte line) survives between tiles, and a tile emits only whole aligned lines
+// [a0, ae): the carried keys + the head of the tile's run complete the pending line (F1, 16 lanes per line), the
+// rest of the run up to the last line boundary follows (F2), and the tail behind it becomes the new carry.  Only
+// the first and last line of a digit's chunk range are partial.
+#ifndef SC_NT
+#define SC_NT 512
+#endif
+#define SC_ITEMS (RS_TILE / SC_NT)
+#define SC_WAVES (SC_NT / 64)
+#define SC_LINE 16                     // keys per output line (128 bytes)
+
 template <int SRC>
 __device__ __forceinline__ u32 rs_load_tile(const u64 *__restrict__ in, const TextKeySrc &ts, u64 tile, u64 end,
-                                            u64 (&key)[RS_ITEMS]) {
+                                            u64 (&key)[SC_ITEMS]) {
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const u64 wbase = tile + (u64)w * (64u * RS_ITEMS);
+    const u64 wbase = tile + (u64)w * (64u * SC_ITEMS);
     u32 vmask = 0;
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
+    for (int r = 0; r < SC_ITEMS; r++) {
         u64 idx = wbase + (u64)r * 64u + lane;
         if (rs_load_key<SRC>(in, ts, idx, end, &key[r])) vmask |= 1u << r;
     }
     return vmask;
 }
-
-// Rank one loaded tile.  On return skeys holds the tile's keys grouped by digit (stable), lstart[d] the first
-// LDS slot of digit d, and the return value of each thread d is the tile's count of digit d.
-__device__ __forceinline__ u32 rs_rank_loaded(const u64 (&key)[RS_ITEMS], u32 vmask, const RsDigit &dg, u64 *skeys,
-                                              u32 (*wavecnt)[RS_RADIX], u32 *lstart, u32 *scan_tmp, u32 *tile_total) {
-    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+// the same tile layout with the keys computed from the staged text words
+__device__ __forceinline__ u32 rs_load_tile_text(const TextKeySrc &ts, TextStage &st, u64 tile, u64 end,
+                                                 u64 (&key)[SC_ITEMS]) {
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const u64 wbase = tile + (u64)w * (64u * SC_ITEMS);
+    rs_stage_text(ts, ts.pos0 + tile, st);
+    u32 vmask = 0;
 #pragma unroll
-    for (u32 i = 0; i < DEBWT_WAVES; i++) wavecnt[i][tid] = 0;
-    __syncthreads();
-    u32 rnk[RS_ITEMS];
-    const u64 lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        bool valid = (vmask >> r) & 1u;
-        u32 d = rs_digit(dg, key[r]);
-        u64 m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            bool bit = (d >> b) & 1u;
-            u64 bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
-        }
-        u32 before = (u32)__popcll(m & lt);
-        u32 base = wavecnt[w][d];
-        rnk[r] = base + before;
-        if (valid && before == 0) wavecnt[w][d] = base + (u32)__popcll(m);
+    for (int r = 0; r < SC_ITEMS; r++) {
+        u64 idx = wbase + (u64)r * 64u + lane;
+        if (rs_staged_key(ts, st, idx, end, &key[r])) vmask |= 1u << r;
     }
-    __syncthreads();
-    u32 c0 = wavecnt[0][tid], c1 = wavecnt[1][tid], c2 = wavecnt[2][tid], c3 = wavecnt[3][tid];
-    u32 total = c0 + c1 + c2 + c3;
-    wavecnt[0][tid] = 0; wavecnt[1][tid] = c0; wavecnt[2][tid] = c0 + c1; wavecnt[3][tid] = c0 + c1 + c2;
-    u32 ls = block_scan_excl(total, scan_tmp, tile_total);
-    lstart[tid] = ls;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        if ((vmask >> r) & 1u) {
-            u32 d = rs_digit(dg, key[r]);
-            skeys[lstart[d] + wavecnt[w][d] + rnk[r]] = key[r];
-        }
-    }
-    __syncthreads();
-    return total;
+    return vmask;
 }
 
+// per-digit flush parameters of a tile
+struct __attribute__((aligned(16))) ScHead { u32 a0, ls, cc, nhead; };   // F1: line [a0, a0+nhead): cc carried keys, then the run from ls
+struct __attribute__((aligned(16))) ScBody { u32 delta, lo, fl, pad; };  // F2: slot j -> position g = delta + j; g < lo: done by F1; g < fl: out; else carry[g - fl]
+
+struct ScShared {
+    u64 skeys[RS_TILE];                   // the tile grouped by digit; its first 8*SC_WAVES*256 bytes double as peer masks
+    u64 carry[RS_RADIX][SC_LINE];
+    unsigned short wavecnt[SC_WAVES][RS_RADIX];   // counts, then first slots (< RS_TILE)
+    ScHead head[RS_RADIX];
+    ScBody body[RS_RADIX];
+    u32 run[RS_RADIX];                    // absolute output position of the digit's next key
+    u32 cc[RS_RADIX];                     // carried keys of the digit (positions [run - cc, run))
+    u32 scan_tmp[SC_WAVES + 1];
+};
+
+// Ranks one loaded tile and stages it in sh.skeys grouped by digit (stable); fills head/body for the flush and
+// advances run/cc.  Returns the tile's key count.
+// Peers (lanes of a wave round that carry the same digit) are found through LDS instead of one ballot per digit
+// bit: every lane ORs its lane bit into the 64-bit word of its digit, reads the word back -- that is the peer mask --
+// and the first peer clears it for the next round.  LDS executes a wave's instructions in order, so the read sees
+// the whole round's ORs and the clear comes after every read.
+// FULL: every item of the tile is a key (the common case of the array passes): no per-item predicates.
+template <int FIXED0, int FULL>
+__device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmask, const RsDigit &dg, ScShared &sh,
+                                            u32 oalign) {
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    u64 *wmask = sh.skeys + w * RS_RADIX;
+    for (u32 i = tid; i < SC_WAVES * RS_RADIX; i += SC_NT) { (&sh.wavecnt[0][0])[i] = 0; sh.skeys[i] = 0ull; }   // counters and peer masks
+    __syncthreads();
+    u32 pk[SC_ITEMS];                         // rank inside the wave's digit run | digit << 16
+    const u64 lbit = 1ull << lane, lt = lbit - 1ull;
+#pragma unroll
+    for (int r = 0; r < SC_ITEMS; r++) {
+        const bool valid = FULL || ((vmask >> r) & 1u);
+        const u32 d = rs_digit<FIXED0>(dg, key[r]);
+        if (valid) __hip_atomic_fetch_or(&wmask[d], lbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();
+        const u64 m = valid ? __hip_atomic_load(&wmask[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+        const u32 before = (u32)__popcll(m & lt);
+        const u32 base = sh.wavecnt[w][d];
+        pk[r] = (base + before) | (d << 16);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) {
+            sh.wavecnt[w][d] = (unsigned short)(base + (u32)__popcll(m));
+            __hip_atomic_store(&wmask[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_sched_barrier(0);    // keep a round's arithmetic inside the round (register pressure)
+    }
+    __syncthreads();
+    // digit d = thread d: counts of the waves -> first LDS slot of every (wave, digit) run; flush parameters
+    u32 len = 0, c[SC_WAVES];
+    if (tid < RS_RADIX) {
+#pragma unroll
+        for (u32 i = 0; i < SC_WAVES; i++) { c[i] = sh.wavecnt[i][tid]; len += c[i]; }
+    }
+    u32 incl = wave_scan_incl(len);
+    if (lane == 63) sh.scan_tmp[w] = incl;
+    __syncthreads();
+    u32 tile_total = 0;
+    if (tid < RS_RADIX) {
+        u32 ls = incl - len;
+#pragma unroll
+        for (u32 i = 0; i < RS_RADIX / 64; i++) { u32 t = sh.scan_tmp[i]; if (i < w) ls += t; tile_total += t; }
+        u32 acc = ls;
+#pragma unroll
+        for (u32 i = 0; i < SC_WAVES; i++) { sh.wavecnt[i][tid] = (unsigned short)acc; acc += c[i]; }
+        const u32 run = sh.run[tid], cc = sh.cc[tid];
+        const u32 a0 = run - cc, e = run + len;
+        const u32 ae = ((e + oalign) & ~(SC_LINE - 1u)) - oalign;           // last line boundary <= e
+        const u32 hl = ((a0 + oalign) | (SC_LINE - 1u)) + 1u - oalign;       // first line boundary > a0
+        const bool flush = (int)(ae - a0) > 0;                               // a line completes in this tile
+        sh.head[tid] = ScHead{a0, ls, cc, flush ? hl - a0 : 0u};
+        sh.body[tid] = ScBody{run - ls, flush ? hl : a0, flush ? ae : a0, 0u};
+        sh.run[tid] = e;
+        sh.cc[tid] = flush ? e - ae : cc + len;
+    } else {
+#pragma unroll
+        for (u32 i = 0; i < RS_RADIX / 64; i++) tile_total += sh.scan_tmp[i];
+    }
+    __syncthreads();
+    u32 slot[SC_ITEMS];                       // all offset reads in flight, then the writes
+#pragma unroll
+    for (int r = 0; r < SC_ITEMS; r++) slot[r] = sh.wavecnt[w][pk[r] >> 16] + (pk[r] & 0xFFFFu);
+#pragma unroll
+    for (int r = 0; r < SC_ITEMS; r++)
+        if (FULL || ((vmask >> r) & 1u)) sh.skeys[slot[r]] = key[r];
+    __syncthreads();
+    return tile_total;
+}
+
+// F1: the pending line of every digit, 16 lanes per digit
+__device__ __forceinline__ void rs_flush_heads(ScShared &sh, u64 *__restrict__ out) {
+#pragma unroll
+    for (u32 i = 0; i < RS_RADIX * SC_LINE / SC_NT; i++) {
+        const u32 p = i * SC_NT + threadIdx.x, d = p / SC_LINE, s = p % SC_LINE;
+        const ScHead h = sh.head[d];
+        if (s < h.nhead) out[h.a0 + s] = s < h.cc ? sh.carry[d][s] : sh.skeys[h.ls + s - h.cc];
+    }
+}
+template <int FIXED0>
+__device__ __forceinline__ void rs_flush_slot(ScShared &sh, const RsDigit &dg, u64 *__restrict__ out, u32 j, u64 k) {
+    const u32 d = rs_digit<FIXED0>(dg, k);
+    const ScBody b = sh.body[d];
+    const u32 g = b.delta + j;
+    if ((int)(g - b.fl) >= 0) sh.carry[d][g - b.fl] = k;
+    else if ((int)(g - b.lo) >= 0) out[g] = k;
+}
+
+#ifndef RS_WAVES_EU
+#define RS_WAVES_EU 4                  // 128 VGPRs: two 512-thread workgroups per CU, as the LDS footprint allows
+#endif
 template <int SRC, int AUX>
-__global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts,
-                                                               u64 *__restrict__ out, u64 n, u64 chunk, RsDigit dg,
-                                                               const u32 *__restrict__ offsets,
-                                                               const u32 *__restrict__ digit_base, u32 nchunks) {
-    __shared__ u64 skeys[RS_TILE];
-    __shared__ u32 wavecnt[DEBWT_WAVES][RS_RADIX];
-    __shared__ u32 lstart[RS_RADIX];
-    __shared__ u32 run[RS_RADIX];
-    __shared__ u32 scan_tmp[8];
-    const u32 tid = threadIdx.x;
-    run[tid] = offsets[(u64)tid * nchunks + blockIdx.x] + digit_base[tid];
+__global__ __launch_bounds__(SC_NT) __attribute__((amdgpu_waves_per_eu(RS_WAVES_EU, RS_WAVES_EU)))
+void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 chunk, RsDigit dg,
+                       const u32 *__restrict__ offsets, const u32 *__restrict__ digit_base, u32 nchunks) {
+    __shared__ ScShared sh;
+    __shared__ u64 stext[SRC ? RS_STEXT : 1], ssep[SRC ? RS_SSEP : 1];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid < RS_RADIX) {
+        sh.run[tid] = offsets[(u64)tid * nchunks + blockIdx.x] + digit_base[tid];
+        sh.cc[tid] = 0;
+    }
+    const u32 oalign = (u32)(reinterpret_cast<uintptr_t>(out) >> 3) & (SC_LINE - 1u);   // lines are 128-byte aligned addresses
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < n ? beg + chunk : n;
-    u64 key[RS_ITEMS];
-    u32 vmask = rs_load_tile<SRC>(in, ts, beg, end, key);
+    TextStage st{stext, ssep, 0, 0};
     for (u64 tile = beg; tile < end; tile += RS_TILE) {
-        u32 tot;
-        u32 mine = rs_rank_loaded(key, vmask, dg, skeys, wavecnt, lstart, scan_tmp, &tot);
-#ifdef RS_PREFETCH
-        // the next tile's loads are in flight while this tile's runs are stored
-        if (tile + RS_TILE < end) vmask = rs_load_tile<SRC>(in, ts, tile + RS_TILE, end, key);
-#endif
-        for (u32 j = tid; j < tot; j += RS_BLOCK) {
-            u64 k = skeys[j];
-            u32 d = rs_digit(dg, k);
-            out[(u64)run[d] + (j - lstart[d])] = k;
+        u64 key[SC_ITEMS];
+        if (SRC == 0 && tile + RS_TILE <= end) {
+            const u64 *src = in + tile + (u64)w * (64u * SC_ITEMS) + lane;
+#pragma unroll
+            for (int r = 0; r < SC_ITEMS; r++) key[r] = src[r * 64];
+            rs_rank_tile<!AUX, 1>(key, 0xFFFFFFFFu, dg, sh, oalign);
+            rs_flush_heads(sh, out);
+            u64 k[SC_ITEMS];
+#pragma unroll
+            for (int r = 0; r < SC_ITEMS; r++) k[r] = sh.skeys[tid + r * SC_NT];
+            __syncthreads();                                   // F1 has read the old carry
+#pragma unroll
+            for (int r = 0; r < SC_ITEMS; r++) rs_flush_slot<!AUX>(sh, dg, out, tid + r * SC_NT, k[r]);
+        } else {
+            u32 vmask = SRC ? rs_load_tile_text(ts, st, tile, end, key) : rs_load_tile<SRC>(in, ts, tile, end, key);
+            u32 tot = rs_rank_tile<!AUX, 0>(key, vmask, dg, sh, oalign);
+            rs_flush_heads(sh, out);
+            __syncthreads();
+            for (u32 j = tid; j < tot; j += SC_NT) rs_flush_slot<!AUX>(sh, dg, out, j, sh.skeys[j]);
         }
         __syncthreads();
-        run[tid] += mine;
-#ifndef RS_PREFETCH
-        if (tile + RS_TILE < end) vmask = rs_load_tile<SRC>(in, ts, tile + RS_TILE, end, key);
-#endif
+    }
+    // the last, partial line of every digit
+#pragma unroll
+    for (u32 i = 0; i < RS_RADIX * SC_LINE / SC_NT; i++) {
+        const u32 p = i * SC_NT + tid, d = p / SC_LINE, s = p % SC_LINE;
+        const u32 cc = sh.cc[d];
+        if (s < cc) out[sh.run[d] - cc + s] = sh.carry[d][s];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // hybrid: local finish of prefix buckets in LDS
 
-#define RL_CAP RS_TILE                 // keys a 256-thread workgroup finishes (4096)
+#define RL_CAP 4096                    // keys a 256-thread workgroup finishes
 #define RL_H (RL_CAP * 7 / 8)          // its tile stride: tile j starts at the first bucket boundary >= j*RL_H
 #define RLW_CAP 1024                   // keys a single wave finishes (16 per lane, no barriers at all)
 #define RLW_H (RLW_CAP * 7 / 8)
@@ -394,7 +553,7 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
             rs_hist_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, text->n, chunk, dg, ws.counts, nchunks);
             rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
             rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
-            rs_scatter_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts,
+            rs_scatter_kernel<1, 0><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts,
                                                                    digit_tot, nchunks);
             src = a; dst = b;
             continue;
@@ -405,9 +564,9 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
         rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
         rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
         if (ev) (void)hipEventRecord(pass_events[2 * ev_idx], stream);
-        if (aux) rs_scatter_kernel<0, 1><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts,
+        if (aux) rs_scatter_kernel<0, 1><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts,
                                                                           digit_tot, nchunks);
-        else rs_scatter_kernel<0, 0><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts,
+        else rs_scatter_kernel<0, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts,
                                                                       digit_tot, nchunks);
         if (ev) { (void)hipEventRecord(pass_events[2 * ev_idx + 1], stream); ev_idx++; if (npairs) *npairs = ev_idx; }
         u64 *t = src; src = dst; dst = t;
@@ -496,8 +655,8 @@ hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const Te
     }
     rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
     rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
-    if (text) rs_scatter_kernel<1, 1><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
-    else rs_scatter_kernel<0, 1><<<nchunks, RS_BLOCK, 0, stream>>>(src, none, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    if (text) rs_scatter_kernel<1, 1><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    else rs_scatter_kernel<0, 1><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
     u32 tot[RS_RADIX];
     hipError_t e = hipMemcpyAsync(tot, digit_tot, sizeof tot, hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
