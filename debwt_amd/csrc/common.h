@@ -61,6 +61,13 @@ __device__ __forceinline__ u64 upper_bound_dev(const T *__restrict__ a, u64 lo, 
     return lo;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)) -- in a streaming kernel that exposes the full HBM store latency at every
+// barrier and defeats prefetching.  Use only where no global data is exchanged between the waves of a workgroup.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- wave / block scans ----------------------------------------------------------------------------
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }

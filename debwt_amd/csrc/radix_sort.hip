@@ -10,6 +10,7 @@
 #include "radix_sort.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <utility>
 #include <vector>
 
@@ -19,9 +20,11 @@
 // what a pass buckets by: mode 0 = an 8-bit digit of the key; mode 1 = the shard that owns the key's 12-bit
 // prefix bin (k-mer bucket exchange); mode 2 = the shard that owns the block id carried in bits 36.. of a blue
 // entry (bounds[i] = first block of shard i)
-// FIXED0: the pass is known at compile time to bucket by a key digit (the key-sort kernels)
+// FIXED0: the pass is known at compile time to bucket by a key digit (the key-sort kernels); 2: and the digit lies
+// in the upper key word (shift >= 32: every pass of the hybrid sort for k >= 28) -- one bit-field extract
 template <int FIXED0>
 __device__ __forceinline__ u32 rs_digit(const RsDigit &g, u64 k) {
+    if (FIXED0 == 2) return __builtin_amdgcn_ubfe((u32)(k >> 32), (u32)g.shift - 32u, (u32)__popc(g.mask));
     if (FIXED0 || g.mode == 0) {
         // 32-bit funnel shift instead of a 64-bit one (a digit never needs more than 32 bits of the key);
         // branch-free in the (uniform) shift
@@ -71,11 +74,11 @@ struct TextStage {
 __device__ __forceinline__ void rs_stage_text(const TextKeySrc &ts, u64 p0, TextStage &st) {
     const u64 wfirst = p0 ? (p0 - 1) >> 5 : 0, sfirst = p0 >> 6;
     const u64 wlim = ((ts.n + 63) >> 5) + 2, slim = (ts.n >> 6) + 3;      // words the two buffers hold
-    __syncthreads();
+    lds_barrier();
     for (u32 j = threadIdx.x; j < RS_STEXT; j += blockDim.x) st.stext[j] = wfirst + j < wlim ? ts.text[wfirst + j] : 0ull;
     for (u32 j = threadIdx.x; j < RS_SSEP; j += blockDim.x) st.ssep[j] = sfirst + j < slim ? ts.sepbits[sfirst + j] : 0ull;
     st.tpos = wfirst << 5; st.spos = sfirst << 6;
-    __syncthreads();
+    lds_barrier();
 }
 // key of tile item idx (text position ts.pos0 + idx) from the staged words
 __device__ __forceinline__ bool rs_staged_key(const TextKeySrc &ts, const TextStage &st, u64 idx, u64 end, u64 *key) {
@@ -209,8 +212,10 @@ __device__ __forceinline__ u32 rs_load_tile_text(const TextKeySrc &ts, TextStage
 }
 
 // per-digit flush parameters of a tile
-struct __attribute__((aligned(16))) ScHead { u32 a0, ls, cc, nhead; };   // F1: line [a0, a0+nhead): cc carried keys, then the run from ls
-struct __attribute__((aligned(16))) ScBody { u32 delta, lo, fl, pad; };  // F2: slot j -> position g = delta + j; g < lo: done by F1; g < fl: out; else carry[g - fl]
+// F1: line [a0, a0+nhead): cc carried keys, then the run from LDS slot ls
+struct __attribute__((aligned(8))) ScHead { u32 a0; unsigned short ls; u8 cc, nhead; };
+// F2: LDS slot j holds position delta + j; j < lo: written by F1; j < fl: goes out; else to carry[j - fl]
+struct __attribute__((aligned(8))) ScBody { u32 delta; short lo, fl; };
 
 struct ScShared {
     u64 skeys[RS_TILE];                   // the tile grouped by digit; its first 8*SC_WAVES*256 bytes double as peer masks
@@ -236,9 +241,9 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     u64 *wmask = sh.skeys + w * RS_RADIX;
     for (u32 i = tid; i < SC_WAVES * RS_RADIX; i += SC_NT) { (&sh.wavecnt[0][0])[i] = 0; sh.skeys[i] = 0ull; }   // counters and peer masks
-    __syncthreads();
+    lds_barrier();
     u32 pk[SC_ITEMS];                         // rank inside the wave's digit run | digit << 16
-    const u64 lbit = 1ull << lane, lt = lbit - 1ull;
+    const u64 lbit = 1ull << lane;
 #pragma unroll
     for (int r = 0; r < SC_ITEMS; r++) {
         const bool valid = FULL || ((vmask >> r) & 1u);
@@ -246,7 +251,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
         if (valid) __hip_atomic_fetch_or(&wmask[d], lbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_wave_barrier();
         const u64 m = valid ? __hip_atomic_load(&wmask[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-        const u32 before = (u32)__popcll(m & lt);
+        const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));   // popc(m & lanes below)
         const u32 base = sh.wavecnt[w][d];
         pk[r] = (base + before) | (d << 16);
         __builtin_amdgcn_wave_barrier();
@@ -256,7 +261,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
         }
         __builtin_amdgcn_sched_barrier(0);    // keep a round's arithmetic inside the round (register pressure)
     }
-    __syncthreads();
+    lds_barrier();
     // digit d = thread d: counts of the waves -> first LDS slot of every (wave, digit) run; flush parameters
     u32 len = 0, c[SC_WAVES];
     if (tid < RS_RADIX) {
@@ -265,7 +270,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
     }
     u32 incl = wave_scan_incl(len);
     if (lane == 63) sh.scan_tmp[w] = incl;
-    __syncthreads();
+    lds_barrier();
     u32 tile_total = 0;
     if (tid < RS_RADIX) {
         u32 ls = incl - len;
@@ -279,50 +284,92 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
         const u32 ae = ((e + oalign) & ~(SC_LINE - 1u)) - oalign;           // last line boundary <= e
         const u32 hl = ((a0 + oalign) | (SC_LINE - 1u)) + 1u - oalign;       // first line boundary > a0
         const bool flush = (int)(ae - a0) > 0;                               // a line completes in this tile
-        sh.head[tid] = ScHead{a0, ls, cc, flush ? hl - a0 : 0u};
-        sh.body[tid] = ScBody{run - ls, flush ? hl : a0, flush ? ae : a0, 0u};
+        const u32 delta = run - ls;           // mod 2^32
+        sh.head[tid] = ScHead{a0, (unsigned short)ls, (u8)cc, (u8)(flush ? hl - a0 : 0u)};
+        sh.body[tid] = ScBody{delta, (short)((flush ? hl : a0) - delta), (short)((flush ? ae : a0) - delta)};
         sh.run[tid] = e;
         sh.cc[tid] = flush ? e - ae : cc + len;
     } else {
 #pragma unroll
         for (u32 i = 0; i < RS_RADIX / 64; i++) tile_total += sh.scan_tmp[i];
     }
-    __syncthreads();
+    lds_barrier();
     u32 slot[SC_ITEMS];                       // all offset reads in flight, then the writes
 #pragma unroll
     for (int r = 0; r < SC_ITEMS; r++) slot[r] = sh.wavecnt[w][pk[r] >> 16] + (pk[r] & 0xFFFFu);
 #pragma unroll
     for (int r = 0; r < SC_ITEMS; r++)
         if (FULL || ((vmask >> r) & 1u)) sh.skeys[slot[r]] = key[r];
-    __syncthreads();
+    lds_barrier();
     return tile_total;
 }
 
-// F1: the pending line of every digit, 16 lanes per digit
+// F1: the pending line of every digit, 16 lanes per digit.  Parameter words first, then all key reads, then
+// the stores: the LDS round trips of the iterations overlap instead of chaining.
 __device__ __forceinline__ void rs_flush_heads(ScShared &sh, u64 *__restrict__ out) {
+    constexpr u32 NI = RS_RADIX * SC_LINE / SC_NT;
+    const u32 s = threadIdx.x % SC_LINE, d0 = threadIdx.x / SC_LINE;
+    const u64 *hw = reinterpret_cast<const u64 *>(sh.head);
+    const u64 *lds = sh.skeys;                               // skeys and carry are contiguous: one index space
+    static_assert(offsetof(ScShared, carry) == sizeof(u64) * RS_TILE, "carry follows skeys");
+    u64 h[NI], v[NI];
 #pragma unroll
-    for (u32 i = 0; i < RS_RADIX * SC_LINE / SC_NT; i++) {
-        const u32 p = i * SC_NT + threadIdx.x, d = p / SC_LINE, s = p % SC_LINE;
-        const ScHead h = sh.head[d];
-        if (s < h.nhead) out[h.a0 + s] = s < h.cc ? sh.carry[d][s] : sh.skeys[h.ls + s - h.cc];
+    for (u32 i = 0; i < NI; i++) h[i] = hw[d0 + i * (SC_NT / SC_LINE)];
+#pragma unroll
+    for (u32 i = 0; i < NI; i++) {
+        const u32 d = d0 + i * (SC_NT / SC_LINE);
+        const u32 ls = (u32)(h[i] >> 32) & 0xFFFFu, cc = (u32)(h[i] >> 48) & 0xFFu;
+        v[i] = lds[s < cc ? RS_TILE + d * SC_LINE + s : ls + s - cc];
+    }
+#pragma unroll
+    for (u32 i = 0; i < NI; i++) {
+        const u32 a0 = (u32)h[i], nhead = (u32)(h[i] >> 56);
+#if defined(RS_DIAG) && RS_DIAG == 2           // diagnostics (wrong results on purpose): (almost) no stores
+        if (s < nhead && a0 == 0x7FFFFFF1u) out[a0 + s] = v[i];
+#else
+        if (s < nhead) out[a0 + s] = v[i];
+#endif
+    }
+}
+// F2: the tile's keys (k[r] = LDS slot tid + r*SC_NT): whole lines go out, the tail behind the last line boundary
+// becomes the carry
+template <int FIXED0>
+__device__ __forceinline__ void rs_flush_body(ScShared &sh, const RsDigit &dg, u64 *__restrict__ out,
+                                              const u64 (&k)[SC_ITEMS]) {
+    const u64 *bw = reinterpret_cast<const u64 *>(sh.body);
+    u32 d[SC_ITEMS];
+    u64 b[SC_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SC_ITEMS; r++) { d[r] = rs_digit<FIXED0>(dg, k[r]); b[r] = bw[d[r]]; }
+#pragma unroll
+    for (int r = 0; r < SC_ITEMS; r++) {
+        const int js = (int)(threadIdx.x + r * SC_NT);
+        const int lo = (short)(b[r] >> 32), fl = (short)(b[r] >> 48);
+        if (js >= fl) sh.carry[d[r]][js - fl] = k[r];
+#if defined(RS_DIAG) && RS_DIAG == 2
+        else if (js >= lo && js == 0x7FFFFFF1) out[(u32)b[r] + (u32)js] = k[r];
+#else
+        else if (js >= lo) out[(u32)b[r] + (u32)js] = k[r];
+#endif
     }
 }
 template <int FIXED0>
 __device__ __forceinline__ void rs_flush_slot(ScShared &sh, const RsDigit &dg, u64 *__restrict__ out, u32 j, u64 k) {
     const u32 d = rs_digit<FIXED0>(dg, k);
     const ScBody b = sh.body[d];
-    const u32 g = b.delta + j;
-    if ((int)(g - b.fl) >= 0) sh.carry[d][g - b.fl] = k;
-    else if ((int)(g - b.lo) >= 0) out[g] = k;
+    const int js = (int)j;
+    if (js >= b.fl) sh.carry[d][js - b.fl] = k;
+    else if (js >= b.lo) out[b.delta + j] = k;
 }
 
 #ifndef RS_WAVES_EU
 #define RS_WAVES_EU 4                  // 128 VGPRs: two 512-thread workgroups per CU, as the LDS footprint allows
 #endif
-template <int SRC, int AUX>
+template <int SRC, int AUX, int HI>
 __global__ __launch_bounds__(SC_NT) __attribute__((amdgpu_waves_per_eu(RS_WAVES_EU, RS_WAVES_EU)))
 void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 chunk, RsDigit dg,
                        const u32 *__restrict__ offsets, const u32 *__restrict__ digit_base, u32 nchunks) {
+    constexpr int DG = AUX ? 0 : (HI ? 2 : 1);
     __shared__ ScShared sh;
     __shared__ u64 stext[SRC ? RS_STEXT : 1], ssep[SRC ? RS_SSEP : 1];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -334,28 +381,50 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < n ? beg + chunk : n;
     TextStage st{stext, ssep, 0, 0};
-    for (u64 tile = beg; tile < end; tile += RS_TILE) {
-        u64 key[SC_ITEMS];
-        if (SRC == 0 && tile + RS_TILE <= end) {
-            const u64 *src = in + tile + (u64)w * (64u * SC_ITEMS) + lane;
+    u64 key[SC_ITEMS];
+    const u64 *src = in + (u64)w * (64u * SC_ITEMS) + lane;
+    if (SRC == 0 && beg + RS_TILE <= end) {
 #pragma unroll
-            for (int r = 0; r < SC_ITEMS; r++) key[r] = src[r * 64];
-            rs_rank_tile<!AUX, 1>(key, 0xFFFFFFFFu, dg, sh, oalign);
+        for (int r = 0; r < SC_ITEMS; r++) key[r] = src[beg + r * 64];
+    }
+    for (u64 tile = beg; tile < end; tile += RS_TILE) {
+        if (SRC == 0 && tile + RS_TILE <= end) {
+            // whole tile; its keys were loaded while the previous tile was being flushed
+            rs_rank_tile<DG, 1>(key, 0xFFFFFFFFu, dg, sh, oalign);
+#ifndef RS_NO_PREFETCH
+            if (tile + 2 * RS_TILE <= end) {
+#pragma unroll
+                for (int r = 0; r < SC_ITEMS; r++) key[r] = src[tile + RS_TILE + r * 64];
+            }
+#endif
+#if !defined(RS_DIAG) || RS_DIAG != 4          // diagnostics 4: no flush at all
+#if !defined(RS_DIAG) || RS_DIAG != 5          // diagnostics 5: no F1
             rs_flush_heads(sh, out);
+#endif
             u64 k[SC_ITEMS];
 #pragma unroll
             for (int r = 0; r < SC_ITEMS; r++) k[r] = sh.skeys[tid + r * SC_NT];
-            __syncthreads();                                   // F1 has read the old carry
+            lds_barrier();                                   // F1 has read the old carry
+#if !defined(RS_DIAG) || RS_DIAG != 6          // diagnostics 6: no F2
+            rs_flush_body<DG>(sh, dg, out, k);
+#else
+            if (k[0] == 0x123456789ull) out[0] = k[1] + k[2] + k[3] + k[4] + k[5] + k[6] + k[7];
+#endif
+#endif
+#ifdef RS_NO_PREFETCH
+            if (tile + 2 * RS_TILE <= end) {
 #pragma unroll
-            for (int r = 0; r < SC_ITEMS; r++) rs_flush_slot<!AUX>(sh, dg, out, tid + r * SC_NT, k[r]);
+                for (int r = 0; r < SC_ITEMS; r++) key[r] = src[tile + RS_TILE + r * 64];
+            }
+#endif
         } else {
             u32 vmask = SRC ? rs_load_tile_text(ts, st, tile, end, key) : rs_load_tile<SRC>(in, ts, tile, end, key);
-            u32 tot = rs_rank_tile<!AUX, 0>(key, vmask, dg, sh, oalign);
+            u32 tot = rs_rank_tile<DG, 0>(key, vmask, dg, sh, oalign);
             rs_flush_heads(sh, out);
-            __syncthreads();
-            for (u32 j = tid; j < tot; j += SC_NT) rs_flush_slot<!AUX>(sh, dg, out, j, sh.skeys[j]);
+            lds_barrier();
+            for (u32 j = tid; j < tot; j += SC_NT) rs_flush_slot<DG>(sh, dg, out, j, sh.skeys[j]);
         }
-        __syncthreads();
+        lds_barrier();
     }
     // the last, partial line of every digit
 #pragma unroll
@@ -553,8 +622,8 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
             rs_hist_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, text->n, chunk, dg, ws.counts, nchunks);
             rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
             rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
-            rs_scatter_kernel<1, 0><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts,
-                                                                   digit_tot, nchunks);
+            if (shift >= 32) rs_scatter_kernel<1, 0, 1><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
+            else rs_scatter_kernel<1, 0, 0><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
             src = a; dst = b;
             continue;
         }
@@ -564,10 +633,9 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
         rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
         rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
         if (ev) (void)hipEventRecord(pass_events[2 * ev_idx], stream);
-        if (aux) rs_scatter_kernel<0, 1><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts,
-                                                                          digit_tot, nchunks);
-        else rs_scatter_kernel<0, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts,
-                                                                      digit_tot, nchunks);
+        if (aux) rs_scatter_kernel<0, 1, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
+        else if (shift >= 32) rs_scatter_kernel<0, 0, 1><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
+        else rs_scatter_kernel<0, 0, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
         if (ev) { (void)hipEventRecord(pass_events[2 * ev_idx + 1], stream); ev_idx++; if (npairs) *npairs = ev_idx; }
         u64 *t = src; src = dst; dst = t;
     }
@@ -655,8 +723,8 @@ hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const Te
     }
     rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
     rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
-    if (text) rs_scatter_kernel<1, 1><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
-    else rs_scatter_kernel<0, 1><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    if (text) rs_scatter_kernel<1, 1, 0><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    else rs_scatter_kernel<0, 1, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
     u32 tot[RS_RADIX];
     hipError_t e = hipMemcpyAsync(tot, digit_tot, sizeof tot, hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
