@@ -228,6 +228,11 @@ struct ScShared {
     u32 scan_tmp[SC_WAVES + 1];
 };
 
+// counters and peer masks (the masks alias the first SC_WAVES*256 slots of skeys) to zero
+__device__ __forceinline__ void rs_clear_rank_state(ScShared &sh) {
+    for (u32 i = threadIdx.x; i < SC_WAVES * RS_RADIX; i += SC_NT) { (&sh.wavecnt[0][0])[i] = 0; sh.skeys[i] = 0ull; }
+}
+
 // Ranks one loaded tile and stages it in sh.skeys grouped by digit (stable); fills head/body for the flush and
 // advances run/cc.  Returns the tile's key count.
 // Peers (lanes of a wave round that carry the same digit) are found through LDS instead of one ballot per digit
@@ -240,8 +245,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
                                             u32 oalign) {
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     u64 *wmask = sh.skeys + w * RS_RADIX;
-    for (u32 i = tid; i < SC_WAVES * RS_RADIX; i += SC_NT) { (&sh.wavecnt[0][0])[i] = 0; sh.skeys[i] = 0ull; }   // counters and peer masks
-    lds_barrier();
+    // counters and peer masks are clear: rs_clear_rank_state ran during the previous tile's flush
     u32 pk[SC_ITEMS];                         // rank inside the wave's digit run | digit << 16
     const u64 lbit = 1ull << lane;
 #pragma unroll
@@ -324,18 +328,14 @@ __device__ __forceinline__ void rs_flush_heads(ScShared &sh, u64 *__restrict__ o
 #pragma unroll
     for (u32 i = 0; i < NI; i++) {
         const u32 a0 = (u32)h[i], nhead = (u32)(h[i] >> 56);
-#if defined(RS_DIAG) && RS_DIAG == 2           // diagnostics (wrong results on purpose): (almost) no stores
-        if (s < nhead && a0 == 0x7FFFFFF1u) out[a0 + s] = v[i];
-#else
         if (s < nhead) out[a0 + s] = v[i];
-#endif
     }
 }
 // F2: the tile's keys (k[r] = LDS slot tid + r*SC_NT): whole lines go out, the tail behind the last line boundary
 // becomes the carry
 template <int FIXED0>
 __device__ __forceinline__ void rs_flush_body(ScShared &sh, const RsDigit &dg, u64 *__restrict__ out,
-                                              const u64 (&k)[SC_ITEMS]) {
+                                              const u64 (&k)[SC_ITEMS], int tot) {
     const u64 *bw = reinterpret_cast<const u64 *>(sh.body);
     u32 d[SC_ITEMS];
     u64 b[SC_ITEMS];
@@ -345,23 +345,11 @@ __device__ __forceinline__ void rs_flush_body(ScShared &sh, const RsDigit &dg, u
     for (int r = 0; r < SC_ITEMS; r++) {
         const int js = (int)(threadIdx.x + r * SC_NT);
         const int lo = (short)(b[r] >> 32), fl = (short)(b[r] >> 48);
+        if (js >= tot) continue;
         if (js >= fl) sh.carry[d[r]][js - fl] = k[r];
-#if defined(RS_DIAG) && RS_DIAG == 2
-        else if (js >= lo && js == 0x7FFFFFF1) out[(u32)b[r] + (u32)js] = k[r];
-#else
         else if (js >= lo) out[(u32)b[r] + (u32)js] = k[r];
-#endif
     }
 }
-template <int FIXED0>
-__device__ __forceinline__ void rs_flush_slot(ScShared &sh, const RsDigit &dg, u64 *__restrict__ out, u32 j, u64 k) {
-    const u32 d = rs_digit<FIXED0>(dg, k);
-    const ScBody b = sh.body[d];
-    const int js = (int)j;
-    if (js >= b.fl) sh.carry[d][js - b.fl] = k;
-    else if (js >= b.lo) out[b.delta + j] = k;
-}
-
 #ifndef RS_WAVES_EU
 #define RS_WAVES_EU 4                  // 128 VGPRs: two 512-thread workgroups per CU, as the LDS footprint allows
 #endif
@@ -381,6 +369,8 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < n ? beg + chunk : n;
     TextStage st{stext, ssep, 0, 0};
+    rs_clear_rank_state(sh);
+    lds_barrier();
     u64 key[SC_ITEMS];
     const u64 *src = in + (u64)w * (64u * SC_ITEMS) + lane;
     if (SRC == 0 && beg + RS_TILE <= end) {
@@ -388,42 +378,25 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
         for (int r = 0; r < SC_ITEMS; r++) key[r] = src[beg + r * 64];
     }
     for (u64 tile = beg; tile < end; tile += RS_TILE) {
+        int tot = RS_TILE;
         if (SRC == 0 && tile + RS_TILE <= end) {
             // whole tile; its keys were loaded while the previous tile was being flushed
             rs_rank_tile<DG, 1>(key, 0xFFFFFFFFu, dg, sh, oalign);
-#ifndef RS_NO_PREFETCH
             if (tile + 2 * RS_TILE <= end) {
 #pragma unroll
                 for (int r = 0; r < SC_ITEMS; r++) key[r] = src[tile + RS_TILE + r * 64];
             }
-#endif
-#if !defined(RS_DIAG) || RS_DIAG != 4          // diagnostics 4: no flush at all
-#if !defined(RS_DIAG) || RS_DIAG != 5          // diagnostics 5: no F1
-            rs_flush_heads(sh, out);
-#endif
-            u64 k[SC_ITEMS];
-#pragma unroll
-            for (int r = 0; r < SC_ITEMS; r++) k[r] = sh.skeys[tid + r * SC_NT];
-            lds_barrier();                                   // F1 has read the old carry
-#if !defined(RS_DIAG) || RS_DIAG != 6          // diagnostics 6: no F2
-            rs_flush_body<DG>(sh, dg, out, k);
-#else
-            if (k[0] == 0x123456789ull) out[0] = k[1] + k[2] + k[3] + k[4] + k[5] + k[6] + k[7];
-#endif
-#endif
-#ifdef RS_NO_PREFETCH
-            if (tile + 2 * RS_TILE <= end) {
-#pragma unroll
-                for (int r = 0; r < SC_ITEMS; r++) key[r] = src[tile + RS_TILE + r * 64];
-            }
-#endif
         } else {
             u32 vmask = SRC ? rs_load_tile_text(ts, st, tile, end, key) : rs_load_tile<SRC>(in, ts, tile, end, key);
-            u32 tot = rs_rank_tile<DG, 0>(key, vmask, dg, sh, oalign);
-            rs_flush_heads(sh, out);
-            lds_barrier();
-            for (u32 j = tid; j < tot; j += SC_NT) rs_flush_slot<DG>(sh, dg, out, j, sh.skeys[j]);
+            tot = (int)rs_rank_tile<DG, 0>(key, vmask, dg, sh, oalign);
         }
+        rs_flush_heads(sh, out);
+        u64 k[SC_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SC_ITEMS; r++) k[r] = sh.skeys[tid + r * SC_NT];
+        lds_barrier();                                         // F1 has read the old carry, every wave holds its slots
+        rs_flush_body<DG>(sh, dg, out, k, tot);
+        rs_clear_rank_state(sh);                               // the next tile ranks right after the barrier
         lds_barrier();
     }
     // the last, partial line of every digit
