@@ -415,6 +415,9 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
 #define RL_H (RL_CAP * 7 / 8)          // its tile stride: tile j starts at the first bucket boundary >= j*RL_H
 #define RLW_CAP 1024                   // keys a single wave finishes (16 per lane, no barriers at all)
 #define RLW_H (RLW_CAP * 7 / 8)
+#ifndef RL_MAX_ROUNDS
+#define RL_MAX_ROUNDS 16               // merge-split rounds before a wave tile falls back to the full network
+#endif
 
 // first index i >= x (0 < x < n) where the bucket prefix changes (or n); one wave, all lanes return it.
 // `reach`: how far a boundary may lie for the tile to fit; beyond it the run's end is found by bisection.
@@ -499,6 +502,61 @@ __global__ __launch_bounds__(NT) void rs_local_kernel(u64 *__restrict__ keys, u6
 #pragma unroll
     for (int r = 0; r < KPT; r++) k[r] = A[RL_PAD(tid * KPT + r)];
     __syncthreads();
+    // Wave tiles first try a network sized for what the data looks like here: the keys arrive ordered by bucket and a
+    // bucket holds ~16 keys, so after sorting every lane's 16 keys a key is at most a few lanes from its place.
+    // Rounds of merge-splits between neighbouring lanes (even pairs, then odd pairs: a block odd-even transposition
+    // sort, ~18 operations per key and round instead of the full network's ~270) run until a ballot finds every lane
+    // boundary in order -- runs of equal keys (repeat families) are in order from the start.  Anything that is not
+    // sorted after RL_MAX_ROUNDS rounds goes through the full bitonic network below.
+    bool sorted = false;
+    if (NT == 64) {
+#pragma unroll
+        for (int lk = 1; lk <= 4; lk++) {
+#pragma unroll
+            for (int lj = lk - 1; lj >= 0; lj--) {
+                const int jj = 1 << lj;
+#pragma unroll
+                for (int r = 0; r < KPT; r++)
+                    if ((r & jj) == 0) rl_cex(k[r], k[r | jj], (r & (1 << lk)) == 0);
+            }
+        }
+        for (int round = 0; round < RL_MAX_ROUNDS; round++) {
+            u64 nxt = __shfl_down(k[0], 1, 64);
+            bool ok = tid == 63 || k[KPT - 1] <= nxt;
+            if (__ballot(!ok) == 0ull) { sorted = true; break; }
+            // partner lane of this round; lanes without one (0 and 63 in odd rounds) keep their keys
+            const bool odd = round & 1;
+            const bool lower = ((tid ^ (u32)odd) & 1u) == 0;
+            const int partner = lower ? (int)tid + 1 : (int)tid - 1;
+            const bool active = partner >= 0 && partner < 64;
+            const int src = active ? partner : (int)tid;
+            u64 t[KPT];
+#pragma unroll
+            for (int r = 0; r < KPT; r++) t[r] = __shfl(k[KPT - 1 - r], src, 64);
+            if (active) {
+                // merge-split: the lower lane keeps the 16 smallest of the 32, the upper lane the 16 largest
+#pragma unroll
+                for (int r = 0; r < KPT; r++) {
+                    bool pless = t[r] < k[r];
+                    k[r] = (lower == pless) ? t[r] : k[r];
+                }
+                // each half is bitonic now: four in-lane merge steps sort it ascending
+#pragma unroll
+                for (int lj = 3; lj >= 0; lj--) {
+                    const int jj = 1 << lj;
+#pragma unroll
+                    for (int r = 0; r < KPT; r++)
+                        if ((r & jj) == 0) rl_cex(k[r], k[r | jj], true);
+                }
+            }
+        }
+        if (!sorted) {
+            u64 nxt = __shfl_down(k[0], 1, 64);
+            bool ok = tid == 63 || k[KPT - 1] <= nxt;
+            sorted = __ballot(!ok) == 0ull;
+        }
+    }
+    if (!sorted) {
 #pragma unroll
     for (int lk = 1; lk <= LOGN; lk++) {
         const u32 kk = 1u << lk;
@@ -537,6 +595,7 @@ __global__ __launch_bounds__(NT) void rs_local_kernel(u64 *__restrict__ keys, u6
                 __syncthreads();
             }
         }
+    }
     }
 #pragma unroll
     for (int r = 0; r < KPT; r++) A[RL_PAD(tid * KPT + r)] = k[r];
