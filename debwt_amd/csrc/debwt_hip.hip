@@ -368,7 +368,21 @@ static int classify_local(debwt_ctx *c) {
     // pflag (n bytes) is free until the SP stage: it holds the per-distinct-key classification byte
     u8 *cf = c->pflag.as<u8>();
     ClassifyFlagsF ff{cc, c->K, cf};
-    if ((rc = cp_count2(c, ff, D, cp_area(c, 1), 1, cp_area(c, 2), 2))) return rc;
+    {
+        u32 nchunks; u64 chunk;
+        plan_chunks(D, &nchunks, &chunk);
+        u32 *ca = cp_area(c, 1), *cb = cp_area(c, 2);
+        u32 *wl = (c->sk == c->keysA.as<u64>() ? c->keysB : c->keysA).as<u32>();   // the sort's scratch buffer: >= 8 M bytes
+        u32 *wl_count = cp_area(c, 7);
+        if (D) {
+            k_classify_flags<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ff, chunk, ca, cb, wl, wl_count);
+            k_classify_groups<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ff, chunk, ca, cb, wl, wl_count);
+        } else { HIPCHK(c, hipMemsetAsync(ca, 0, sizeof(u32), c->stream)); HIPCHK(c, hipMemsetAsync(cb, 0, sizeof(u32), c->stream)); }
+        cp_scan_kernel<<<1, 1024, 0, c->stream>>>(ca, D ? nchunks : 1, ca + CP_MAXCHUNKS);
+        cp_scan_kernel<<<1, 1024, 0, c->stream>>>(cb, D ? nchunks : 1, cb + CP_MAXCHUNKS);
+        HIPCHK(c, hipMemcpyAsync(&c->h_scalars[1], ca + CP_MAXCHUNKS, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&c->h_scalars[2], cb + CP_MAXCHUNKS, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
     if ((rc = sync_check(c))) return rc;
     c->Q = c->h_scalars[1];
     c->Rmo = c->h_scalars[2];

@@ -178,16 +178,16 @@ struct RleF {
 struct ClassifyCommon {
     const u64 *dk; const u32 *dstart; u64 D; u64 M;
     const u64 *head_keys; u64 nrec;
-    // instances of distinct key e that are real edges (record-start instances carry the fake pred 3)
-    __device__ u32 real_count(u64 e) const {
+    // does distinct key e have an instance that is a real edge?  (record-start instances carry the fake pred 3:
+    // only a key that equals a record-start key needs its instance count)
+    __device__ bool real_count(u64 e) const {
         u64 k = dk[e];
+        if ((k & 3) != 3) return true;
+        u64 lo = lower_bound_dev<u64>(head_keys, 0, nrec, k);
+        if (lo >= nrec || head_keys[lo] != k) return true;
+        u64 hi = upper_bound_dev<u64>(head_keys, lo, nrec, k);
         u32 cnt = (e + 1 < D ? dstart[e + 1] : (u32)M) - dstart[e];
-        if ((k & 3) == 3) {
-            u64 lo = lower_bound_dev<u64>(head_keys, 0, nrec, k);
-            u64 hi = upper_bound_dev<u64>(head_keys, lo, nrec, k);
-            cnt -= (u32)(hi - lo);
-        }
-        return cnt;
+        return cnt > (u32)(hi - lo);
     }
     __device__ bool is_head(u64 node) const {
         u64 k = (node << 2) | 3ull;
@@ -204,7 +204,7 @@ __device__ __forceinline__ bool eval_multi_in(const ClassifyCommon &c, u64 e, u3
     u64 f = e;
     for (; f < c.D && f < e + 4 && (c.dk[f] >> 2) == node; f++)
         if (c.real_count(f)) preds |= 1u << (c.dk[f] & 3);
-    *freq = (f < c.D ? c.dstart[f] : (u32)c.M) - c.dstart[e];
+    if (freq) *freq = (f < c.D ? c.dstart[f] : (u32)c.M) - c.dstart[e];
     return __popc(preds) >= 2 || c.is_head(node);
 }
 
@@ -244,14 +244,91 @@ struct ClassifyFlagsF {
             mi = ((k & 3) == 3 && c.is_head(k >> 2)) ? 1u : 0u;
             mo = 0;
         } else {
-            u32 fr;
-            mi = eval_multi_in(c, e, &fr) ? 1u : 0u;
+            mi = eval_multi_in(c, e, nullptr) ? 1u : 0u;
             mo = eval_multi_out(c, K, e, nullptr);
         }
         cf[e] = (u8)(mi | (mo << 1));
         *a = mi; *b = mo;
     }
 };
+// The same sweep as a kernel of its own: a thread takes 4 consecutive distinct keys with two 16-byte loads, the
+// keys before and behind come from the neighbouring lanes; a key whose (K-1)-prefix group is just itself (the bulk:
+// every unique k-mer) is classified in registers, only the others walk their group in memory.  One 4-byte store
+// of the four classification bytes.  Chunks as plan_chunks (multiples of 1024 keys).
+// Keys inside larger groups (about 1 % of them, but some in nearly every wave) are not walked here -- a few lanes
+// chasing dependent loads would stall every wave -- but queued (wave-aggregated append, order irrelevant) for
+// k_classify_groups, where every lane has such a key.  The queue of a chunk is wl[beg ..), wl_count[chunk] entries.
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_classify_flags(ClassifyFlagsF f, u64 chunk, u32 *__restrict__ counts_a,
+                                                                 u32 *__restrict__ counts_b, u32 *__restrict__ wl,
+                                                                 u32 *__restrict__ wl_count) {
+    __shared__ u32 red[2][DEBWT_WAVES];
+    __shared__ u32 qn;
+    const ClassifyCommon &c = f.c;
+    const u64 D = c.D;
+    u64 beg = (u64)blockIdx.x * chunk;
+    u64 end = beg + chunk < D ? beg + chunk : D;
+    u32 la = 0, lb = 0;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    wl += beg;
+    for (u64 tile = beg; tile < end; tile += DEBWT_BLOCK * 4) {
+        const u64 e0 = tile + (u64)threadIdx.x * 4;
+        u64 k[6];                                              // k[0] = key before e0, k[1..4] = e0..e0+3, k[5] = key behind
+        const bool whole = e0 + 4 <= end;                      // end <= D and D's buffer is padded: loads stay inside
+        if (whole) {
+            ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(c.dk + e0);
+            ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(c.dk + e0 + 2);
+            k[1] = v0.x; k[2] = v0.y; k[3] = v1.x; k[4] = v1.y;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) k[1 + t] = e0 + t < D ? c.dk[e0 + t] : ~0ull;
+        }
+        u64 up = __shfl_up(k[4], 1, 64), dn = __shfl_down(k[1], 1, 64);
+        const u32 lane = threadIdx.x & 63u;
+        // the wave's first/last lane (and lanes next to a partial thread) read their neighbours from memory
+        k[0] = (lane == 0 || !whole) ? (e0 && e0 <= D ? c.dk[e0 - 1] : ~0ull) : up;
+        k[5] = (lane == 63 || !whole || e0 + 8 > end) ? (e0 + 4 < D ? c.dk[e0 + 4] : ~0ull) : dn;
+        u32 word = 0, queued = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const u64 e = e0 + t;
+            if (e >= end) break;
+            const u64 key = k[1 + t], W = key >> 4;
+            const bool alone = (e == 0 || (k[t] >> 4) != W) && (e + 1 >= D || (k[2 + t] >> 4) != W);
+            if (alone) {
+                u32 mi = ((key & 3) == 3 && c.is_head(key >> 2)) ? 1u : 0u;
+                word |= mi << (8 * t);
+                la += mi;
+            } else {
+                queued |= 1u << t;
+            }
+        }
+        {   // append the queued keys of the wave: one atomic per wave and tile
+            u32 nq = __popc(queued);
+            u32 incl = wave_scan_incl(nq);
+            u32 base = 0;
+            if (lane == 63 && incl) base = atomicAdd(&qn, incl);
+            base = __shfl(base, 63, 64) + incl - nq;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if ((queued >> t) & 1u) wl[base++] = (u32)(e0 + t);
+        }
+        if (whole) *reinterpret_cast<u32 *>(f.cf + e0) = word;
+        else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (e0 + t < end) f.cf[e0 + t] = (u8)(word >> (8 * t));
+        }
+    }
+    u32 ia = wave_scan_incl(la), ib = wave_scan_incl(lb);
+    if (lane_id() == 63) { red[0][threadIdx.x >> 6] = ia; red[1][threadIdx.x >> 6] = ib; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 sa = 0, sb = 0;
+        for (int w = 0; w < DEBWT_WAVES; w++) { sa += red[0][w]; sb += red[1][w]; }
+        counts_a[blockIdx.x] = sa; counts_b[blockIdx.x] = sb;
+        wl_count[blockIdx.x] = qn;
+    }
+}
 // ordered compaction of both fact kinds from the classification bytes: every thread owns 16 consecutive
 // bytes (one 16-byte load); one block scan per 4096 distinct keys carries both running offsets
 struct FactEmitArgs {
@@ -324,6 +401,33 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_emit_facts(FactEmitArgs a, u64 
             }
         }
         base_mi += tot[0]; base_mo += tot[1];
+    }
+}
+
+// the queued keys of a chunk, one per thread; classification bytes, and the chunk's counters of the sweep above
+// grow by what they add
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_classify_groups(ClassifyFlagsF f, u64 chunk, u32 *__restrict__ counts_a,
+                                                                  u32 *__restrict__ counts_b, const u32 *__restrict__ wl,
+                                                                  const u32 *__restrict__ wl_count) {
+    __shared__ u32 red[2][DEBWT_WAVES];
+    const u32 nq = wl_count[blockIdx.x];
+    if (nq == 0) return;
+    wl += (u64)blockIdx.x * chunk;
+    u32 la = 0, lb = 0;
+    for (u32 i = threadIdx.x; i < nq; i += DEBWT_BLOCK) {
+        const u64 e = wl[i];
+        const u32 mi = eval_multi_in(f.c, e, nullptr) ? 1u : 0u;
+        const u32 mo = eval_multi_out(f.c, f.K, e, nullptr);
+        if (mi | mo) f.cf[e] = (u8)(mi | (mo << 1));
+        la += mi; lb += mo;
+    }
+    u32 ia = wave_scan_incl(la), ib = wave_scan_incl(lb);
+    if (lane_id() == 63) { red[0][threadIdx.x >> 6] = ia; red[1][threadIdx.x >> 6] = ib; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 sa = 0, sb = 0;
+        for (int w = 0; w < DEBWT_WAVES; w++) { sa += red[0][w]; sb += red[1][w]; }
+        counts_a[blockIdx.x] += sa; counts_b[blockIdx.x] += sb;
     }
 }
 
