@@ -37,7 +37,7 @@ SYMBOLS = [
     "debwt_shard_begin", "debwt_shard_histogram", "debwt_shard_set_range", "debwt_shard_classify_local",
     "debwt_shard_facts_export", "debwt_shard_classify_global", "debwt_shard_info", "debwt_shard_fetch",
     "debwt_shard_partition_keys", "debwt_shard_import_keys", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
-    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place",
+    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap",
 ]
 
 
@@ -123,5 +123,7 @@ def lib():
     L.debwt_shard_info.argtypes = [vp, u64p, u64p, u64p]
     L.debwt_shard_fetch.restype = ctypes.c_int
     L.debwt_shard_fetch.argtypes = [vp, u64p, u64p, u64p]
+    L.debwt_set_range_cap.restype = ctypes.c_int
+    L.debwt_set_range_cap.argtypes = [vp, ctypes.c_uint64]
     _lib = L
     return L

@@ -99,6 +99,10 @@ class DeBWT:
         self._chk(self._L.debwt_load_ascii(self._h, b"".join(recs), _p64(lens), len(recs)))
         self.n, self.nrec = int(lens.sum()) + len(recs), len(recs)
 
+    def set_range_cap(self, max_instances):
+        """Largest number of node instances sorted in one go; larger texts are built in k-mer-prefix ranges."""
+        self._chk(self._L.debwt_set_range_cap(self._h, int(max_instances)))
+
     # -- stages (src/main.c:83-149) -------------------------------------------------------------------
     def kmer_sort_rle(self):
         self._chk(self._L.debwt_kmer_sort_rle(self._h))

@@ -54,6 +54,18 @@ struct debwt_ctx {
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
     u64 D = 0, Q = 0, Rmo = 0, R = 0, B = 0, S = 0, nlarge = 0, nfacts = 0;
+    u64 rQ = 0, rB = 0, rnlarge = 0;   // blocks, blue rows, large blocks of the range just classified
+    // Key ranges of this context, sorted and classified one after the other over the resident text (one range unless
+    // the node instances exceed range_cap: "bucket streaming" for texts whose keys do not fit HBM at once).
+    // D, Rmo and the buffers keysA/keysB/dk/dstart/pflag/mi_*/bstart/facts belong to the range being processed;
+    // Q, B, nlarge and blk_*/facts_acc/large_q/mchar/sprow cover the whole context with 64-bit offsets.
+    struct KeyRange { u64 key_lo, key_hi, M, Mbase, Q, qbase, B, Bbase, s0, s1; };
+    std::vector<KeyRange> ranges;
+    u64 range_cap = 1ull << 31;
+    u64 Mctx = 0;               // node instances of this context (sum over its ranges)
+    u64 nfacts_acc = 0;         // facts accumulated over the ranges
+    bool local_done = false;    // classify_local already ran per range (multi-range build)
+    DevBuf blk_j0, blk_freq, blk_start, facts_acc, large_tmp;
     // k-mer-prefix shard of a multi-GPU build (world == 1: the whole key space)
     int shard_rank = 0, shard_world = 1;
     u64 Mfull = 0;              // node instances of the whole text
@@ -67,7 +79,8 @@ struct debwt_ctx {
     bool keys_imported = false; // sharded exchange mode: this shard's keys arrived by alltoallv (keysA)
     u64 g0 = 0, g1 = 0;         // text slice of this shard for the SP stage, in 32-position groups
     u64 S_local = 0, B_slice = 0, sp_off = 0;
-    int hbits = 10;
+    int hbits = 10, pbits = 13;
+    bool abs32 = true;          // fill cursors hold absolute blue slots
 
     hipEvent_t ev[8]{};         // stage boundaries
     hipEvent_t ev_pass[16][2]{};
@@ -94,6 +107,21 @@ int ensure(debwt_ctx *c, DevBuf &b, size_t bytes) {
     return DEBWT_OK;
 }
 #define ENSURE(c, b, bytes) do { int r_ = ensure((c), (b), (bytes)); if (r_) return r_; } while (0)
+// grows a buffer that accumulates over the key ranges: the first `used` bytes survive
+int ensure_keep(debwt_ctx *c, DevBuf &b, size_t bytes, size_t used) {
+    if (bytes <= b.cap) return DEBWT_OK;
+    size_t want = bytes + bytes / 2 + 256;
+    void *np = nullptr;
+    HIPCHK(c, hipMalloc(&np, want));
+    if (b.p) {
+        if (used) HIPCHK(c, hipMemcpyAsync(np, b.p, used, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+    }
+    b.p = np; b.cap = want;
+    return DEBWT_OK;
+}
+#define ENSURE_KEEP(c, b, bytes, used) do { int r_ = ensure_keep((c), (b), (bytes), (used)); if (r_) return r_; } while (0)
 
 void plan_chunks(u64 n, u32 *nchunks, u64 *chunk) {
     const u64 DEBWT_TILE = (u64)DEBWT_BLOCK * CP_VEC;
@@ -101,6 +129,7 @@ void plan_chunks(u64 n, u32 *nchunks, u64 *chunk) {
     u64 c = tiles < CP_MAXCHUNKS ? tiles : CP_MAXCHUNKS;
     if (c == 0) c = 1;
     u64 per = (tiles + c - 1) / c;
+    if (per == 0) per = 1;                              // n == 0: one empty chunk
     *chunk = per * DEBWT_TILE;
     *nchunks = (u32)((n + *chunk - 1) / *chunk);
     if (*nchunks == 0) *nchunks = 1;
@@ -155,16 +184,20 @@ RadixWorkspace radix_ws(debwt_ctx *c) {
     return ws;
 }
 
+// main: the key sort of a range (kernels named for the profile, keys possibly read off the text); otherwise one of
+// the small auxiliary sorts.  Pass events are recorded when `record_passes`.
 int sort_keys(debwt_ctx *c, u64 *a, u64 *b, u64 count, int key_bits, u64 **result, bool record_passes,
-              const TextKeySrc *text = nullptr) {
+              const TextKeySrc *text = nullptr, bool main_sort = false) {
     RadixWorkspace ws = radix_ws(c);
     hipError_t e = hipSuccess;
+    const bool main = main_sort || record_passes;
     if (record_passes) {
         *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo, &c->ev_pass[0][0], 16,
                                  &c->n_pass_events, &e, text);
         c->st.radix_pass_keys = count;
     } else {
-        *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo | 16, nullptr, 0, nullptr, &e);
+        *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo | (main ? 0 : 16), nullptr, 0,
+                                 nullptr, &e, text);
     }
     if (e != hipSuccess) { c->err = std::string("radix sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
     return DEBWT_OK;
@@ -224,7 +257,8 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q,
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
-                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor};
+                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
+                     &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -247,13 +281,13 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     const int K = c->K;
     if (n <= nrec * (uint64_t)K) return DEBWT_EINVAL;
     uint64_t M = n - nrec * (uint64_t)K;
-    if (M >= 0xFFFFFFF0ull) return DEBWT_ERANGE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->h_text = packed;
     c->h_sep.assign(sep, sep + nrec);
-    c->n = n; c->nrec = nrec; c->M = M; c->Mfull = M; c->NS = nrec * (uint64_t)K;
+    c->n = n; c->nrec = nrec; c->M = M; c->Mfull = M; c->Mctx = M; c->NS = nrec * (uint64_t)K;
     c->shard_rank = 0; c->shard_world = 1; c->key_lo = c->key_hi = 0; c->Mbase = 0; c->qbase = 0;
     c->keys_imported = false;
+    c->ranges.clear();
     size_t tw = (size_t)((n + 63) >> 5) + 2, bw = (size_t)(n >> 6) + 3;
     ENSURE(c, c->text, tw * 8);
     ENSURE(c, c->sepbits, bw * 8);
@@ -263,14 +297,7 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     HIPCHK(c, hipMemcpyAsync(c->sep.p, sep, nrec * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->sepbits.p, 0, bw * 8, c->stream));
     k_set_sepbits<<<grid_for(nrec, 256), 256, 0, c->stream>>>(c->sep.as<u64>(), nrec, c->sepbits.as<u64>());
-    // workspace that depends only on n
-    ENSURE(c, c->keysA, M * 8 + 64);
-    ENSURE(c, c->keysB, M * 8 + 64);
-    ENSURE(c, c->rs_skew, (M / 2048 + 2) * 4);
-    ENSURE(c, c->dk, M * 8 + 64);
-    ENSURE(c, c->dstart, M * 4 + 64);
-    ENSURE(c, c->mchar, M + 64);
-    ENSURE(c, c->pflag, n + 64);
+    // workspace that depends only on n (the key buffers are sized per key range in debwt_kmer_sort_rle)
     ENSURE(c, c->head_keys, nrec * 8);
     ENSURE(c, c->spkey, c->NS * 8);
     ENSURE(c, c->sprow, c->NS * 8);
@@ -283,6 +310,12 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     c->stage = ST_LOADED;
     memset(&c->st, 0, sizeof c->st);
     c->st.n = n; c->st.nrec = nrec; c->st.n_main = M;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_set_range_cap(debwt_ctx *c, uint64_t max_instances) {
+    if (!c || max_instances < 4096) return DEBWT_EINVAL;
+    c->range_cap = std::min<uint64_t>(max_instances, 0xFFFFFFF0ull - 1);
     return DEBWT_OK;
 }
 
@@ -318,39 +351,133 @@ extern "C" int debwt_load_ascii(debwt_ctx *c, const char *seq, const uint64_t *r
 // ---------------------------------------------------------------------------------------------------
 // stage 1: keys, sort, RLE                                                            (a-1, a-2, a-3)
 
+// Cuts the key space into ranges of at most range_cap node instances at 12-mer prefix bins (the census the
+// reference balances its sort threads on, src/mySort.c:98-110).  A sharded or key-importing context has exactly
+// the range it was given.
+static int plan_ranges(debwt_ctx *c) {
+    c->ranges.clear();
+    c->local_done = false;
+    debwt_ctx::KeyRange r{};
+    if (c->shard_world > 1 || c->keys_imported || c->Mfull <= c->range_cap) {
+        if (c->M >= 0xFFFFFFF0ull) { c->err = "a key range must hold fewer than 2^32 node instances"; return DEBWT_ERANGE; }
+        r.key_lo = c->key_lo; r.key_hi = c->key_hi; r.M = c->M;
+        c->ranges.push_back(r);
+        c->Mctx = c->M;
+        return DEBWT_OK;
+    }
+    ENSURE(c, c->shard_hist, SHARD_BINS * 8);
+    HIPCHK(c, hipMemsetAsync(c->shard_hist.p, 0, SHARD_BINS * 8, c->stream));
+    k_prefix_hist<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), 0, c->n, c->K,
+                                                        c->shard_hist.as<u64>());
+    std::vector<u64> hist(SHARD_BINS);
+    HIPCHK(c, hipMemcpyAsync(hist.data(), c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
+    int rc = sync_check(c);
+    if (rc) return rc;
+    const u64 cap = std::min<u64>(c->range_cap, 0xFFFFFFF0ull - 1);
+    const u64 P = (c->Mfull + cap - 1) / cap;
+    const u64 per = (c->Mfull + P - 1) / P;
+    const u64 limit = std::min(cap, per + per / 16);            // near-equal ranges, never above the cap
+    const int kb = 2 * c->cfg.k;
+    auto push = [&](u32 lo, u32 hi, u64 m, u64 base) {
+        debwt_ctx::KeyRange q{};
+        q.key_lo = (u64)lo << (kb - 12);
+        q.key_hi = hi == SHARD_BINS ? 0ull : ((u64)hi << (kb - 12));
+        q.M = m; q.Mbase = base;
+        c->ranges.push_back(q);
+    };
+    u64 acc = 0, base = 0, total = 0;
+    u32 lo = 0;
+    for (u32 b = 0; b < SHARD_BINS; b++) {
+        if (hist[b] > cap) { c->err = "one 12-mer prefix bin holds more node instances than a key range may"; return DEBWT_ERANGE; }
+        if (acc && acc + hist[b] > limit) { push(lo, b, acc, base); base += acc; acc = 0; lo = b; }
+        acc += hist[b]; total += hist[b];
+    }
+    push(lo, SHARD_BINS, acc, base);
+    if (total != c->Mfull) { c->err = "prefix census differs from the number of node instances"; return DEBWT_EINTERNAL; }
+    c->Mctx = c->Mfull;
+    return DEBWT_OK;
+}
+
+static int classify_local(debwt_ctx *c);
+static int append_range(debwt_ctx *c, debwt_ctx::KeyRange &r);
+
 extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
     if (!c) return DEBWT_EINVAL;
     if (c->stage < ST_LOADED) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    const u64 n = c->n, M = c->M;
+    const u64 n = c->n;
+    int rc = plan_ranges(c);
+    if (rc) return rc;
+    u64 maxM = 0;
+    for (auto &r : c->ranges) maxM = std::max(maxM, r.M);
+    ENSURE(c, c->keysA, maxM * 8 + 64);
+    ENSURE(c, c->keysB, maxM * 8 + 64);
+    ENSURE(c, c->rs_skew, (maxM / 2048 + 2) * 4);
+    ENSURE(c, c->dk, maxM * 8 + 64);
+    ENSURE(c, c->dstart, maxM * 4 + 64);
+    ENSURE(c, c->pflag, maxM + 64);                      // classification byte per distinct key of a range
+    ENSURE(c, c->mchar, c->Mctx + 64);
+    c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0;
+    const size_t P = c->ranges.size();
+    u64 Dsum = 0;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     // the keys (node << 2 | pred) are read off the text inside the first radix pass: no unsorted key array
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, c->key_lo, c->key_hi};
-    // exchange mode of a sharded build: the shard's keys are already in keysA (alltoallv), sort them from there
-    int rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), M, 2 * c->cfg.k, &c->sk, true,
-                       c->keys_imported ? nullptr : &ts);
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    RleF f{c->sk, c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>()};
-    if ((rc = cp_count(c, f, M, cp_area(c, 0), 0))) return rc;
-    if ((rc = cp_emit(c, f, M, cp_area(c, 0)))) return rc;
-
-    // host special-region module while the GPU sorts (src/collect#$.c:118-157,348-602)
-    auto t0 = std::chrono::steady_clock::now();
-    build_special_tables(c->h_text, n, c->h_sep.data(), c->nrec, c->K, &c->special);
-    c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    const SpecialTables &sp = c->special;
-    ENSURE(c, c->branch, sp.branch.size() * 8 + 64);
-    HIPCHK(c, hipMemcpyAsync(c->head_keys.p, sp.head_keys.data(), c->nrec * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->spkey.p, sp.key.data(), c->NS * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->spchr.p, sp.chr.data(), c->NS, hipMemcpyHostToDevice, c->stream));
-    if (!sp.branch.empty())
-        HIPCHK(c, hipMemcpyAsync(c->branch.p, sp.branch.data(), sp.branch.size() * 8, hipMemcpyHostToDevice, c->stream));
-    if ((rc = sync_check(c))) return rc;
-    c->D = c->h_scalars[0];
-    c->st.distinct_keys = c->D;
-    c->st.special_branch_num = sp.branch.size();
+    for (size_t i = 0; i < P; i++) {
+        debwt_ctx::KeyRange &r = c->ranges[i];
+        c->key_lo = r.key_lo; c->key_hi = r.key_hi; c->M = r.M;
+        TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, c->key_lo, c->key_hi};
+        // exchange mode of a sharded build: the shard's keys are already in keysA (alltoallv), sort them from there
+        rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), r.M, 2 * c->cfg.k, &c->sk, i == 0,
+                       c->keys_imported ? nullptr : &ts, true);
+        if (rc) return rc;
+        if (P == 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+        RleF f{c->sk, c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase};
+        if ((rc = cp_count(c, f, r.M, cp_area(c, 0), 0))) return rc;
+        if ((rc = cp_emit(c, f, r.M, cp_area(c, 0)))) return rc;
+        if (i == 0) {
+            // host special-region module while the GPU sorts (src/collect#$.c:118-157,348-602)
+            auto t0 = std::chrono::steady_clock::now();
+            build_special_tables(c->h_text, n, c->h_sep.data(), c->nrec, c->K, &c->special);
+            c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            const SpecialTables &sp = c->special;
+            ENSURE(c, c->branch, sp.branch.size() * 8 + 64);
+            HIPCHK(c, hipMemcpyAsync(c->head_keys.p, sp.head_keys.data(), c->nrec * 8, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->spkey.p, sp.key.data(), c->NS * 8, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->spchr.p, sp.chr.data(), c->NS, hipMemcpyHostToDevice, c->stream));
+            if (!sp.branch.empty())
+                HIPCHK(c, hipMemcpyAsync(c->branch.p, sp.branch.data(), sp.branch.size() * 8, hipMemcpyHostToDevice, c->stream));
+        }
+        // special suffixes whose key lies in this range, and their rows among the context's instances
+        {
+            const std::vector<uint64_t> &key = c->special.key;          // ascending (suffix order implies key order)
+            u64 s0 = 0, s1 = c->NS;
+            if (c->shard_world > 1 || P > 1) {
+                s0 = std::lower_bound(key.begin(), key.end(), r.key_lo >> 2) - key.begin();
+                s1 = r.key_hi ? (u64)(std::lower_bound(key.begin(), key.end(), r.key_hi >> 2) - key.begin()) : c->NS;
+            }
+            r.s0 = s0; r.s1 = s1;
+            if (s1 > s0)
+                k_special_rows<<<grid_for(s1 - s0, 256), 256, 0, c->stream>>>(
+                    c->sk, r.M, c->spkey.as<u64>() + s0, s1 - s0, r.Mbase + (s0 - c->ranges[0].s0), c->sprow.as<u64>() + s0);
+        }
+        if ((rc = sync_check(c))) return rc;
+        c->D = c->h_scalars[0];
+        Dsum += c->D;
+        if (P > 1) {
+            // the range's keys are gone after this iteration: classify them now
+            if ((rc = classify_local(c))) return rc;
+            if ((rc = append_range(c, r))) return rc;
+        }
+    }
+    c->s0 = c->ranges.front().s0; c->s1 = c->ranges.back().s1;
+    if (P > 1) {
+        c->local_done = true;
+        HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    }
+    c->st.distinct_keys = Dsum;
+    c->st.special_branch_num = c->special.branch.size();
     c->stage = ST_SORTED;
     return DEBWT_OK;
 }
@@ -363,7 +490,7 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
 static int classify_local(debwt_ctx *c) {
     const u64 M = c->M, D = c->D, nrec = c->nrec;
     int rc;
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    if (c->ranges.size() == 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     ClassifyCommon cc{c->dk.as<u64>(), c->dstart.as<u32>(), D, M, c->head_keys.as<u64>(), nrec};
     // pflag (n bytes) is free until the SP stage: it holds the per-distinct-key classification byte
     u8 *cf = c->pflag.as<u8>();
@@ -384,14 +511,14 @@ static int classify_local(debwt_ctx *c) {
         HIPCHK(c, hipMemcpyAsync(&c->h_scalars[2], cb + CP_MAXCHUNKS, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     }
     if ((rc = sync_check(c))) return rc;
-    c->Q = c->h_scalars[1];
+    c->rQ = c->h_scalars[1];
     c->Rmo = c->h_scalars[2];
-    const u64 Q = c->Q, Rmo = c->Rmo;
+    const u64 Q = c->rQ, Rmo = c->Rmo;
     ENSURE(c, c->facts, (Rmo + Q) * 8 + 64);
     ENSURE(c, c->mi_j0, Q * 4 + 64);
     ENSURE(c, c->mi_freq, Q * 4 + 64);
     ENSURE(c, c->bstart, Q * 4 + 64);
-    ENSURE(c, c->large_q, Q * 4 + 64);
+    ENSURE(c, c->large_tmp, Q * 4 + 64);
     u64 *facts = c->facts.as<u64>();
     {
         const u64 nslots = Q + Rmo;
@@ -407,14 +534,38 @@ static int classify_local(debwt_ctx *c) {
     BlockStartF fb{c->mi_freq.as<u32>(), c->bstart.as<u32>()};
     if ((rc = cp_count(c, fb, Q, cp_area(c, 4), 4))) return rc;
     if ((rc = cp_emit(c, fb, Q, cp_area(c, 4)))) return rc;
-    LargeBlockF fl{c->mi_freq.as<u32>(), BLUE_LDS_CAP, c->large_q.as<u32>()};
+    LargeBlockF fl{c->mi_freq.as<u32>(), BLUE_LDS_CAP, c->large_tmp.as<u32>()};
     if ((rc = cp_count(c, fl, Q, cp_area(c, 5), 5))) return rc;
     if ((rc = cp_emit(c, fl, Q, cp_area(c, 5)))) return rc;
     if ((rc = sync_check(c))) return rc;
-    c->B = c->h_scalars[4];
-    c->nlarge = c->h_scalars[5];
-    c->facts_ready = true;
+    c->rB = c->h_scalars[4];
+    c->rnlarge = c->h_scalars[5];
     return DEBWT_OK;
+}
+
+// appends the range just classified (facts, block tables, large-block list) to the context-wide tables
+static int append_range(debwt_ctx *c, debwt_ctx::KeyRange &r) {
+    const u64 Q = c->rQ, nf = c->Rmo + Q;
+    r.Q = Q; r.qbase = c->Q; r.B = c->rB; r.Bbase = c->B;
+    ENSURE_KEEP(c, c->facts_acc, (c->nfacts_acc + nf) * 8 + 64, c->nfacts_acc * 8);
+    ENSURE_KEEP(c, c->blk_j0, (c->Q + Q) * 8 + 64, c->Q * 8);
+    ENSURE_KEEP(c, c->blk_freq, (c->Q + Q) * 4 + 64, c->Q * 4);
+    ENSURE_KEEP(c, c->blk_start, (c->Q + Q) * 8 + 64, c->Q * 8);
+    ENSURE_KEEP(c, c->large_q, (c->nlarge + c->rnlarge) * 4 + 64, c->nlarge * 4);
+    if (nf) HIPCHK(c, hipMemcpyAsync(c->facts_acc.as<u64>() + c->nfacts_acc, c->facts.p, nf * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (Q)
+        k_append_blocks<<<grid_for(Q, 256), 256, 0, c->stream>>>(c->mi_j0.as<u32>(), c->mi_freq.as<u32>(), c->bstart.as<u32>(), Q,
+                                                                 r.Mbase, r.Bbase, c->blk_j0.as<u64>() + r.qbase,
+                                                                 c->blk_freq.as<u32>() + r.qbase, c->blk_start.as<u64>() + r.qbase);
+    if (c->rnlarge) {
+        HIPCHK(c, hipMemcpyAsync(c->large_q.as<u32>() + c->nlarge, c->large_tmp.p, c->rnlarge * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (r.qbase)
+            k_offset_u32<<<grid_for(c->rnlarge, 256), 256, 0, c->stream>>>(c->large_q.as<u32>() + c->nlarge, c->rnlarge, (u32)r.qbase);
+    }
+    c->nfacts_acc += nf; c->Q += Q; c->B += c->rB; c->nlarge += c->rnlarge;
+    if (c->Q >= 0xFFFFFFF0ull) { c->err = "more than 2^32 multi-in blocks"; return DEBWT_ERANGE; }
+    c->facts_ready = true;
+    return sync_check(c);
 }
 
 // global half: the red table from the facts of ALL shards (d_facts: device, nfacts words, any order) plus the
@@ -445,19 +596,6 @@ static int classify_global(debwt_ctx *c, const u64 *d_facts, u64 nfacts, u64 qba
     RedBlockF fq{c->red.as<u64>(), c->red_q.as<u32>()};
     if ((rc = cp_count(c, fq, R, cp_area(c, 6), 6))) return rc;
     if ((rc = cp_emit(c, fq, R, cp_area(c, 6)))) return rc;
-    // special suffixes whose key lies in this shard's node range, and their rows among the shard's instances
-    {
-        const std::vector<uint64_t> &key = c->special.key;          // ascending (suffix order implies key order)
-        u64 s0 = 0, s1 = c->NS;
-        if (c->shard_world > 1) {
-            s0 = std::lower_bound(key.begin(), key.end(), c->key_lo >> 2) - key.begin();
-            s1 = c->key_hi ? (u64)(std::lower_bound(key.begin(), key.end(), c->key_hi >> 2) - key.begin()) : c->NS;
-        }
-        c->s0 = s0; c->s1 = s1;
-        if (s1 > s0)
-            k_special_rows<<<grid_for(s1 - s0, 256), 256, 0, c->stream>>>(c->sk, c->M, c->spkey.as<u64>() + s0, s1 - s0,
-                                                                        c->sprow.as<u64>() + s0);
-    }
     ENSURE(c, c->blue, c->B * 8 + 64);
     if ((rc = sync_check(c))) return rc;
     if (c->shard_world == 1 && c->h_scalars[6] != Q) {
@@ -475,9 +613,12 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     if (c->stage < ST_SORTED) return DEBWT_ESTATE;
     if (c->shard_world > 1) { c->err = "sharded context: use debwt_shard_classify_local/_global"; return DEBWT_ESTATE; }
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    int rc = classify_local(c);
-    if (rc) return rc;
-    return classify_global(c, c->facts.as<u64>(), c->Rmo + c->Q, 0, c->B);
+    int rc;
+    if (!c->local_done) {
+        if ((rc = classify_local(c))) return rc;
+        if ((rc = append_range(c, c->ranges[0]))) return rc;
+    }
+    return classify_global(c, c->facts_acc.as<u64>(), c->nfacts_acc, 0, c->B);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -487,10 +628,9 @@ extern "C" int debwt_classify(debwt_ctx *c) {
 //   sp_flags   node table + flags of the text groups [g0, g1) + their multi-out / multi-in counts
 //   sp_emit    SP symbols of the slice at their global offset, work list of the slice's multi-in positions
 //   sp_finish  4-bit packed SP code of the WHOLE text (after the slices' symbols were all-gathered)
-static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
-    int rc;
+// node table + prefilter from the red table; flag masks sized for the whole text
+static int sp_prepare(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-    if (c->n >= (1ull << 32)) { c->err = "n >= 2^32 needs prefix-range passes"; return DEBWT_ERANGE; }
     // S <= n; the SP symbol buffer is sized for the worst case once
     ENSURE(c, c->spsym, c->n + 64);
     const u64 ngroups = (c->n + 31) >> 5;
@@ -502,7 +642,10 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
     int pb = hbits + ((c->cfg.reserved & 15) ? (c->cfg.reserved & 15) - 8 : 3);
     if (pb < 10) pb = 10;
     if (pb > 31 || hbits > 31) { c->err = "red table too large for 32-bit slots"; return DEBWT_ERANGE; }
-    c->hbits = hbits;
+    c->hbits = hbits; c->pbits = pb;
+    // absolute 32-bit fill cursors unless the context's blue slots need more bits (cfg.reserved bit 4 forces the
+    // 64-bit form: tests)
+    c->abs32 = c->B < 0xFFFFFFF0ull && !(c->cfg.reserved & 16);
     size_t rb_bytes = ((size_t)1 << pb) / 8 + 64, ht_slots = (size_t)1 << hbits;
     ENSURE(c, c->rbits, rb_bytes);
     ENSURE(c, c->htab, ht_slots * sizeof(HSlot));
@@ -510,13 +653,24 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
     HIPCHK(c, hipMemsetAsync(c->htab.p, 0, ht_slots * sizeof(HSlot), c->stream));
     if (c->R)
         k_build_hash<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->red_q.as<u32>(),
-                                                                c->bstart.as<u32>(), (u32)c->qbase, (u32)c->Q, hbits,
-                                                                c->htab.as<HSlot>(), pb, c->rbits.as<u32>());
+                                                                c->blk_start.as<u64>(), c->abs32 ? 1 : 0, (u32)c->qbase,
+                                                                (u32)c->Q, hbits, c->htab.as<HSlot>(), pb, c->rbits.as<u32>());
+    return DEBWT_OK;
+}
+
+// SP stage of the text groups [g0, g1) (a slice of fewer than 2^32 positions: the compaction counters are 32-bit):
+//   sp_flags   flags of the slice + its multi-out / multi-in counts
+//   sp_emit    SP symbols of the slice at their global offset, work list of the slice's multi-in positions
+//   sp_finish  packed SP code of the WHOLE text (after all slices / after the slices' symbols were all-gathered)
+#define SP_SLICE_GROUPS (1ull << 26)
+static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
+    int rc;
+    if (g1 - g0 > (1ull << 27) - 2) { c->err = "text slice of the SP stage exceeds 2^32 positions"; return DEBWT_ERANGE; }
     c->g0 = g0; c->g1 = g1;
     const u64 ng = g1 - g0;
     if (ng)
         k_sp_flags<<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-            c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), hbits, c->rbits.as<u32>(), pb,
+            c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
             c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1);
     SpCountF fc{c->momask.as<u32>() + g0, c->mimask.as<u32>() + g0};
     if ((rc = cp_count2(c, fc, ng, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
@@ -532,7 +686,7 @@ static int sp_emit(debwt_ctx *c, u64 sp_off) {
     ENSURE(c, c->mi_list, c->B_slice * 16 + 64);
     if (ng) {
         SpEmitArgs ea{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->momask.as<u32>(), c->mimask.as<u32>(),
-                      c->spsym.as<u8>(), c->mi_list.as<ulonglong2>(), c->g0, (u32)sp_off};
+                      c->spsym.as<u8>(), c->mi_list.as<ulonglong2>(), c->g0, sp_off};
         u32 nchunks; u64 chunk;
         plan_chunks(ng, &nchunks, &chunk);
         k_sp_emit<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ea, ng, chunk, cp_area(c, 0), cp_area(c, 1));
@@ -555,14 +709,28 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     if (c->stage < ST_CLASSIFIED) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc;
-    // the whole text on this context (also every shard of a "replicated scan" sharded build)
-    if ((rc = sp_flags(c, 0, (c->n + 31) >> 5))) return rc;
-    if (c->B_slice != c->Btotal) { c->err = "multi-in positions differ from the block total"; return DEBWT_EINTERNAL; }
-    if ((rc = sp_emit(c, 0))) return rc;
-    if (c->B_slice)
-        k_blue_fill<<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-            c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, c->blue.as<u64>());
-    return sp_finish(c, c->S_local);
+    // the whole text on this context (also every shard of a "replicated scan" sharded build), slice by slice
+    if ((rc = sp_prepare(c))) return rc;
+    const u64 ngroups = (c->n + 31) >> 5;
+    u64 S = 0, Bseen = 0;
+    for (u64 g0 = 0; g0 < ngroups; g0 += SP_SLICE_GROUPS) {
+        const u64 g1 = std::min(ngroups, g0 + SP_SLICE_GROUPS);
+        if ((rc = sp_flags(c, g0, g1))) return rc;
+        if ((rc = sp_emit(c, S))) return rc;
+        if (c->B_slice) {
+            if (c->abs32)
+                k_blue_fill<1><<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+                    c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, c->blk_start.as<u64>(),
+                    (u32)c->qbase, c->blue.as<u64>());
+            else
+                k_blue_fill<0><<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+                    c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, c->blk_start.as<u64>(),
+                    (u32)c->qbase, c->blue.as<u64>());
+        }
+        S += c->S_local; Bseen += c->B_slice;
+    }
+    if (Bseen != c->Btotal) { c->err = "multi-in positions differ from the block total"; return DEBWT_EINTERNAL; }
+    return sp_finish(c, S);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -578,28 +746,29 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
     if (Q) {
         u32 g1 = (u32)std::min<u64>(Q, 1u << 16);
         // small blocks are the bulk: a small LDS footprint keeps 32 single-wave workgroups per CU in flight
-        k_blue_refine<64, 128><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
-                                                        c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q, 0u,
+        k_blue_refine<64, 128><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
+                                                        c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q, 0u,
                                                         c->spn.as<u64>(), c->S, c->mchar.as<u8>());
-        k_blue_refine<64, BLUE_WAVE_CAP><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
-                                                                  c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q,
+        k_blue_refine<64, BLUE_WAVE_CAP><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
+                                                                  c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
                                                                   128u, c->spn.as<u64>(), c->S, c->mchar.as<u8>());
         u32 g2 = (u32)std::min<u64>(Q, 1u << 12);
-        k_blue_refine<256, BLUE_LDS_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), c->bstart.as<u32>(),
-                                                                   c->mi_freq.as<u32>(), c->mi_j0.as<u32>(), (u32)Q,
+        k_blue_refine<256, BLUE_LDS_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
+                                                                   c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
                                                                    (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
                                                                    c->mchar.as<u8>());
     }
     c->st.blue_max_block = 0;
     if (c->nlarge) {
         // heavy-tail blocks (satellite / poly-A nodes): bitonic network in HBM, one block at a time
-        std::vector<u32> lq(c->nlarge), fr(c->nlarge), bs(c->nlarge), j0(c->nlarge);
+        std::vector<u32> lq(c->nlarge), fr(c->nlarge);
+        std::vector<u64> bs(c->nlarge), j0(c->nlarge);
         HIPCHK(c, hipMemcpyAsync(lq.data(), c->large_q.p, c->nlarge * 4, hipMemcpyDeviceToHost, c->stream));
         if ((rc = sync_check(c))) return rc;
         for (u64 t = 0; t < c->nlarge; t++) {
-            HIPCHK(c, hipMemcpyAsync(&fr[t], c->mi_freq.as<u32>() + lq[t], 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(&bs[t], c->bstart.as<u32>() + lq[t], 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(&j0[t], c->mi_j0.as<u32>() + lq[t], 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&fr[t], c->blk_freq.as<u32>() + lq[t], 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&bs[t], c->blk_start.as<u64>() + lq[t], 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&j0[t], c->blk_j0.as<u64>() + lq[t], 8, hipMemcpyDeviceToHost, c->stream));
         }
         if ((rc = sync_check(c))) return rc;
         u32 maxm = 0;
@@ -630,13 +799,13 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
 // stage 5: assembly                                                                            (a-6)
 
 // rows of this shard: its node instances with its special suffixes merged in (the whole BWT when not sharded)
-static u64 shard_rows(const debwt_ctx *c) { return c->M + (c->s1 - c->s0); }
+static u64 shard_rows(const debwt_ctx *c) { return c->Mctx + (c->s1 - c->s0); }
 
 static int run_assemble(debwt_ctx *c, u8 *rowsym) {
     const u64 rows = shard_rows(c);
     u64 nw = (rows + 31) >> 5;
     k_assemble<<<grid_for(nw, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-        c->mchar.as<u8>(), c->M, c->sprow.as<u64>() + c->s0, c->spchr.as<u8>() + c->s0, c->s1 - c->s0, rows,
+        c->mchar.as<u8>(), c->Mctx, c->sprow.as<u64>() + c->s0, c->spchr.as<u8>() + c->s0, c->s1 - c->s0, rows,
         c->bwt.as<u64>(), c->hmask.as<u32>(), c->dollar.as<u64>(), rowsym);
     return DEBWT_OK;
 }
@@ -717,7 +886,8 @@ extern "C" int debwt_shard_begin(debwt_ctx *c, int rank, int world) {
     if (!c || world < 1 || rank < 0 || rank >= world) return DEBWT_EINVAL;
     if (c->stage < ST_LOADED) return DEBWT_ESTATE;
     c->shard_rank = rank; c->shard_world = world; c->keys_imported = false;
-    c->key_lo = c->key_hi = 0; c->M = c->Mfull; c->Mbase = 0; c->qbase = 0; c->s0 = 0; c->s1 = c->NS;
+    c->key_lo = c->key_hi = 0; c->M = c->Mctx = c->Mfull; c->Mbase = 0; c->qbase = 0; c->s0 = 0; c->s1 = c->NS;
+    c->ranges.clear();
     c->stage = ST_LOADED;
     return DEBWT_OK;
 }
@@ -744,7 +914,7 @@ extern "C" int debwt_shard_set_range(debwt_ctx *c, uint32_t bin_lo, uint32_t bin
     const int kb = 2 * c->cfg.k;                       // key bits; a bin is the top 12 of them
     c->key_lo = (u64)bin_lo << (kb - 12);
     c->key_hi = bin_hi == SHARD_BINS ? 0ull : ((u64)bin_hi << (kb - 12));   // 0: no upper bound (last shard)
-    c->M = m_keys; c->Mbase = m_base;
+    c->M = c->Mctx = m_keys; c->Mbase = m_base;
     c->stage = ST_LOADED;
     return DEBWT_OK;
 }
@@ -753,8 +923,10 @@ extern "C" int debwt_shard_classify_local(debwt_ctx *c, uint64_t *nfacts, uint64
     if (!c) return DEBWT_EINVAL;
     if (c->stage < ST_SORTED) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->ranges.size() != 1) return DEBWT_ESTATE;
     int rc = classify_local(c);
     if (rc) return rc;
+    if ((rc = append_range(c, c->ranges[0]))) return rc;
     if (nfacts) *nfacts = c->Rmo + c->Q;
     if (nblocks) *nblocks = c->Q;
     if (blue_rows) *blue_rows = c->B;
@@ -811,6 +983,7 @@ extern "C" int debwt_shard_import_keys(debwt_ctx *c, const uint64_t *d_keys, uin
     if (!c || (!d_keys && count)) return DEBWT_EINVAL;
     if (c->stage < ST_LOADED || count != c->M) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    ENSURE(c, c->keysA, count * 8 + 64);
     if (count) HIPCHK(c, hipMemcpyAsync(c->keysA.p, d_keys, count * 8, hipMemcpyDeviceToDevice, c->stream));
     c->keys_imported = true;
     return sync_check(c);
@@ -822,8 +995,9 @@ extern "C" int debwt_shard_sp_flags(debwt_ctx *c, uint64_t *sp_symbols, uint64_t
     HIPCHK(c, hipSetDevice(c->cfg.device));
     u64 p0, p1;
     shard_slice(c, &p0, &p1);
-    int rc = sp_flags(c, p0 >> 5, (p1 + 31) >> 5);
+    int rc = sp_prepare(c);
     if (rc) return rc;
+    if ((rc = sp_flags(c, p0 >> 5, (p1 + 31) >> 5))) return rc;
     if (sp_symbols) *sp_symbols = c->S_local;
     if (mi_positions) *mi_positions = c->B_slice;
     return DEBWT_OK;
@@ -880,11 +1054,12 @@ extern "C" int debwt_shard_blue_place(debwt_ctx *c, const uint64_t *d_entries, u
     if (count != c->B) { c->err = "received blue entries differ from the rows of the owned blocks"; return DEBWT_EINTERNAL; }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     ENSURE(c, c->qcursor, c->Q * 4 + 64);
-    if (c->Q) HIPCHK(c, hipMemcpyAsync(c->qcursor.p, c->bstart.p, c->Q * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (c->Q) HIPCHK(c, hipMemsetAsync(c->qcursor.p, 0, c->Q * 4, c->stream));
     if (count)
         k_blue_place<<<grid_for(count, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>((const u64 *)d_entries, count,
                                                                                  (u32)c->qbase, (u32)c->Q,
-                                                                                 c->qcursor.as<u32>(), c->blue.as<u64>());
+                                                                                 c->qcursor.as<u32>(), c->blk_start.as<u64>(),
+                                                                                 c->blue.as<u64>());
     return sync_check(c);
 }
 
@@ -931,8 +1106,11 @@ extern "C" int debwt_fetch_array(debwt_ctx *c, debwt_array which, void *dst, uin
     Stage need = ST_SORTED;
     std::vector<uint64_t> host;
     switch (which) {
-        case DEBWT_ARR_SORTED_KEYS: src = c->sk; cnt = c->M; break;
-        case DEBWT_ARR_DISTINCT_KEYS: src = c->dk.p; cnt = c->D; break;
+        case DEBWT_ARR_SORTED_KEYS:
+        case DEBWT_ARR_DISTINCT_KEYS:
+            if (c->ranges.size() != 1) { c->err = "sorted keys are not kept by a multi-range build"; return DEBWT_ESTATE; }
+            if (which == DEBWT_ARR_SORTED_KEYS) { src = c->sk; cnt = c->M; } else { src = c->dk.p; cnt = c->D; }
+            break;
         case DEBWT_ARR_RED: src = c->red.p; cnt = c->R; need = ST_CLASSIFIED; break;
         case DEBWT_ARR_SP_SYMBOLS: src = c->spsym.p; cnt = c->S; esz = 1; need = ST_SP; break;
         case DEBWT_ARR_BLUE: src = c->blue.p; cnt = c->B; need = ST_SP; break;
@@ -940,24 +1118,25 @@ extern "C" int debwt_fetch_array(debwt_ctx *c, debwt_array which, void *dst, uin
         case DEBWT_ARR_CASE3_BOUND: {
             need = ST_CLASSIFIED;
             if (c->stage < need) return DEBWT_ESTATE;
-            std::vector<u32> fr(c->Q), bs(c->Q), j0(c->Q);
+            std::vector<u32> fr(c->Q);
+            std::vector<uint64_t> bs(c->Q), j0(c->Q);
             std::vector<uint64_t> sprow(c->NS);
             if (c->Q) {
-                HIPCHK(c, hipMemcpy(fr.data(), c->mi_freq.p, c->Q * 4, hipMemcpyDeviceToHost));
-                HIPCHK(c, hipMemcpy(bs.data(), c->bstart.p, c->Q * 4, hipMemcpyDeviceToHost));
-                HIPCHK(c, hipMemcpy(j0.data(), c->mi_j0.p, c->Q * 4, hipMemcpyDeviceToHost));
+                HIPCHK(c, hipMemcpy(fr.data(), c->blk_freq.p, c->Q * 4, hipMemcpyDeviceToHost));
+                HIPCHK(c, hipMemcpy(bs.data(), c->blk_start.p, c->Q * 8, hipMemcpyDeviceToHost));
+                HIPCHK(c, hipMemcpy(j0.data(), c->blk_j0.p, c->Q * 8, hipMemcpyDeviceToHost));
             }
             HIPCHK(c, hipMemcpy(sprow.data(), c->sprow.p, c->NS * 8, hipMemcpyDeviceToHost));
             if (which == DEBWT_ARR_BLUE_BOUND) {
                 host.resize(c->Q);
-                for (u64 q = 0; q < c->Q; q++) host[q] = (uint64_t)bs[q] + fr[q] - 1;   // src/INandOut.c:359-361
+                for (u64 q = 0; q < c->Q; q++) host[q] = bs[q] + fr[q] - 1;   // src/INandOut.c:359-361
             } else {
                 // rows: instance j sits below every special suffix whose rank among the instances is <= j
                 std::vector<uint64_t> mrank(c->NS);
                 for (u64 s = 0; s < c->NS; s++) mrank[s] = sprow[s] - s;
                 host.resize(2 * c->Q);
                 for (u64 q = 0; q < c->Q; q++) {
-                    uint64_t before = std::upper_bound(mrank.begin(), mrank.end(), (uint64_t)j0[q]) - mrank.begin();
+                    uint64_t before = std::upper_bound(mrank.begin(), mrank.end(), j0[q]) - mrank.begin();
                     host[2 * q] = j0[q] + before;                                        // src/INandOut.c:349-352
                     host[2 * q + 1] = host[2 * q] + fr[q] - 1;
                 }
@@ -996,7 +1175,13 @@ extern "C" int debwt_kmer_count_sorted(debwt_ctx *c, uint64_t *kmers, uint64_t *
     const int k = c->cfg.k;
     if (c->n <= c->nrec * (u64)k) return DEBWT_EINVAL;
     const u64 Mk = c->n - c->nrec * (u64)k;
+    if (c->n >= 0xFFFFFFF0ull) return DEBWT_ERANGE;
     c->stage = ST_LOADED;   // the pipeline buffers are reused
+    ENSURE(c, c->keysA, c->n * 8 + 64);
+    ENSURE(c, c->keysB, c->n * 8 + 64);
+    ENSURE(c, c->rs_skew, (c->n / 2048 + 2) * 4);
+    ENSURE(c, c->dk, c->n * 8 + 64);
+    ENSURE(c, c->dstart, c->n * 4 + 64);
     int rc;
     k_extract_keys<<<grid_for(c->n, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
         c->text.as<u64>(), c->sepbits.as<u64>(), c->sep.as<u64>(), c->nrec, c->n, k, 1, c->keysA.as<u64>());

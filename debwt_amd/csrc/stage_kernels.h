@@ -466,6 +466,22 @@ struct LargeBlockF {
     __device__ void emit(u64 q, u32 off, u32 c) const { if (c) large_q[off] = (u32)q; }
 };
 
+// block tables of one key range (local instance / blue indices) -> the context-wide tables with 64-bit offsets
+__global__ void k_append_blocks(const u32 *__restrict__ mi_j0, const u32 *__restrict__ mi_freq,
+                                const u32 *__restrict__ bstart, u64 Q, u64 mbase, u64 bbase,
+                                u64 *__restrict__ blk_j0, u32 *__restrict__ blk_freq, u64 *__restrict__ blk_start) {
+    u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    blk_j0[q] = mbase + mi_j0[q];
+    blk_freq[q] = mi_freq[q];
+    blk_start[q] = bbase + bstart[q];
+}
+// large blocks of a range: local block ids -> context-wide ids
+__global__ void k_offset_u32(u32 *__restrict__ v, u64 n, u32 add) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] += add;
+}
+
 // Node lookup for the text scan (the job of blackTable + BinarySearch_red, src/generateSP.c:53-59,542-566,
 // 725-737): an open-addressing table over the red nodes (load <= 1/2, linear probing so a probe sequence stays
 // inside one 128-byte line) behind a one-bit-per-bin prefilter that fits L2.  A slot carries everything the blue
@@ -473,7 +489,7 @@ struct LargeBlockF {
 // Both tables are indexed by multiplicative hashes of the node, so neighbouring text positions spread evenly.
 struct __attribute__((aligned(16))) HSlot {
     u64 key;    // node<<2 | multiin<<1 | multiout; 0 = empty
-    u32 cur;    // next free blue slot of the node's block (absolute), HCURSOR_SKIP when another shard owns it
+    u32 cur;    // fill cursor of the node's block (see k_build_hash), HCURSOR_SKIP when another shard owns it
     u32 q;      // global block id
 };
 #define HCURSOR_SKIP 0xFFFFFFFFu
@@ -481,7 +497,7 @@ __device__ __forceinline__ u32 red_hash(u64 node, int bits) { return (u32)((node
 __device__ __forceinline__ u32 red_hash2(u64 node, int bits) { return (u32)((node * 0xC2B2AE3D27D4EB4Full) >> (64 - bits)); }
 
 __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__restrict__ red_q,
-                             const u32 *__restrict__ bstart, u32 qbase, u32 Qlocal, int hbits,
+                             const u64 *__restrict__ blk_start, int abs32, u32 qbase, u32 Qlocal, int hbits,
                              HSlot *__restrict__ htab, int pb, u32 *__restrict__ rbits) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
@@ -493,10 +509,12 @@ __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__re
         if (old == 0ull) break;
         h = (h + 1) & mask;
     }
-    // fill cursor of a multi-in node = first blue slot of its block (redPoint analogue, src/INandOut.c:413)
+    // fill cursor of a multi-in node (redPoint analogue, src/INandOut.c:413): the next free blue slot of its block
+    // when all blue slots of the context fit 32 bits (abs32), else the entries placed so far (the block's first
+    // slot is then added from blk_start[q], a 64-bit offset)
     if (v & 2ull) {
         u32 q = red_q[r] - qbase;                                // wraps for blocks before this shard
-        htab[h].cur = q < Qlocal ? bstart[q] : HCURSOR_SKIP;
+        htab[h].cur = q < Qlocal ? (abs32 ? (u32)blk_start[q] : 0u) : HCURSOR_SKIP;
         htab[h].q = red_q[r];                                    // global block id (blue-entry exchange)
     }
     u32 hb = red_hash2(node, pb);
@@ -517,10 +535,10 @@ __device__ __forceinline__ u32 red_lookup(const HSlot *__restrict__ htab, int hb
 
 // rows of the special suffixes: rank among the node instances + own rank (src/INandOut.c:419-439)
 __global__ void k_special_rows(const u64 *__restrict__ sk, u64 M, const u64 *__restrict__ spkey, u64 NS,
-                               u64 *__restrict__ sprow) {
+                               u64 row_base, u64 *__restrict__ sprow) {
     u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= NS) return;
-    sprow[s] = s + upper_bound_dev<u64>(sk, 0, M, (spkey[s] << 2) | 3ull);
+    sprow[s] = row_base + s + upper_bound_dev<u64>(sk, 0, M, (spkey[s] << 2) | 3ull);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -591,7 +609,7 @@ struct SpEmitArgs {
     const u32 *momask; const u32 *mimask;
     u8 *spsym; ulonglong2 *mi_list;
     u64 g0;                    // first group of the slice (the scan arrays are indexed relative to it)
-    u32 sp_base;               // SP symbols emitted by the slices before this one
+    u64 sp_base;               // SP symbols emitted by the slices before this one
 };
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngroups, u64 chunk,
                                                           const u32 *__restrict__ off_mo,
@@ -599,7 +617,8 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
     __shared__ u32 tmp[2 * DEBWT_WAVES];
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < ngroups ? beg + chunk : ngroups;
-    u32 base_mo = off_mo[blockIdx.x] + a.sp_base, base_mi = off_mi[blockIdx.x];
+    u64 base_mo = (u64)off_mo[blockIdx.x] + a.sp_base;
+    u32 base_mi = off_mi[blockIdx.x];
     for (u64 tile = beg; tile < end; tile += DEBWT_BLOCK) {
         u64 g = tile + threadIdx.x;
         u32 mo = 0, mi = 0;
@@ -607,7 +626,8 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
         g += a.g0;
         u32 val[2] = {(u32)__popc(mo), (u32)__popc(mi)}, ex[2], tot[2];
         block_scan_excl_vec<2>(val, ex, tot, tmp);
-        u32 off = base_mo + ex[0], omi = base_mi + ex[1];
+        u64 off = base_mo + ex[0];
+        u32 omi = base_mi + ex[1];
         u32 all = mo | mi;
         u64 w0 = 0, w1 = 0, wp = 0, sbp = 0;
         if (mi) {                                              // the group's text words, the word and separators before it
@@ -624,7 +644,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
                 if (i == 0) pred = 5;
                 else if ((sbp >> t) & 1ull) pred = 4;          // bit t of sbp = position i-1
                 else pred = t ? ((w0 >> (2 * (32 - t))) & 3ull) : (wp & 3ull);
-                a.mi_list[omi++] = make_ulonglong2(win >> (64 - 2 * a.K), ((u64)off << 4) | pred);
+                a.mi_list[omi++] = make_ulonglong2(win >> (64 - 2 * a.K), (off << 4) | pred);
             }
             if ((mo >> t) & 1u) {
                 // the symbol K ahead; the separator itself when it follows the window (src/generateSP.c:626-660)
@@ -640,17 +660,27 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
 
 // one thread per multi-in position: node -> table slot -> slot in the block through the block's cursor, which
 // lives in the same table line (the reference's per-red-entry lock, src/generateSP.c:662-680)
+template <int ABS32>
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const ulonglong2 *__restrict__ mi_list, u64 B,
                                                             HSlot *__restrict__ htab, int hbits,
+                                                            const u64 *__restrict__ blk_start, u32 qbase,
                                                             u64 *__restrict__ blue) {
     u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     ulonglong2 it = mi_list[b];
     u32 fl;
     u32 h = red_lookup(htab, hbits, it.x, &fl);
-    if (h == 0xFFFFFFFFu || htab[h].cur == HCURSOR_SKIP) return;           // block owned by another shard
-    u32 slot = atomicAdd(&htab[h].cur, 1u);                                 // absolute slot: starts at the block start
-    blue[slot] = it.y;                                                      // pred | spIndex << 4 (:666-672)
+    if (h == 0xFFFFFFFFu) return;
+    if (ABS32) {
+        if (htab[h].cur == HCURSOR_SKIP) return;                            // block owned by another shard
+        u32 slot = atomicAdd(&htab[h].cur, 1u);                             // absolute slot: starts at the block start
+        blue[slot] = it.y;                                                  // pred | spIndex << 4 (:666-672)
+    } else {
+        const uint2 cq = *reinterpret_cast<const uint2 *>(&htab[h].cur);    // cursor and block id: one 8-byte load
+        if (cq.x == HCURSOR_SKIP) return;
+        u32 slot = atomicAdd(&htab[h].cur, 1u);
+        blue[blk_start[cq.y - qbase] + slot] = it.y;
+    }
 }
 
 // sharded build: a multi-in position of this shard's text slice -> (global block id << 36 | spIndex << 4 | pred),
@@ -668,6 +698,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route(const ulonglong2 *__
 }
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_place(const u64 *__restrict__ ent, u64 count, u32 qbase,
                                                              u32 Qlocal, u32 *__restrict__ qcursor,
+                                                             const u64 *__restrict__ blk_start,
                                                              u64 *__restrict__ blue) {
     u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= count) return;
@@ -675,7 +706,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_place(const u64 *__restric
     u32 q = (u32)(e >> 36) - qbase;
     if (q >= Qlocal) return;                                                // misrouted entry: never index outside
     u32 slot = atomicAdd(&qcursor[q], 1u);
-    blue[slot] = e & 0xFFFFFFFFFull;                                        // pred | spIndex << 4
+    blue[blk_start[q] + slot] = e & 0xFFFFFFFFFull;                         // pred | spIndex << 4
 }
 
 // SP symbols -> 3 bits per symbol in one MSB-first bit stream (symbol s at stream bits [3s, 3s+3)); a window
@@ -732,8 +763,8 @@ __device__ __forceinline__ bool sp_less_deep(const u64 *__restrict__ spn, u64 S,
 // comparison.  A workgroup of NT threads holds the block in LDS; each round is a bitonic network on
 // (group, window) pairs, a prefix-max for the new group ids and LDS atomics for the group census.
 template <int NT, int CAP>
-__global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, const u32 *__restrict__ bstart,
-                                                     const u32 *__restrict__ mi_freq, const u32 *__restrict__ mi_j0,
+__global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, const u64 *__restrict__ bstart,
+                                                     const u32 *__restrict__ mi_freq, const u64 *__restrict__ mi_j0,
                                                      u32 Q, u32 lo_excl, const u64 *__restrict__ spn, u64 S,
                                                      u8 *__restrict__ mchar) {
     __shared__ u64 se[CAP];     // entries
@@ -751,7 +782,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
         if (m <= lo_excl || m > CAP) continue;
         u32 maxg = m;
         const u64 b0 = bstart[q];
-        const u32 j0 = mi_j0[q];
+        const u64 j0 = mi_j0[q];
         u32 P = 2;
         while (P < m) P <<= 1;
         u32 mask = 0;
@@ -924,13 +955,13 @@ __global__ void k_large_step(u64 *__restrict__ k0, u64 *__restrict__ en, u64 P, 
     else lt = sp_less_deep(spn, S, eb, ea);
     if (lt == up) { k0[i] = kb; k0[l] = ka; en[i] = eb; en[l] = ea; }
 }
-__global__ void k_large_store(u64 *__restrict__ blue, u64 b0, u32 m, u32 j0, const u64 *__restrict__ en,
+__global__ void k_large_store(u64 *__restrict__ blue, u64 b0, u32 m, u64 j0, const u64 *__restrict__ en,
                               u8 *__restrict__ mchar) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     u64 e = en[t];
     blue[b0 + t] = e;
-    mchar[(u64)j0 + t] = (u8)(e & 15);
+    mchar[j0 + t] = (u8)(e & 15);
 }
 
 // ---------------------------------------------------------------------------------------------------

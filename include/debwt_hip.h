@@ -29,7 +29,7 @@ extern "C" {
 #define DEBWT_ENOMEM (-2)   /* device or host allocation failed */
 #define DEBWT_EDEVICE (-3)  /* HIP runtime error (see debwt_last_error) */
 #define DEBWT_ESTATE (-4)   /* stage called out of order */
-#define DEBWT_ERANGE (-5)   /* input exceeds a capacity of this build (n_main or S >= 2^32) */
+#define DEBWT_ERANGE (-5)   /* input exceeds a capacity of this build (see debwt_last_error) */
 #define DEBWT_EINTERNAL (-6)/* consistency check failed */
 
 typedef struct debwt_ctx debwt_ctx;
@@ -79,6 +79,13 @@ int debwt_load_text(debwt_ctx *ctx, const uint64_t *packed, uint64_t n, const ui
  * lower case ACGT only (src/main.c:18-23), every record > 32 bases (src/collect#$.c:41-45).
  * Packs on the host, then behaves like debwt_load_text (the packed copy is owned by ctx). */
 int debwt_load_ascii(debwt_ctx *ctx, const char *seq, const uint64_t *reclen, uint64_t nrec);
+
+/* Texts whose node instances (one 8-byte key per base) do not fit HBM at once, or number 2^32 or more, are built
+ * in key ranges: prefix ranges of the k-mer space holding at most `max_instances` keys each, sorted and classified
+ * one after the other over the resident 2-bit text -- the single-GPU form of SURVEY 8e's bucket sharding (the
+ * reference's analogue is its per-thread bucket segments, src/mySort.c:98-110).  Default 2^31; tests lower it to
+ * drive the multi-range path on small inputs.  The result does not depend on it. */
+int debwt_set_range_cap(debwt_ctx *ctx, uint64_t max_instances);
 
 /* ---- stage entry points, to be called in this order after a load ------------------------------ */
 

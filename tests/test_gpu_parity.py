@@ -270,3 +270,69 @@ def test_stage_order_and_errors(api):
     d.load_ascii(["ACGT" * 30 + "TTGACCA" * 9, "acgtacgttgca" * 11])
     d.build()
     d.close()
+
+
+# ---- key ranges: texts whose node instances exceed the range cap are sorted and classified range by range ------
+
+@pytest.mark.parametrize("entry", [e for e in MANIFEST if e["k"] in (12, 32)], ids=golden_id)
+def test_multi_range_build_matches_reference_golden(api, entry):
+    """The same golden vectors with the key space cut into many prefix ranges (cap = 4096 instances)."""
+    recs = golden_records(entry)
+    d = api.DeBWT(k=entry["k"])
+    d.set_range_cap(4096)
+    d.load_records(recs)
+    d.build()
+    words, hrows, drow = d.fetch()
+    st = d.stats()
+    sha = entry["sha256"]
+    assert _sha(words) == sha["bwt"] and _sha(hrows) == sha["hash"]
+    assert _sha(np.array([drow], dtype=np.uint64)) == sha["dollar"]
+    c = entry["counters"]
+    assert st["case3num"] == c["case3num"] and st["blue_bound_num"] == c["blueBoundNum"]
+    assert st["red_capacity"] == c["redCapacity"] and st["blue_capacity"] == c["blueCapacity"]
+    d.close()
+
+
+@pytest.mark.parametrize("cap", [1 << 20, 3_000_000, 1 << 23])
+def test_multi_range_equals_single_range_midsize(api, cap):
+    from debwt_amd import synth
+    recs = synth.make_workload("pan_16M_4")
+    _, (w1, h1, d1), st1 = _run(api, recs, 32)
+    d = api.DeBWT(k=32, tune=16 if cap == 3_000_000 else 0)      # 16: block-relative fill cursors + 64-bit block starts
+    d.set_range_cap(cap)
+    d.load_records(recs)
+    d.build()
+    w2, h2, d2 = d.fetch()
+    st2 = d.stats()
+    assert np.array_equal(w1, w2) and np.array_equal(h1, h2) and d1 == d2
+    for key in ("red_capacity", "blue_capacity", "blue_bound_num", "sp_len", "distinct_keys", "blue_large_blocks"):
+        assert st1[key] == st2[key], key
+    # stage-wise arrays that do not depend on the ranges
+    for which in (api.ARR_RED, api.ARR_SP_SYMBOLS, api.ARR_BLUE_BOUND, api.ARR_CASE3_BOUND):
+        assert np.array_equal(_run(api, recs, 32)[0].fetch_array(which), d.fetch_array(which)), which
+    with pytest.raises(api.DebwtError):
+        d.fetch_array(api.ARR_SORTED_KEYS)           # not kept by a multi-range build
+    d.close()
+
+
+def test_multi_range_with_large_blocks_and_many_records(api, oracle):
+    """Blocks above the LDS capacity and special suffixes spread over several ranges."""
+    rng = np.random.default_rng(77)
+    units = [rng.integers(0, 4, size=40).astype(np.uint8) for _ in range(3)]
+    recs = []
+    for i in range(30):
+        parts = []
+        for j in range(300):                                 # 9000 copies of each unit over the collection
+            parts.append(units[j % 3])
+            parts.append(rng.integers(0, 4, size=int(rng.integers(3, 9))).astype(np.uint8))
+        recs.append(np.concatenate(parts))
+    d = api.DeBWT(k=20)
+    d.set_range_cap(20000)
+    d.load_records(recs)
+    d.build()
+    words, hrows, drow = d.fetch()
+    st = d.stats()
+    ow, oh, od, ost = oracle.build_bwt(oracle.sym_from_codes(recs), 20)
+    assert st["blue_large_blocks"] > 0
+    assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
+    d.close()
