@@ -61,7 +61,7 @@ struct debwt_ctx {
     // Q, B, nlarge and blk_*/facts_acc/large_q/mchar/sprow cover the whole context with 64-bit offsets.
     struct KeyRange { u64 key_lo, key_hi, M, Mbase, Q, qbase, B, Bbase, s0, s1; };
     std::vector<KeyRange> ranges;
-    u64 range_cap = 1ull << 31;
+    u64 range_cap = 0;          // 0: from the free HBM at the first build (plan_ranges)
     u64 Mctx = 0;               // node instances of this context (sum over its ranges)
     u64 nfacts_acc = 0;         // facts accumulated over the ranges
     bool local_done = false;    // classify_local already ran per range (multi-range build)
@@ -358,7 +358,22 @@ static int plan_ranges(debwt_ctx *c) {
     c->ranges.clear();
     c->local_done = false;
     debwt_ctx::KeyRange r{};
-    if (c->shard_world > 1 || c->keys_imported || c->Mfull <= c->range_cap) {
+    u64 range_cap = c->range_cap;
+    if (!range_cap) {
+        // as many keys per range as HBM allows: ~30 bytes per key of range workspace (two key buffers, distinct keys,
+        // first instances, classification bytes) next to what the later stages hold for the whole text
+        // (~4 bytes per position: row symbols, SP code, flag masks, blue entries, BWT)
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        const u64 held = c->keysA.cap + c->keysB.cap + c->dk.cap + c->dstart.cap + c->pflag.cap + c->mchar.cap +
+                         c->spsym.cap + c->momask.cap + c->mimask.cap + c->blue.cap + c->mi_list.cap;   // reused by this build
+        const u64 avail = free_b + held;
+        const u64 later = 4 * c->n + (8ull << 30);
+        range_cap = avail > later + (30ull << 28) ? (avail - later) / 30 : (1ull << 28);
+        range_cap = std::min<u64>(range_cap, 0xFFFFFFF0ull - (1ull << 20));
+        if (range_cap >= c->Mfull && c->Mfull < 0xFFFFFFF0ull) range_cap = c->Mfull;
+    }
+    if (c->shard_world > 1 || c->keys_imported || c->Mfull <= range_cap) {
         if (c->M >= 0xFFFFFFF0ull) { c->err = "a key range must hold fewer than 2^32 node instances"; return DEBWT_ERANGE; }
         r.key_lo = c->key_lo; r.key_hi = c->key_hi; r.M = c->M;
         c->ranges.push_back(r);
@@ -373,7 +388,7 @@ static int plan_ranges(debwt_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(hist.data(), c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
     int rc = sync_check(c);
     if (rc) return rc;
-    const u64 cap = std::min<u64>(c->range_cap, 0xFFFFFFF0ull - 1);
+    const u64 cap = std::min<u64>(range_cap, 0xFFFFFFF0ull - 1);
     const u64 P = (c->Mfull + cap - 1) / cap;
     const u64 per = (c->Mfull + P - 1) / P;
     const u64 limit = std::min(cap, per + per / 16);            // near-equal ranges, never above the cap
@@ -631,8 +646,6 @@ extern "C" int debwt_classify(debwt_ctx *c) {
 // node table + prefilter from the red table; flag masks sized for the whole text
 static int sp_prepare(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-    // S <= n; the SP symbol buffer is sized for the worst case once
-    ENSURE(c, c->spsym, c->n + 64);
     const u64 ngroups = (c->n + 31) >> 5;
     ENSURE(c, c->momask, ngroups * 4 + 64);
     ENSURE(c, c->mimask, ngroups * 4 + 64);
@@ -683,6 +696,8 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
 static int sp_emit(debwt_ctx *c, u64 sp_off) {
     const u64 ng = c->g1 - c->g0;
     c->sp_off = sp_off;
+    // the SP symbol buffer grows with the slices (S is ~0.1 n, the worst case n)
+    ENSURE_KEEP(c, c->spsym, sp_off + c->S_local + 64, c->shard_world > 1 ? 0 : sp_off);
     ENSURE(c, c->mi_list, c->B_slice * 16 + 64);
     if (ng) {
         SpEmitArgs ea{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->momask.as<u32>(), c->mimask.as<u32>(),
@@ -1020,6 +1035,7 @@ extern "C" int debwt_shard_sp_import(debwt_ctx *c, const uint8_t *d_src, uint64_
     if (!c || (!d_src && sp_total)) return DEBWT_EINVAL;
     if (c->stage < ST_CLASSIFIED || sp_total > c->n) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    ENSURE(c, c->spsym, sp_total + 64);
     if (sp_total) HIPCHK(c, hipMemcpyAsync(c->spsym.p, d_src, sp_total, hipMemcpyDeviceToDevice, c->stream));
     int rc = sp_finish(c, sp_total);
     if (rc) return rc;
@@ -1031,6 +1047,10 @@ extern "C" int debwt_shard_blue_route(debwt_ctx *c, const uint32_t *first_block_
     // blue entries of this shard's text slice, grouped by the shard that owns their block
     if (!c || !first_block_of_shard || !d_out || !offs) return DEBWT_EINVAL;
     if (c->stage < ST_CLASSIFIED || capacity < c->B_slice) return DEBWT_ESTATE;
+    if (first_block_of_shard[c->shard_world] >= (1u << 28) || c->sp_off + c->S_local >= (1ull << 33)) {
+        c->err = "routed blue entries hold 28-bit block ids and 33-bit SP indices";
+        return DEBWT_ERANGE;
+    }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const u32 w = (u32)c->shard_world;
     ENSURE(c, c->qbounds, (w + 1) * 4);

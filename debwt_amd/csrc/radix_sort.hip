@@ -95,6 +95,42 @@ __device__ __forceinline__ bool rs_staged_key(const TextKeySrc &ts, const TextSt
     return true;
 }
 
+// N consecutive tile items from idx0 on: the 64 symbols that start one symbol before the first item and the
+// separator bits are fetched once, the window rolls (every shift is a compile-time constant), so a key costs a
+// few ALU operations instead of five LDS reads.  Returns the mask of items that are keys.
+template <int N>
+__device__ __forceinline__ u32 rs_staged_keys(const TextKeySrc &ts, const TextStage &st, u64 idx0, u64 end, u64 (&key)[N]) {
+    static_assert(N <= 16, "the rolled window holds 64 symbols");
+    u32 vmask = 0;
+#pragma unroll
+    for (int r = 0; r < N; r++) key[r] = ~0ull;
+    if (idx0 >= end) return 0;
+    const u64 p0 = ts.pos0 + idx0;
+    const u64 rel = p0 ? p0 - 1 - st.tpos : 0;
+    const u32 w = (u32)(rel >> 5), sh = (u32)(rel & 31) << 1;
+    const u64 a0 = st.stext[w], a1 = st.stext[w + 1], a2 = st.stext[w + 2];
+    u64 A = sh ? (a0 << sh) | (a1 >> (64 - sh)) : a0;            // symbols p0-1 .. p0+30
+    u64 B = sh ? (a1 << sh) | (a2 >> (64 - sh)) : a1;            // symbols p0+31 .. p0+62
+    if (p0 == 0) {                                               // the text's first position: the 'T' that stands
+        B = (A << 62) | (B >> 2);                                // at separators goes before it (fake pred 3)
+        A = (3ull << 62) | (A >> 2);
+    }
+    const u64 S = sep_window(st.ssep, p0 - st.spos);             // bit r: separator at p0 + r
+    const u64 kmask = (1ull << ts.K) - 1ull;
+    const int nsh = 64 - 2 * ts.K;
+#pragma unroll
+    for (int r = 0; r < N; r++) {
+        const int j = r + 1;                                      // item r starts at symbol j of (A, B)
+        if (idx0 + r >= end || ((S >> r) & kmask)) continue;      // behind the chunk / window holds a separator
+        const u64 win = (A << (2 * j)) | (B >> (64 - 2 * j));
+        const u64 k = ((win >> nsh) << 2) | ((A >> (64 - 2 * j)) & 3ull);
+        if (k < ts.key_lo || (ts.key_hi && k >= ts.key_hi)) continue;   // not this shard's prefix range
+        key[r] = k;
+        vmask |= 1u << r;
+    }
+    return vmask;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // algo 1
 
@@ -125,12 +161,11 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict
         TextStage st{stext, ssep, 0, 0};
         for (u64 tile = beg; tile < end; tile += RS_TILE) {
             rs_stage_text(ts, ts.pos0 + tile, st);
-#pragma unroll 4
-            for (u32 r = 0; r < RS_ITEMS; r++) {
-                u64 k;
-                if (rs_staged_key(ts, st, tile + (u64)r * RS_BLOCK + threadIdx.x, end, &k))
-                    atomicAdd(&h[rs_digit<!AUX>(dg, k)], 1u);
-            }
+            u64 k[RS_ITEMS];
+            u32 vm = rs_staged_keys<RS_ITEMS>(ts, st, tile + (u64)threadIdx.x * RS_ITEMS, end, k);
+#pragma unroll
+            for (u32 r = 0; r < RS_ITEMS; r++)
+                if ((vm >> r) & 1u) atomicAdd(&h[rs_digit<!AUX>(dg, k[r])], 1u);
         }
     }
     __syncthreads();
@@ -196,19 +231,12 @@ __device__ __forceinline__ u32 rs_load_tile(const u64 *__restrict__ in, const Te
     }
     return vmask;
 }
-// the same tile layout with the keys computed from the staged text words
+// a tile of keys computed from the staged text words
 __device__ __forceinline__ u32 rs_load_tile_text(const TextKeySrc &ts, TextStage &st, u64 tile, u64 end,
                                                  u64 (&key)[SC_ITEMS]) {
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const u64 wbase = tile + (u64)w * (64u * SC_ITEMS);
+    // a lane takes SC_ITEMS consecutive positions (the first pass may rank the keys in any order)
     rs_stage_text(ts, ts.pos0 + tile, st);
-    u32 vmask = 0;
-#pragma unroll
-    for (int r = 0; r < SC_ITEMS; r++) {
-        u64 idx = wbase + (u64)r * 64u + lane;
-        if (rs_staged_key(ts, st, idx, end, &key[r])) vmask |= 1u << r;
-    }
-    return vmask;
+    return rs_staged_keys<SC_ITEMS>(ts, st, tile + (u64)threadIdx.x * SC_ITEMS, end, key);
 }
 
 // per-digit flush parameters of a tile

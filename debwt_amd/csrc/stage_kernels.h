@@ -683,8 +683,9 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const ulonglong2 *__r
     }
 }
 
-// sharded build: a multi-in position of this shard's text slice -> (global block id << 36 | spIndex << 4 | pred),
-// to be sent to the shard that owns the block; and the owner's placement of the entries it received
+// sharded build: a multi-in position of this shard's text slice -> (global block id << 36 | spIndex << 3 | pred),
+// to be sent to the shard that owns the block (28 + 33 + 3 bits: Q < 2^28 blocks, S < 2^33 SP symbols, checked by
+// the host); and the owner's placement of the entries it received
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route(const ulonglong2 *__restrict__ mi_list, u64 B,
                                                              const HSlot *__restrict__ htab, int hbits,
                                                              u64 *__restrict__ out) {
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route(const ulonglong2 *__
     u32 fl;
     u32 h = red_lookup(htab, hbits, it.x, &fl);
     u64 q = h == 0xFFFFFFFFu ? 0xFFFFFFFull : (u64)htab[h].q;
-    out[b] = (q << 36) | it.y;
+    out[b] = (q << 36) | ((it.y >> 4) << 3) | (it.y & 7ull);
 }
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_place(const u64 *__restrict__ ent, u64 count, u32 qbase,
                                                              u32 Qlocal, u32 *__restrict__ qcursor,
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_place(const u64 *__restric
     u32 q = (u32)(e >> 36) - qbase;
     if (q >= Qlocal) return;                                                // misrouted entry: never index outside
     u32 slot = atomicAdd(&qcursor[q], 1u);
-    blue[blk_start[q] + slot] = e & 0xFFFFFFFFFull;                         // pred | spIndex << 4
+    blue[blk_start[q] + slot] = (e & 7ull) | (((e >> 3) & 0x1FFFFFFFFull) << 4);   // pred | spIndex << 4
 }
 
 // SP symbols -> 3 bits per symbol in one MSB-first bit stream (symbol s at stream bits [3s, 3s+3)); a window

@@ -1,5 +1,5 @@
 """Texts beyond 2^32 positions on ONE MI355X: the key space is built in prefix ranges over the resident text.
-python scripts/gpu_bign.py [total_bases=5000000000] [records=24] [--cap N]
+python scripts/gpu_bign.py [total_bases=5000000000] [records=24] [--cap N] [--pan]
 Checks: k-invariance (k=32 vs k=24 give the identical BWT), '#' rows ascending, symbol census = text census."""
 import hashlib, sys, time
 sys.path.insert(0, ".")
@@ -10,7 +10,10 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 total = int(args[0]) if args else 5_000_000_000
 nrec = int(args[1]) if len(args) > 1 else 24
 cap = int(sys.argv[sys.argv.index("--cap") + 1]) if "--cap" in sys.argv else None
-t0 = time.time(); recs = synth.chromosomes(total, nrec); tg = time.time() - t0
+if "--pan" in sys.argv:      # SURVEY 8d distribution P: nrec genomes = one base genome each with independent SNPs at 1e-3
+    t0 = time.time(); recs = synth.pan_genome(total // nrec, nrec); tg = time.time() - t0
+else:
+    t0 = time.time(); recs = synth.chromosomes(total, nrec); tg = time.time() - t0
 n = sum(len(r) for r in recs) + len(recs)
 print(f"generated n={n} ({n / 2**32:.2f} x 2^32) in {tg:.0f}s", flush=True)
 t0 = time.time(); words, n2, sep = api.pack_records(recs); tp = time.time() - t0
