@@ -4,8 +4,7 @@
  *   deBWT -o OUT [-t T] [-k K] [-j DIR] [--device D] INPUT.fa[.gz]
  *
  * Same contract as /root/reference/src/main.c:25-53,175-186: options are `flag value` pairs, INPUT last;
- * -k 12..32 (default 32); -t parsed and validated (default 8) but unused -- there are no host threads in
- * this path; -j accepted and ignored (no Jellyfish); OUT is probed by create+remove before any work
+ * -k 12..32 (default 32); -t (default 8) = host threads of the FASTA ingest; -j accepted and ignored (no Jellyfish); OUT is probed by create+remove before any work
  * (src/main.c:55-58); exit status 0 on success, 1 with a message on stderr otherwise.  Output files OUT,
  * OUT.#, OUT.$ are those of src/insertCase3.c:115-131.
  */
@@ -14,7 +13,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
-#include <zlib.h>
 
 #include "../include/debwt_hip.h"
 
@@ -24,7 +22,7 @@ static void usage(void) {
                     "Please make sure your sequence don't contain any uncertain characters like 'N'\n"
                     "options:\n"
                     "-o: output bwt file(binary)\n"
-                    "-t (optional): maximum thread number(default 8; unused by the GPU path)\n"
+                    "-t (optional): maximum thread number(default 8; host threads of the FASTA ingest)\n"
                     "-k (optional): k-mer length (from 12 to 32, default 32)\n"
                     "-j (optional): jellyfish directory (accepted, ignored)\n"
                     "--device (optional): GPU ordinal (default 0)\n"
@@ -35,40 +33,6 @@ static double now(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec + ts.tv_nsec * 1e-9;
-}
-
-/* FASTA -> concatenated sequence + record lengths (the reference reads through kseq.h + zlib,
- * src/collect#$.c:34-90) */
-static int read_fasta(const char *path, char **seq_out, uint64_t **len_out, uint64_t *nrec_out) {
-    gzFile f = gzopen(path, "rb");
-    if (!f) { fprintf(stderr, "can not open ref file\n"); return -1; }
-    gzbuffer(f, 1 << 20);
-    size_t cap = 1 << 24, len = 0, rcap = 64, nrec = 0;
-    char *seq = malloc(cap);
-    uint64_t *rl = malloc(rcap * sizeof *rl);
-    static char buf[1 << 20];
-    int in_header = 0, r;
-    if (!seq || !rl) return -1;
-    while ((r = gzread(f, buf, sizeof buf)) > 0) {
-        for (int i = 0; i < r; i++) {
-            char c = buf[i];
-            if (in_header) { if (c == '\n') in_header = 0; continue; }
-            if (c == '>') {
-                in_header = 1;
-                if (nrec == rcap) { rcap *= 2; rl = realloc(rl, rcap * sizeof *rl); if (!rl) return -1; }
-                rl[nrec++] = 0;
-                continue;
-            }
-            if (c == '\n' || c == '\r' || c == ' ' || c == '\t') continue;
-            if (!nrec) { fprintf(stderr, "sequence before the first header\n"); return -1; }
-            if (len == cap) { cap *= 2; seq = realloc(seq, cap); if (!seq) return -1; }
-            seq[len++] = c;
-            rl[nrec - 1]++;
-        }
-    }
-    gzclose(f);
-    *seq_out = seq; *len_out = rl; *nrec_out = nrec;
-    return 0;
 }
 
 static int write_file(const char *path, const void *p, size_t bytes) {
@@ -104,29 +68,24 @@ int main(int argc, char **argv) {
 
     fprintf(stderr, "run deBWT (MI355X path): sequence file %s, output %s, k-mer length %d\n", source, obj, k);
     double t0 = now();
-    char *seq; uint64_t *reclen, nrec;
-    if (read_fasta(source, &seq, &reclen, &nrec) || !nrec) return 1;
-    uint64_t n = nrec;
-    for (uint64_t r = 0; r < nrec; r++) {
-        if (reclen[r] <= 32) { fprintf(stderr, "Length <= 32!\n"); return 1; }   /* src/collect#$.c:41-45 */
-        n += reclen[r];
-    }
-    double t1 = now();
     debwt_config cfg = {k, device, 0, 0};
     debwt_ctx *ctx = NULL;
     int rc = debwt_create(&cfg, &ctx);
     if (rc) { fprintf(stderr, "debwt_create: %s\n", debwt_strerror(rc)); return 1; }
-    rc = debwt_load_ascii(ctx, seq, reclen, nrec);
+    double t1 = now();
+    /* the reference's collect (src/collect#$.c:34-90): here `threads` host threads parse and pack the file */
+    rc = debwt_load_fasta(ctx, source, (int)(threads > 256 ? 256 : threads));
     if (rc) {
-        fprintf(stderr, "load: %s %s (sequence must be ACGT only, records > 32 bases)\n", debwt_strerror(rc),
-                debwt_last_error(ctx));
+        fprintf(stderr, "%s (sequence must be ACGT only, records > 32 bases)\n", debwt_last_error(ctx));
         return 1;
     }
-    free(seq);
     double t2 = now();
     rc = debwt_build(ctx);
     if (rc) { fprintf(stderr, "build: %s %s\n", debwt_strerror(rc), debwt_last_error(ctx)); return 1; }
     double t3 = now();
+    debwt_stats st;
+    debwt_get_stats(ctx, &st);
+    const uint64_t n = st.n, nrec = st.nrec;
     size_t nw = (size_t)((n + 31) >> 5);
     uint64_t *bwt = malloc(nw * 8), *hash_rows = malloc((nrec ? nrec : 1) * 8), dollar = 0;
     if (!bwt || !hash_rows) return 1;
@@ -140,18 +99,16 @@ int main(int argc, char **argv) {
     memcpy(p + ol, ".$", 3);
     if (write_file(p, &dollar, 8)) return 1;                               /* :127-131 */
     double t4 = now();
-    debwt_stats st;
-    debwt_get_stats(ctx, &st);
     printf("BWTLEN=%lu\n", (unsigned long)st.n);                           /* src/collect#$.c:59 */
     printf("the case3num is %lu\nthe blueBoundNum is %lu\nthe redCapacity is %lu\nthe blueCapacity is %lu\n",
            (unsigned long)st.case3num, (unsigned long)st.blue_bound_num, (unsigned long)st.red_capacity,
            (unsigned long)st.blue_capacity);                               /* src/generateSP.c:28-31 */
-    printf("read %.3f s, load %.3f s, build %.3f s (device %.3f ms: extract %.2f sort %.2f classify %.2f "
+    printf("device init %.3f s, read+pack+load (%ld threads) %.3f s, build %.3f s (device %.3f ms: extract %.2f sort %.2f classify %.2f "
            "SP %.2f blue %.2f assemble %.2f), write %.3f s\n",
-           t1 - t0, t2 - t1, t3 - t2, st.ms_total, st.ms_extract, st.ms_sort, st.ms_classify, st.ms_sp, st.ms_blue,
+           t1 - t0, threads, t2 - t1, t3 - t2, st.ms_total, st.ms_extract, st.ms_sort, st.ms_classify, st.ms_sp, st.ms_blue,
            st.ms_assemble, t4 - t3);
     fprintf(stderr, "success output bwt!\n");
     debwt_destroy(ctx);
-    free(bwt); free(hash_rows); free(reclen); free(p);
+    free(bwt); free(hash_rows); free(p);
     return 0;
 }

@@ -14,6 +14,12 @@ class DebwtConfig(ctypes.Structure):
                 ("reserved", ctypes.c_int)]
 
 
+class DebwtPackedText(ctypes.Structure):
+    _fields_ = [("words", ctypes.POINTER(ctypes.c_uint64)), ("nwords", ctypes.c_uint64), ("n", ctypes.c_uint64),
+                ("sep", ctypes.POINTER(ctypes.c_uint64)), ("nrec", ctypes.c_uint64),
+                ("seconds_read", ctypes.c_double), ("seconds_pack", ctypes.c_double)]
+
+
 class DebwtStats(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_uint64) for n in (
         "n", "nrec", "red_capacity", "blue_capacity", "blue_bound_num", "case3num", "sp_len",
@@ -37,7 +43,7 @@ SYMBOLS = [
     "debwt_shard_begin", "debwt_shard_histogram", "debwt_shard_set_range", "debwt_shard_classify_local",
     "debwt_shard_facts_export", "debwt_shard_classify_global", "debwt_shard_info", "debwt_shard_fetch",
     "debwt_shard_partition_keys", "debwt_shard_import_keys", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
-    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap",
+    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta",
 ]
 
 
@@ -123,6 +129,13 @@ def lib():
     L.debwt_shard_info.argtypes = [vp, u64p, u64p, u64p]
     L.debwt_shard_fetch.restype = ctypes.c_int
     L.debwt_shard_fetch.argtypes = [vp, u64p, u64p, u64p]
+    L.debwt_pack_fasta.restype = ctypes.c_int
+    L.debwt_pack_fasta.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(DebwtPackedText), ctypes.c_char_p,
+                                   ctypes.c_size_t]
+    L.debwt_free_packed.restype = None
+    L.debwt_free_packed.argtypes = [ctypes.POINTER(DebwtPackedText)]
+    L.debwt_load_fasta.restype = ctypes.c_int
+    L.debwt_load_fasta.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
     L.debwt_set_range_cap.restype = ctypes.c_int
     L.debwt_set_range_cap.argtypes = [vp, ctypes.c_uint64]
     _lib = L

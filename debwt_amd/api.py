@@ -99,6 +99,12 @@ class DeBWT:
         self._chk(self._L.debwt_load_ascii(self._h, b"".join(recs), _p64(lens), len(recs)))
         self.n, self.nrec = int(lens.sum()) + len(recs), len(recs)
 
+    def load_fasta(self, path, threads=8):
+        """FASTA (plain or gzip) parsed and packed by `threads` host threads, then loaded."""
+        self._chk(self._L.debwt_load_fasta(self._h, str(path).encode(), int(threads)))
+        st = self.stats()
+        self.n, self.nrec = st["n"], st["nrec"]
+
     def set_range_cap(self, max_instances):
         """Largest number of node instances sorted in one go; larger texts are built in k-mer-prefix ranges."""
         self._chk(self._L.debwt_set_range_cap(self._h, int(max_instances)))
@@ -184,3 +190,19 @@ def write_outputs(path, words, hash_rows, dollar_row):
     np.ascontiguousarray(words, dtype=np.uint64).tofile(path)
     np.ascontiguousarray(hash_rows, dtype=np.uint64).tofile(path + ".#")
     np.array([dollar_row], dtype=np.uint64).tofile(path + ".$")
+
+
+def pack_fasta(path, threads=8):
+    """Host-only: (words, n, sep, seconds_read, seconds_pack) of a FASTA file in the reference's 2-bit layout."""
+    L = _lib.lib()
+    pt = _lib.DebwtPackedText()
+    err = ctypes.create_string_buffer(256)
+    rc = L.debwt_pack_fasta(str(path).encode(), int(threads), ctypes.byref(pt), err, 256)
+    if rc:
+        raise DebwtError(rc, err.value.decode())
+    try:
+        words = np.ctypeslib.as_array(pt.words, shape=(pt.nwords,)).copy()
+        sep = np.ctypeslib.as_array(pt.sep, shape=(pt.nrec,)).copy()
+        return words, int(pt.n), sep, pt.seconds_read, pt.seconds_pack
+    finally:
+        L.debwt_free_packed(ctypes.byref(pt))

@@ -17,6 +17,7 @@
 
 #include "radix_sort.h"
 #include "special_host.h"
+#include "fasta_host.h"
 #include "stage_kernels.h"
 
 namespace {
@@ -311,6 +312,27 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     memset(&c->st, 0, sizeof c->st);
     c->st.n = n; c->st.nrec = nrec; c->st.n_main = M;
     return DEBWT_OK;
+}
+
+static_assert(sizeof(debwt_packed_text) == sizeof(PackedText), "C ABI mirror of PackedText");
+
+extern "C" int debwt_pack_fasta(const char *path, int threads, debwt_packed_text *out, char *errbuf, size_t errlen) {
+    if (!path || !out) return DEBWT_EINVAL;
+    memset(out, 0, sizeof *out);
+    return pack_fasta_file(path, threads, reinterpret_cast<PackedText *>(out), errbuf, errlen) ? DEBWT_EINVAL : DEBWT_OK;
+}
+extern "C" void debwt_free_packed(debwt_packed_text *p) { free_packed_text(reinterpret_cast<PackedText *>(p)); }
+
+extern "C" int debwt_load_fasta(debwt_ctx *c, const char *path, int threads) {
+    if (!c || !path) return DEBWT_EINVAL;
+    PackedText pt{};
+    char msg[256] = "";
+    if (pack_fasta_file(path, threads, &pt, msg, sizeof msg)) { c->err = msg; return DEBWT_EINVAL; }
+    c->own_text.assign(pt.words, pt.words + pt.nwords);
+    std::vector<uint64_t> sep(pt.sep, pt.sep + pt.nrec);
+    const uint64_t n = pt.n;
+    free_packed_text(&pt);
+    return debwt_load_text(c, c->own_text.data(), n, sep.data(), sep.size());
 }
 
 extern "C" int debwt_set_range_cap(debwt_ctx *c, uint64_t max_instances) {

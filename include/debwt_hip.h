@@ -80,6 +80,23 @@ int debwt_load_text(debwt_ctx *ctx, const uint64_t *packed, uint64_t n, const ui
  * Packs on the host, then behaves like debwt_load_text (the packed copy is owned by ctx). */
 int debwt_load_ascii(debwt_ctx *ctx, const char *seq, const uint64_t *reclen, uint64_t nrec);
 
+/* FASTA ingest (replaces the reference's single-threaded kseq.h + zlib reader, src/collect#$.c:34-90): the file is
+ * mapped (gzip: inflated), parsed and packed by `threads` host threads (the reference's -t) into the text format
+ * above.  Characters other than ACGTacgt and white space, sequence before the first header, FASTQ input and records of
+ * 32 bases or fewer (src/collect#$.c:41-45) are errors.  debwt_pack_fasta is host-only (no GPU needed);
+ * debwt_load_fasta = debwt_pack_fasta + debwt_load_text with the packed copy owned by ctx. */
+typedef struct {
+    uint64_t *words;      /* ((n + 63) >> 5) + 2 words */
+    uint64_t nwords;
+    uint64_t n;           /* BWTLEN */
+    uint64_t *sep;        /* nrec separator positions, sep[nrec-1] == n-1 */
+    uint64_t nrec;
+    double seconds_read, seconds_pack;
+} debwt_packed_text;
+int debwt_pack_fasta(const char *path, int threads, debwt_packed_text *out, char *errbuf, size_t errlen);
+void debwt_free_packed(debwt_packed_text *p);
+int debwt_load_fasta(debwt_ctx *ctx, const char *path, int threads);
+
 /* Texts whose node instances (one 8-byte key per base) do not fit HBM at once, or number 2^32 or more, are built
  * in key ranges: prefix ranges of the k-mer space holding at most `max_instances` keys each, sorted and classified
  * one after the other over the resident 2-bit text -- the single-GPU form of SURVEY 8e's bucket sharding (the

@@ -1,0 +1,50 @@
+"""HBM traffic per launch from two rocprofv3 counter runs (separate passes, counters only):
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d DIR_F -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d DIR_W -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    python scripts/pmc_summarize.py FETCH.csv WRITE.csv KEYS OUT.json
+Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: counter values are KiB;
+on gfx950 FETCH_SIZE reports half of a wide coalesced streaming read, so reads are doubled -- and the factor is
+re-derived inside the same run from rs_hist_kernel<0,0>, which reads exactly 8 B x KEYS; WRITE_SIZE is taken as is."""
+import csv, json, re, sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()
+        acc[name].append(float(row["Counter_Value"]))
+    out = {}
+    for name, v in acc.items():
+        big = [x for x in v if x >= 0.5 * max(v)]          # the same kernel also runs on small auxiliary inputs
+        out[name] = {"launches": len(v), "max_KiB": max(v), "mean_of_large_KiB": sum(big) / len(big)}
+    return out
+
+
+def main():
+    fetch_csv, write_csv, keys, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    F, W = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    hist = next(k for k in F if k.startswith("rs_hist_kernel<0, 0"))
+    known_kib = 8.0 * keys / 1024.0
+    factor = known_kib / F[hist]["mean_of_large_KiB"]
+    scat = next(k for k in F if k.startswith("rs_scatter_kernel<0, 0"))
+    rd = F[scat]["mean_of_large_KiB"] * 1024.0 * factor
+    wr = W[scat]["mean_of_large_KiB"] * 1024.0
+    res = {
+        "calibration": {"kernel": hist + " reads exactly 8 B x %d keys" % keys, "known_KiB": known_kib,
+                        "FETCH_SIZE_KiB": F[hist]["mean_of_large_KiB"], "factor": factor},
+        "rs_scatter_kernel": {"name": scat, "FETCH_SIZE_KiB": F[scat]["mean_of_large_KiB"],
+                              "WRITE_SIZE_KiB": W[scat]["mean_of_large_KiB"], "read_bytes": rd, "write_bytes": wr},
+        "rs_scatter_bytes_per_launch": int(rd + wr),
+        "rs_scatter_algorithmic_bytes_per_launch": 16 * keys,
+        "raw": {"FETCH_SIZE": F, "WRITE_SIZE": W},
+    }
+    json.dump(res, open(out_path, "w"), indent=1)
+    print(json.dumps({k: res[k] for k in ("calibration", "rs_scatter_kernel", "rs_scatter_bytes_per_launch",
+                                          "rs_scatter_algorithmic_bytes_per_launch")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

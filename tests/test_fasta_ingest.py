@@ -1,0 +1,105 @@
+"""Host FASTA ingest (debwt_pack_fasta): the multi-threaded parser against the plain numpy packer on
+the same records -- layout of src/collect#$.c:61-90 -- for every thread count, line shape and error the reference's
+reader distinguishes (src/collect#$.c:34-45, src/main.c:18-23).  No GPU needed."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from debwt_amd import api
+
+ASC = b"ACGT"
+
+
+def _write(path, recs, width=60, lower=False, crlf=False, blank_lines=False, spaces=False, gz=False):
+    eol = b"\r\n" if crlf else b"\n"
+    op = gzip.open if gz else open
+    with op(path, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">rec%d some > description with >signs" % i + eol)
+            s = bytes(ASC[c] for c in r)
+            if lower and i % 2:
+                s = s.lower()
+            for a in range(0, len(s), width):
+                line = s[a:a + width]
+                if spaces and len(line) > 10:
+                    line = line[:5] + b" " + line[5:9] + b"\t" + line[9:]
+                f.write(line + eol)
+                if blank_lines and a % (3 * width) == 0:
+                    f.write(eol)
+
+
+def _check(path, recs, threads):
+    w0, n0, sep0 = api.pack_records(recs)
+    w, n, sep, _, _ = api.pack_fasta(path, threads)
+    nw = (n0 + 63) // 32
+    assert n == n0 and np.array_equal(sep, sep0)
+    assert np.array_equal(w[:nw], w0[:nw])
+
+
+@pytest.fixture(scope="module")
+def recs():
+    rng = np.random.default_rng(3)
+    return [rng.integers(0, 4, size=int(rng.integers(33, 40000))).astype(np.uint8) for _ in range(41)]
+
+
+@pytest.mark.parametrize("threads", [1, 2, 3, 8, 64])
+@pytest.mark.parametrize("shape", ["plain", "lower", "crlf", "blank", "spaces", "wide", "narrow", "gz"])
+def test_pack_fasta_matches_numpy_packer(tmp_path, recs, threads, shape):
+    p = str(tmp_path / ("t.fa.gz" if shape == "gz" else "t.fa"))
+    kw = {"plain": {}, "lower": {"lower": True}, "crlf": {"crlf": True}, "blank": {"blank_lines": True},
+          "spaces": {"spaces": True}, "wide": {"width": 100000}, "narrow": {"width": 1}, "gz": {"gz": True}}[shape]
+    _write(p, recs, **kw)
+    _check(p, recs, threads)
+
+
+def test_pack_fasta_single_long_line_and_many_threads(tmp_path):
+    rng = np.random.default_rng(5)
+    recs = [rng.integers(0, 4, size=3_000_000).astype(np.uint8), rng.integers(0, 4, size=33).astype(np.uint8)]
+    p = str(tmp_path / "l.fa")
+    _write(p, recs, width=10_000_000)
+    for t in (1, 7, 16):
+        _check(p, recs, t)
+
+
+def test_pack_fasta_headers_longer_than_a_chunk(tmp_path):
+    """Chunk starts that fall inside header lines."""
+    rng = np.random.default_rng(6)
+    recs = [rng.integers(0, 4, size=40).astype(np.uint8) for _ in range(30)]
+    p = str(tmp_path / "h.fa")
+    with open(p, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">" + b"x>y" * 20000 + b"\n" + bytes(ASC[c] for c in r) + b"\n")
+    for t in (1, 5, 16):
+        _check(p, recs, t)
+
+
+@pytest.mark.parametrize("content,msg", [
+    (b">a\nACGTNACGT" + b"A" * 40 + b"\n", "not one of ACGTacgt"),
+    (b"ACGT\n>a\n" + b"A" * 40 + b"\n", "before the first header"),
+    (b">a\n" + b"A" * 32 + b"\n", "Length <= 32"),
+    (b"@r\nACGT\n+\nIIII\n", "FASTQ"),
+    (b"", "empty"),
+])
+def test_pack_fasta_errors(tmp_path, content, msg):
+    p = str(tmp_path / "e.fa")
+    open(p, "wb").write(content)
+    with pytest.raises(api.DebwtError) as ei:
+        api.pack_fasta(p, 4)
+    assert msg in str(ei.value)
+
+
+def test_pack_fasta_missing_file():
+    with pytest.raises(api.DebwtError):
+        api.pack_fasta("/nonexistent/x.fa", 2)
+
+
+def test_golden_fasta_files_pack_like_the_python_reader():
+    from conftest import GOLDEN, golden_manifest
+    from debwt_amd import fasta
+    for e in golden_manifest():
+        if e["source"]["kind"] != "fasta":
+            continue
+        path = os.path.join(GOLDEN, e["name"] + ".fa")
+        _check(path, fasta.read_fasta(path)[1], 4)
