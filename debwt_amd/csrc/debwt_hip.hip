@@ -181,6 +181,7 @@ RadixWorkspace radix_ws(debwt_ctx *c) {
     ws.counts = c->rs_counts.as<u32>();
     ws.over = c->rs_over.as<u32>();
     ws.h_over = c->h_over;
+    ws.over_cap = c->rs_over.cap >= 48 ? (u32)std::min<size_t>((c->rs_over.cap - 32) / 16, 0xFFFFFFFFu) : 0;
     ws.skew_list = c->rs_skew.as<u32>();
     return ws;
 }
@@ -189,6 +190,7 @@ RadixWorkspace radix_ws(debwt_ctx *c) {
 // the small auxiliary sorts.  Pass events are recorded when `record_passes`.
 int sort_keys(debwt_ctx *c, u64 *a, u64 *b, u64 count, int key_bits, u64 **result, bool record_passes,
               const TextKeySrc *text = nullptr, bool main_sort = false) {
+    ENSURE(c, c->rs_over, radix_over_bytes(count));      // one list entry per 4096-key tile can be oversize
     RadixWorkspace ws = radix_ws(c);
     hipError_t e = hipSuccess;
     const bool main = main_sort || record_passes;
@@ -241,8 +243,8 @@ extern "C" int debwt_create(const debwt_config *cfg, debwt_ctx **out) {
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) return fail(DEBWT_EDEVICE);
     for (auto &p : c->ev_pass) for (auto &e : p) if (hipEventCreate(&e) != hipSuccess) return fail(DEBWT_EDEVICE);
     if ((rc = ensure(c, c->rs_counts, radix_workspace_bytes(0))) != DEBWT_OK) return fail(rc);
-    if ((rc = ensure(c, c->rs_over, radix_over_bytes())) != DEBWT_OK) return fail(rc);
-    if (hipHostMalloc((void **)&c->h_over, radix_over_bytes(), hipHostMallocDefault) != hipSuccess)
+    if ((rc = ensure(c, c->rs_over, radix_over_bytes(1 << 20))) != DEBWT_OK) return fail(rc);
+    if (hipHostMalloc((void **)&c->h_over, 64, hipHostMallocDefault) != hipSuccess)
         return fail(DEBWT_ENOMEM);
     if ((rc = ensure(c, c->cp_counts, 8 * (CP_MAXCHUNKS + 16) * sizeof(u32))) != DEBWT_OK) return fail(rc);
     if ((rc = ensure(c, c->dollar, 64)) != DEBWT_OK) return fail(rc);
@@ -1251,6 +1253,7 @@ extern "C" int debwt_radix_sort_u64(debwt_ctx *c, uint64_t *d_keys, uint64_t *d_
     if (count >= 0xFFFFFFF0ull) return DEBWT_ERANGE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     ENSURE(c, c->rs_skew, (count / 2048 + 2) * 4);
+    ENSURE(c, c->rs_over, radix_over_bytes(count));
     RadixWorkspace ws = radix_ws(c);
     hipError_t e = hipSuccess;
     int np = 0;

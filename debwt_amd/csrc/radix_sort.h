@@ -14,11 +14,11 @@
 
 struct RadixWorkspace {
     u32 *counts;        // [RS_RADIX][RS_MAXCHUNKS + 1] digit-major chunk histograms / offsets + digit totals
-    u32 *over;          // hybrid path: [0] = number of oversize tiles, then RS_OVER_CAP (start,len) u64 pairs at +16 B
-    u32 *h_over;        // pinned host mirror of `over` (same size)
+    u32 *over;          // hybrid path: [0] = number of oversize tiles, then over_cap (start,len) u64 pairs at +16 B
+    u32 *h_over;        // pinned host word for the count
+    u32 over_cap;       // entries the list holds (radix_over_bytes sizes it for one entry per 4096-key tile)
     u32 *skew_list;     // hybrid path: one byte per 4096-key tile, set when a 1024-key wave tile did not fit
 };
-#define RS_OVER_CAP 4096
 
 // Optional key source for the FIRST pass: node keys (node << 2 | pred) computed on the fly from the 2-bit text,
 // one per position whose K-window holds no separator -- the key array is then never written out unsorted.
@@ -40,7 +40,7 @@ struct RsDigit {
 };
 
 size_t radix_workspace_bytes(u64 max_keys);
-size_t radix_over_bytes();
+size_t radix_over_bytes(u64 max_keys);
 hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const TextKeySrc *text, u64 count, u64 *dst,
                                     const RsDigit &dg, u32 nshards, const RadixWorkspace &ws, u64 *offs_host);
 

@@ -440,7 +440,9 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
 // hybrid: local finish of prefix buckets in LDS
 
 #define RL_CAP 4096                    // keys a 256-thread workgroup finishes
-#define RL_H (RL_CAP * 7 / 8)          // its tile stride: tile j starts at the first bucket boundary >= j*RL_H
+#ifndef RL_H
+#define RL_H (RL_CAP / 2)              // its tile stride: tile j starts at the first bucket boundary >= j*RL_H; a tile
+#endif                                 // fits whenever no bucket in it exceeds RL_CAP - RL_H keys
 #define RLW_CAP 1024                   // keys a single wave finishes (16 per lane, no barriers at all)
 #define RLW_H (RLW_CAP * 7 / 8)
 #ifndef RL_MAX_ROUNDS
@@ -485,10 +487,10 @@ __device__ __forceinline__ void rl_cex(u64 &a, u64 &b, bool up) {      // (a,b) 
 //             does not fit is queued for the HBM path.
 template <int NT>
 __global__ __launch_bounds__(NT) void rs_local_kernel(u64 *__restrict__ keys, u64 n, int pshift,
-                                                       u32 *__restrict__ over, u8 *__restrict__ mark) {
+                                                       u32 *__restrict__ over, u32 over_cap, u8 *__restrict__ mark) {
     constexpr int KPT = 16;
     constexpr u32 CAP = NT * KPT;
-    constexpr u32 H = CAP * 7 / 8;
+    constexpr u32 H = NT == 64 ? RLW_H : RL_H;
     constexpr int LOGN = NT == 64 ? 10 : 12;
     static_assert(NT == 64 || NT == 256, "wave or 4-wave workgroup");
     __shared__ u64 A[CAP + CAP / 16];
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(NT) void rs_local_kernel(u64 *__restrict__ keys, u6
             for (u64 t = t0 + tid; t <= t1; t += NT) mark[t] = 1;
         } else if (tid == 0) {
             u32 idx = atomicAdd(&over[0], 1u);
-            if (idx < RS_OVER_CAP) {
+            if (idx < over_cap) {
                 u64 *list = reinterpret_cast<u64 *>(over + 4);
                 list[2 * idx] = s; list[2 * idx + 1] = cnt64;
             }
@@ -660,7 +662,7 @@ static void rs_plan(u64 n, u32 *nchunks, u64 *chunk) {
     if (*nchunks == 0) *nchunks = 1;
 }
 
-size_t radix_over_bytes() { return 16 + (size_t)RS_OVER_CAP * 16 + 16; }
+size_t radix_over_bytes(u64 max_keys) { return 16 + (size_t)(max_keys / RL_H + 2) * 16 + 16; }
 
 static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
                    hipEvent_t *pass_events, int max_pairs, int *npairs, const TextKeySrc *text = nullptr,
@@ -725,20 +727,21 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
     u32 ntiles = (u32)((n + RL_H - 1) / RL_H), nwtiles = (u32)((n + RLW_H - 1) / RLW_H);
     u8 *mark = reinterpret_cast<u8 *>(ws.skew_list);          // one byte per 4096-key tile
     (void)hipMemsetAsync(mark, 0, ntiles + 1, stream);
-    rs_local_kernel<64><<<nwtiles, 64, 0, stream>>>(src, n, pshift, ws.over, mark);
-    rs_local_kernel<256><<<ntiles, 256, 0, stream>>>(src, n, pshift, ws.over, mark);
+    rs_local_kernel<64><<<nwtiles, 64, 0, stream>>>(src, n, pshift, ws.over, ws.over_cap, mark);
+    rs_local_kernel<256><<<ntiles, 256, 0, stream>>>(src, n, pshift, ws.over, ws.over_cap, mark);
     (void)hipMemcpyAsync(ws.h_over, ws.over, 16, hipMemcpyDeviceToHost, stream);
     if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;
     u32 nover = ws.h_over[0];
     if (nover) {
         // heavy buckets (low-complexity k-mers): finish them together with the all-HBM passes
-        bool whole = nover > RS_OVER_CAP;
+        bool whole = nover > ws.over_cap;
         u64 total = 0;
-        std::vector<u64> offs;
+        std::vector<u64> offs, hlist;
         if (!whole) {
-            (void)hipMemcpyAsync(ws.h_over, ws.over, radix_over_bytes(), hipMemcpyDeviceToHost, stream);
+            hlist.resize(2 * (size_t)nover);
+            (void)hipMemcpyAsync(hlist.data(), ws.over + 4, 16 * (size_t)nover, hipMemcpyDeviceToHost, stream);
             if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;
-            u64 *list = reinterpret_cast<u64 *>(ws.h_over + 4);
+            const u64 *list = hlist.data();
             // ascending by start: the sorted scratch array maps back onto the ranges in address order
             std::vector<std::pair<u64, u64>> rg(nover);
             for (u32 i = 0; i < nover; i++) rg[i] = {list[2 * i], list[2 * i + 1]};

@@ -12,7 +12,8 @@ sed -i "s#\"../../include/debwt_hip.h\"#\"$PWD/include/debwt_hip.h\"#" "$tmp/deb
 F="-O3 -std=c++17 -fPIC -Wno-unused-function --offload-arch=gfx950 $flags"
 ( cd "$tmp" && /opt/rocm/bin/hipcc $F -c radix_sort.hip -o radix_sort.o & 
   cd "$tmp" && /opt/rocm/bin/hipcc $F -c debwt_hip.hip -o debwt_hip.o &
-  cd "$tmp" && /opt/rocm/bin/hipcc $F -x c++ -c special_host.cpp -o special_host.o & wait )
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libdebwt_$name.so "$tmp"/radix_sort.o "$tmp"/debwt_hip.o "$tmp"/special_host.o
+  cd "$tmp" && /opt/rocm/bin/hipcc $F -x c++ -c special_host.cpp -o special_host.o &
+  cd "$tmp" && /opt/rocm/bin/hipcc $F -x c++ -c fasta_host.cpp -o fasta_host.o & wait )
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libdebwt_$name.so "$tmp"/radix_sort.o "$tmp"/debwt_hip.o "$tmp"/special_host.o "$tmp"/fasta_host.o -lz -lpthread
 rm -rf "$tmp"
 echo built build/variants/libdebwt_$name.so

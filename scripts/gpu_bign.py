@@ -2,7 +2,7 @@
 python scripts/gpu_bign.py [total_bases=5000000000] [records=24] [--cap N] [--pan]
 Checks: k-invariance (k=32 vs k=24 give the identical BWT), '#' rows ascending, symbol census = text census."""
 import hashlib, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from debwt_amd import api, synth
 

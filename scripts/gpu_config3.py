@@ -1,7 +1,7 @@
 """BASELINE configs[2]: GRCh38-sized collection (~3.1 Gbp, 24 records) on ONE MI355X, in core.
 python scripts/gpu_config3.py [total_bases] [--inverse]"""
 import hashlib, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from debwt_amd import api, synth
 

@@ -1,6 +1,6 @@
 """Cost of the HBM path for heavy-tail blocks: python scripts/gpu_large_block.py [copies]"""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from debwt_amd import api
 from oracle import oracle as O

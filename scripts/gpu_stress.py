@@ -1,6 +1,6 @@
 """Robustness runs beyond the unit tests: python scripts/gpu_stress.py [big|records|all]"""
 import hashlib, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from debwt_amd import api, synth
 from oracle import oracle as O

@@ -12,7 +12,11 @@ def child(workload):
     if os.path.exists(cache):
         recs = [np.load(cache)]
     else:
-        recs = synth.make_workload(workload)
+        if workload.startswith("pan:"):                      # pan:<bases per genome>:<genomes>
+            _, L, G = workload.split(":")
+            recs = synth.pan_genome(int(L), int(G))
+        else:
+            recs = synth.make_workload(workload)
         if len(recs) == 1: np.save(cache, recs[0])
     d = api.DeBWT(k=32); d.load_records(recs)
     best = None

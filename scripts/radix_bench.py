@@ -1,6 +1,6 @@
 """Micro-benchmark of one radix pass: python scripts/radix_bench.py [count] [algo]"""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from debwt_amd import api
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 250_000_000
