@@ -969,21 +969,62 @@ __global__ void k_large_store(u64 *__restrict__ blue, u64 b0, u32 m, u64 j0, con
 // assembly (insertCase3, src/insertCase3.c:56-104): rows = node-instance symbols in key order with the
 // special suffixes merged in at their rows; 2 bits per row, '#'/'$' rows stored as 3 and recorded
 
+// A workgroup covers 256 words = 8192 rows; the row symbols it needs (a contiguous stretch of mchar: the rows minus
+// the special suffixes before them) are staged in LDS with 16-byte loads; a word whose 32 rows hold no special suffix
+// and no separator symbol (nearly all of them) is packed from 8 LDS words with byte-align and shift/or steps, the
+// others row by row.
+#define ASM_ROWS (DEBWT_BLOCK * 32)
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_assemble(const u8 *__restrict__ mchar, u64 M,
                                                            const u64 *__restrict__ sprow,
                                                            const u8 *__restrict__ spchr, u64 NS, u64 n,
                                                            u64 *__restrict__ bwt, u32 *__restrict__ hmask,
                                                            u64 *__restrict__ dollar_row, u8 *__restrict__ rowsym) {
+    __shared__ u32 sm[ASM_ROWS / 4 + 12];
+    __shared__ u64 sblk;
+    const u64 R0 = (u64)blockIdx.x * ASM_ROWS;
+    if (threadIdx.x == 0) sblk = lower_bound_dev<u64>(sprow, 0, NS, R0);       // special rows before the block
+    __syncthreads();
+    const u64 jb = R0 - sblk, jal = jb & ~15ull;                                 // first instance of the block, 16-aligned
+    // instances [jal, jal + ASM_ROWS + 16): mchar is padded by 64 bytes behind M
+    for (u32 i = threadIdx.x; i < ASM_ROWS / 16 + 2; i += DEBWT_BLOCK) {
+        const u64 a = jal + (u64)i * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (a < M + 48) v = *reinterpret_cast<const uint4 *>(mchar + a);
+        sm[4 * i] = v.x; sm[4 * i + 1] = v.y; sm[4 * i + 2] = v.z; sm[4 * i + 3] = v.w;
+    }
+    __syncthreads();
     u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 nw = (n + 31) >> 5;
     if (w >= nw) return;
     u64 r0 = w << 5;
-    u64 s = lower_bound_dev<u64>(sprow, 0, NS, r0);            // special rows before r0
+    u64 s = lower_bound_dev<u64>(sprow, sblk, NS, r0);            // special rows before r0
     u64 j = r0 - s;
     u64 next_special = s < NS ? sprow[s] : ~0ull;
+    u32 lim = (n - r0) < 32 ? (u32)(n - r0) : 32u;
+    if (lim == 32 && next_special >= r0 + 32 && !rowsym) {
+        // 32 instances from LDS: 9 words, byte-aligned to the first instance
+        const u32 off = (u32)(j - jal);
+        const u32 wi = off >> 2, sh = off & 3u;
+        u32 q[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) q[t] = sm[wi + t];
+        u32 bad = 0;
+        u64 word = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const u32 x = __builtin_amdgcn_alignbyte(q[t + 1], q[t], sh);        // 4 symbols, first in the low byte
+            bad |= x;
+            const u32 p = ((x << 6) | (x >> 4) | (x >> 14) | (x >> 24)) & 0xFFu;  // 2 bits each, first symbol on top
+            word |= (u64)p << (56 - 8 * t);
+        }
+        if (!(bad & 0xFCFCFCFCu)) {                                // no '#' / '$' among them
+            bwt[w] = word;
+            hmask[w] = 0;
+            return;
+        }
+    }
     u64 word = 0;
     u32 hm = 0;
-    u32 lim = (n - r0) < 32 ? (u32)(n - r0) : 32u;
     for (u32 t = 0; t < lim; t++) {
         u64 r = r0 + t;
         u32 c;
@@ -994,7 +1035,6 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_assemble(const u8 *__restrict__
         else if (c == 5) { *dollar_row = r; c = 3; }
         word |= (u64)c << ((31 - t) << 1);
     }
-    (void)M;
     bwt[w] = word;
     hmask[w] = hm;
 }
