@@ -66,7 +66,7 @@ struct debwt_ctx {
     u64 Mctx = 0;               // node instances of this context (sum over its ranges)
     u64 nfacts_acc = 0;         // facts accumulated over the ranges
     bool local_done = false;    // classify_local already ran per range (multi-range build)
-    DevBuf blk_j0, blk_freq, blk_start, facts_acc, large_tmp;
+    DevBuf blk_j0, blk_freq, blk_start, facts_acc, large_tmp, blue_tmp;
     // k-mer-prefix shard of a multi-GPU build (world == 1: the whole key space)
     int shard_rank = 0, shard_world = 1;
     u64 Mfull = 0;              // node instances of the whole text
@@ -261,7 +261,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
                      &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
-                     &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp};
+                     &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -752,11 +752,22 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     if ((rc = sp_prepare(c))) return rc;
     const u64 ngroups = (c->n + 31) >> 5;
     u64 S = 0, Bseen = 0;
+    // Blue fill without atomics when a routed entry (block id | SP index | pred) fits 64 bits: the entries of all
+    // slices are collected in `blue`, sorted by block id, stripped.  Otherwise (or cfg.reserved bit 5: tests) one
+    // cursor atomic per entry.
+    int qbits = 1;
+    while ((1ull << qbits) < c->Q) qbits++;
+    const int qshift = 64 - qbits;
+    const bool route_sort = c->shard_world == 1 && c->Q > 0 && c->n < (1ull << (qshift - 3)) && !(c->cfg.reserved & 32);
     for (u64 g0 = 0; g0 < ngroups; g0 += SP_SLICE_GROUPS) {
         const u64 g1 = std::min(ngroups, g0 + SP_SLICE_GROUPS);
         if ((rc = sp_flags(c, g0, g1))) return rc;
         if ((rc = sp_emit(c, S))) return rc;
-        if (c->B_slice) {
+        if (c->B_slice && route_sort) {
+            if (Bseen + c->B_slice > c->B) { c->err = "multi-in positions exceed the block total"; return DEBWT_EINTERNAL; }
+            k_blue_route_q<<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+                c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, qshift, c->blue.as<u64>() + Bseen);
+        } else if (c->B_slice) {
             if (c->abs32)
                 k_blue_fill<1><<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
                     c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, c->blk_start.as<u64>(),
@@ -769,6 +780,17 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
         S += c->S_local; Bseen += c->B_slice;
     }
     if (Bseen != c->Btotal) { c->err = "multi-in positions differ from the block total"; return DEBWT_EINTERNAL; }
+    if (route_sort && c->B) {
+        // scratch of B words: a key buffer when it is large enough (free since the ranges were classified)
+        u64 *tmp;
+        if (c->keysA.cap >= c->B * 8) tmp = c->keysA.as<u64>();
+        else { ENSURE(c, c->blue_tmp, c->B * 8 + 64); tmp = c->blue_tmp.as<u64>(); }
+        ENSURE(c, c->rs_over, radix_over_bytes(c->B));
+        hipError_t e = hipSuccess;
+        u64 *r = radix_sort_bits(c->stream, c->blue.as<u64>(), tmp, c->B, qshift, 64, radix_ws(c), &e);
+        if (e != hipSuccess) { c->err = std::string("blue entry sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
+        k_blue_strip<<<grid_for(c->B, 256), 256, 0, c->stream>>>(r, c->blue.as<u64>(), c->B, qshift);
+    }
     return sp_finish(c, S);
 }
 

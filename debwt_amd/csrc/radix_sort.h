@@ -53,6 +53,10 @@ hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const Te
 // after the scatter kernel of pass i (no synchronisation); *npairs receives the number recorded.
 // text (optional): when given, the keys are taken from the text in the first pass (`a` is scratch, n = number of
 // valid positions); pass events are then recorded for the array-to-array passes only.
+// Stable LSD passes over the key bits [lo_bit, hi_bit) only (auxiliary kernels); a: input, b: scratch of n words;
+// returns the buffer that holds the result.
+u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
+                     hipError_t *err);
 u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, const RadixWorkspace &ws,
                     int algo, hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err,
                     const TextKeySrc *text = nullptr);

@@ -704,6 +704,15 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
     return src;
 }
 
+u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
+                     hipError_t *err) {
+    *err = hipSuccess;
+    if (n < 2 || hi_bit <= lo_bit) return a;
+    u64 *r = rs_lsd(stream, a, b, n, lo_bit, hi_bit, ws, nullptr, 0, nullptr, nullptr, true);
+    *err = hipGetLastError();
+    return r;
+}
+
 u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, const RadixWorkspace &ws, int algo,
                     hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err, const TextKeySrc *text) {
     *err = hipSuccess;

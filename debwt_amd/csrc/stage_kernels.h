@@ -697,6 +697,26 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route(const ulonglong2 *__
     u64 q = h == 0xFFFFFFFFu ? 0xFFFFFFFull : (u64)htab[h].q;
     out[b] = (q << 36) | ((it.y >> 4) << 3) | (it.y & 7ull);
 }
+// Atomic-free blue fill: a multi-in position -> (block id << qshift | spIndex << 3 | pred); sorting these words by
+// their block bits puts every entry into its block (the blocks' blue slots are the exclusive scan of their sizes in
+// block order), k_blue_strip turns them into blue entries (pred | spIndex << 4).
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route_q(const ulonglong2 *__restrict__ mi_list, u64 B,
+                                                               const HSlot *__restrict__ htab, int hbits, int qshift,
+                                                               u64 *__restrict__ out) {
+    u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    ulonglong2 it = mi_list[b];
+    u32 fl;
+    u32 h = red_lookup(htab, hbits, it.x, &fl);
+    u64 q = h == 0xFFFFFFFFu ? 0ull : (u64)htab[h].q;            // every multi-in position has its node in the table
+    out[b] = (q << qshift) | ((it.y >> 4) << 3) | (it.y & 7ull);
+}
+__global__ void k_blue_strip(const u64 *__restrict__ src, u64 *__restrict__ dst, u64 n, int qshift) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 e = src[i];
+    dst[i] = (e & 7ull) | (((e & ((1ull << qshift) - 1ull)) >> 3) << 4);
+}
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_place(const u64 *__restrict__ ent, u64 count, u32 qbase,
                                                              u32 Qlocal, u32 *__restrict__ qcursor,
                                                              const u64 *__restrict__ blk_start,

@@ -298,7 +298,9 @@ def test_multi_range_equals_single_range_midsize(api, cap):
     from debwt_amd import synth
     recs = synth.make_workload("pan_16M_4")
     _, (w1, h1, d1), st1 = _run(api, recs, 32)
-    d = api.DeBWT(k=32, tune=16 if cap == 3_000_000 else 0)      # 16: block-relative fill cursors + 64-bit block starts
+    # blue fill: 0 = entries routed and sorted by block id; 32 = cursor atomics; 48 = cursor atomics with
+    # block-relative cursors + 64-bit block starts (what a context with >= 2^32 blue rows uses)
+    d = api.DeBWT(k=32, tune={1 << 20: 0, 3_000_000: 48, 1 << 23: 32}[cap])
     d.set_range_cap(cap)
     d.load_records(recs)
     d.build()
