@@ -66,7 +66,7 @@ struct debwt_ctx {
     u64 Mctx = 0;               // node instances of this context (sum over its ranges)
     u64 nfacts_acc = 0;         // facts accumulated over the ranges
     bool local_done = false;    // classify_local already ran per range (multi-range build)
-    DevBuf blk_j0, blk_freq, blk_start, facts_acc, large_tmp, blue_tmp;
+    DevBuf blk_j0, blk_freq, blk_start, facts_acc, large_tmp, blue_tmp, sub_start, sub_j0, sub_freq, sub_depth;
     // k-mer-prefix shard of a multi-GPU build (world == 1: the whole key space)
     int shard_rank = 0, shard_world = 1;
     u64 Mfull = 0;              // node instances of the whole text
@@ -261,7 +261,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
                      &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
-                     &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp};
+                     &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0, &c->sub_freq, &c->sub_depth};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -805,19 +805,41 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     const u64 Q = c->Q;
     if (Q) {
+        // sub-block table for the deep tie groups of the larger size classes (BlueSub)
+        const u32 sub_cap = (u32)std::min<u64>(std::max<u64>(c->B / 8, 1u << 16), 1u << 26);
+        ENSURE(c, c->sub_start, (size_t)sub_cap * 8);
+        ENSURE(c, c->sub_j0, (size_t)sub_cap * 8);
+        ENSURE(c, c->sub_freq, (size_t)sub_cap * 4);
+        ENSURE(c, c->sub_depth, (size_t)sub_cap * 4 + 16);
+        u32 *sub_count = c->sub_depth.as<u32>() + sub_cap;
+        HIPCHK(c, hipMemsetAsync(c->sub_freq.p, 0, (size_t)sub_cap * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(sub_count, 0, 4, c->stream));
+        BlueSub sub{c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), c->sub_depth.as<u32>(), sub_count,
+                    (c->cfg.reserved & 128) ? 0u : sub_cap};      // bit 7: no hand-off (tests)
+        BlueSub none{};
         u32 g1 = (u32)std::min<u64>(Q, 1u << 16);
         // small blocks are the bulk: a small LDS footprint keeps 32 single-wave workgroups per CU in flight
-        k_blue_refine<64, 128><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
-                                                        c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q, 0u,
-                                                        c->spn.as<u64>(), c->S, c->mchar.as<u8>());
-        k_blue_refine<64, BLUE_WAVE_CAP><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
-                                                                  c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
-                                                                  128u, c->spn.as<u64>(), c->S, c->mchar.as<u8>());
+        k_blue_refine<64, 128, 0><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
+                                                           c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q, 0u,
+                                                           c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, none);
+        k_blue_refine<64, BLUE_WAVE_CAP, 128><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
+                                                                     c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
+                                                                     128u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(),
+                                                                     nullptr, nullptr, sub);
         u32 g2 = (u32)std::min<u64>(Q, 1u << 12);
-        k_blue_refine<256, BLUE_LDS_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
-                                                                   c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
-                                                                   (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
-                                                                   c->mchar.as<u8>());
+        k_blue_refine<256, BLUE_LDS_CAP, BLUE_WAVE_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
+                                                                      c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
+                                                                      (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
+                                                                      c->mchar.as<u8>(), nullptr, nullptr, sub);
+        // the queued groups: blocks of their own that start `depth` windows in (<= 128 rows from the 512 class,
+        // <= 512 rows from the 2048 class)
+        const u32 gs = std::min<u32>(sub_cap, 1u << 16);
+        k_blue_refine<64, 128, 0><<<gs, 64, 0, c->stream>>>(
+            c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 0u,
+            c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
+        k_blue_refine<64, BLUE_WAVE_CAP, 0><<<gs, 64, 0, c->stream>>>(
+            c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 128u,
+            c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
     }
     c->st.blue_max_block = 0;
     if (c->nlarge) {

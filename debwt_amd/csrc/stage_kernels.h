@@ -783,11 +783,23 @@ __device__ __forceinline__ bool sp_less_deep(const u64 *__restrict__ spn, u64 S,
 // src/sortBlue.c:192-219), leave the game.  One SP gather per unresolved entry per round -- not per
 // comparison.  A workgroup of NT threads holds the block in LDS; each round is a bitonic network on
 // (group, window) pairs, a prefix-max for the new group ids and LDS atomics for the group census.
-template <int NT, int CAP>
+// Hand-off of deep tie groups: in collections of near-identical genomes the rows of a large block (a repeat family's
+// node over all genomes) separate into small groups within two or three windows, but a few of those groups -- the
+// same locus in several genomes -- stay tied for hundreds of SP symbols, and every further round costs the whole
+// workgroup its barriers.  Once all unresolved groups hold <= SPLIT rows (template parameter, 0 = never) a block of
+// the two larger size classes writes its rows out in their current order and queues each unresolved group as a block
+// of its own (start, rows, first instance, windows already equal) for the wave-per-block kernels.
+struct BlueSub {
+    u64 *start; u32 *freq; u64 *j0; u32 *depth;      // sub-block table (written by SPLIT kernels, read through depth0)
+    u32 *count; u32 cap;                              // entries reserved / capacity
+};
+
+template <int NT, int CAP, int SPLIT>
 __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, const u64 *__restrict__ bstart,
                                                      const u32 *__restrict__ mi_freq, const u64 *__restrict__ mi_j0,
                                                      u32 Q, u32 lo_excl, const u64 *__restrict__ spn, u64 S,
-                                                     u8 *__restrict__ mchar) {
+                                                     u8 *__restrict__ mchar, const u32 *__restrict__ depth0,
+                                                     const u32 *__restrict__ Qdev, BlueSub sub) {
     __shared__ u64 se[CAP];     // entries
     __shared__ u64 sw[CAP];     // current window, first 21 symbols
     __shared__ u64 sx[CAP];     //                 next 21 symbols
@@ -797,10 +809,13 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
     __shared__ u32 wtot[NT / 64 + 1];
     __shared__ u32 flag;
     __shared__ u32 smax;
+    __shared__ u32 sub_n, sub_i, sub_base;
     const u32 tid = threadIdx.x;
+    if (Qdev) { u32 qd = *Qdev; Q = qd < Q ? qd : Q; }           // sub-block table: entries written so far (<= its capacity)
     for (u32 q = blockIdx.x; q < Q; q += gridDim.x) {
         const u32 m = mi_freq[q];
         if (m <= lo_excl || m > CAP) continue;
+        const u64 d0 = depth0 ? depth0[q] : 0;
         u32 maxg = m;
         const u64 b0 = bstart[q];
         const u64 j0 = mi_j0[q];
@@ -825,7 +840,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             for (u32 x = tid; x < m; x += NT) {
                 u32 g = sg[x];
                 bool unresolved = gcnt[g] > 1 && (gmsk[g] & (gmsk[g] - 1));
-                u64 pos = (se[x] >> 4) + depth * (2 * SP_WIN);
+                u64 pos = (se[x] >> 4) + (d0 + depth) * (2 * SP_WIN);
                 bool live = unresolved && pos < S;
                 sw[x] = live ? sp_window(spn, pos) : 0ull;
                 sx[x] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
@@ -939,9 +954,32 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             }
             if (any) { flag = 1; atomicMax(&smax, any); }
             __syncthreads();
-            active = flag != 0 && (depth + 1) * (2 * SP_WIN) < S + 2 * SP_WIN;
+            active = flag != 0 && (d0 + depth + 1) * (2 * SP_WIN) < S + 2 * SP_WIN;
             maxg = smax;
             __syncthreads();
+            if (SPLIT && active && maxg <= (u32)SPLIT) {
+                // queue the unresolved groups: one reservation per block, then one entry per group
+                if (tid == 0) sub_n = 0;
+                __syncthreads();
+                u32 mine = 0;
+                for (u32 x = tid; x < m; x += NT)
+                    if (sg[x] == x && gcnt[x] > 1 && (gmsk[x] & (gmsk[x] - 1))) mine++;
+                if (mine) atomicAdd(&sub_n, mine);
+                __syncthreads();
+                if (tid == 0) { sub_base = atomicAdd(sub.count, sub_n); sub_i = 0; }
+                __syncthreads();
+                const u32 base = sub_base;
+                if ((u64)base + sub_n <= (u64)sub.cap) {                 // else: the table is full, keep refining here
+                    for (u32 x = tid; x < m; x += NT)
+                        if (sg[x] == x && gcnt[x] > 1 && (gmsk[x] & (gmsk[x] - 1))) {
+                            const u32 e = base + atomicAdd(&sub_i, 1u);
+                            sub.start[e] = b0 + x; sub.freq[e] = gcnt[x]; sub.j0[e] = j0 + x;
+                            sub.depth[e] = (u32)(d0 + depth + 1);
+                        }
+                    active = false;
+                }
+                __syncthreads();
+            }
         }
         for (u32 x = tid; x < m; x += NT) {
             u64 e = se[x];

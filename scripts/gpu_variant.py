@@ -18,7 +18,7 @@ def child(workload):
         else:
             recs = synth.make_workload(workload)
         if len(recs) == 1: np.save(cache, recs[0])
-    d = api.DeBWT(k=32); d.load_records(recs)
+    d = api.DeBWT(k=32, tune=int(os.environ.get("TUNE", "0"))); d.load_records(recs)
     best = None
     for it in range(6):
         d.build(); st = d.stats()

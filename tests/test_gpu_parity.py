@@ -338,3 +338,22 @@ def test_multi_range_with_large_blocks_and_many_records(api, oracle):
     assert st["blue_large_blocks"] > 0
     assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
     d.close()
+
+
+@pytest.mark.parametrize("tune", [0, 128])
+def test_pan_genome_deep_tie_groups(api, oracle, tune):
+    """Ten near-identical genomes with repeat families: blocks of hundreds of rows whose tie groups (one locus in
+    several genomes) stay tied for hundreds of SP symbols -- with (0) and without (128) the hand-off of those groups to
+    the wave-per-block kernel."""
+    from debwt_amd import synth
+    recs = synth.pan_genome(400_000, 10)
+    d = api.DeBWT(k=32, tune=tune)
+    d.load_records(recs)
+    d.build()
+    words, hrows, drow = d.fetch()
+    bound = d.fetch_array(api.ARR_BLUE_BOUND).astype(np.int64)
+    sizes = np.diff(np.concatenate([[-1], bound]))
+    assert (sizes > 128).sum() > 100
+    ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), 32)
+    assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
+    d.close()
