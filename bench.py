@@ -130,9 +130,12 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload} (BASELINE configs[1]: chr1-sized synthetic, repeat families)",
-                       "k": args.k, "bases_per_gpu": n, "records_per_gpu": len(recs),
-                       "parallelism": (f"one collection of {world} records built by {world} k-mer-prefix shards"
+            "config": {"workload": (f"{args.workload} (BASELINE configs[1]: chr1-sized synthetic, repeat families)"
+                                    if args.workload == "chr1_250M" else args.workload),
+                       "k": args.k, "bases_per_gpu": n // world if sharded_mode else n,
+                       "records_per_gpu": len(recs) // world if sharded_mode else len(recs),
+                       "parallelism": (f"one collection of {len(recs)} records ({n} bases) built by {world} "
+                                       f"k-mer-prefix shards ({shard_feed} mode)"
                                        if sharded_mode else f"{args.gpus} independent collections, one per GPU")},
             "roofline": {"bound": "hbm", "kernel": "rs_scatter_kernel (one 8-bit radix pass over the keys)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
