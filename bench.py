@@ -15,7 +15,8 @@ The one JSON line also carries
                   8 read + 8 written) / mean launch time from hipEvents recorded inside the timed region on
                   the stream the kernel runs on, against the 8 TB/s HBM peak;
   cpu_baseline -- the CPU oracle (a single-threaded port of the reference path) timed on this box's host
-                  cores on a bounded prefix of the same workload (rank 0, N=1 only).
+                  cores on a bounded prefix of the same workload (rank 0, N=1 only);
+  cpu_reference -- the reference's own stage functions (oracle/_ref, 8 threads) on a shorter prefix, when built.
 """
 import argparse
 import json
@@ -42,6 +43,37 @@ def cpu_baseline(recs, k, budget_bases=150_000_000):
     dt = time.perf_counter() - t0
     return {"value": round(len(sym) / dt / 1e9, 6), "unit": "Gbp/s", "cores": 1, "kind": "port",
             "sample": f"first {len(sample[0])} bases of record 0 of the workload, k={k}, {dt:.1f} s"}
+
+
+def cpu_reference(recs, k, budget_bases=10_000_000):
+    """The reference's OWN stage functions (oracle/_ref/ref_driver: mySort ... insertCase3 compiled from the reference
+    sources where they lie; only the Jellyfish dump in front of them is supplied by the oracle's counter) on a short
+    prefix, with the reference's default of 8 threads.  None where the binary was not built."""
+    import shutil
+    import subprocess
+    import tempfile
+    from debwt_amd import fasta
+    driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(driver):
+        return None
+    d = tempfile.mkdtemp(prefix="debwt_ref_")
+    try:
+        sample = np.ascontiguousarray(recs[0][:budget_bases])
+        fa, out = os.path.join(d, "in.fa"), os.path.join(d, "OUT")
+        fasta.write_fasta(fa, [sample])
+        threads = min(8, os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        p = subprocess.run([driver, d, fa, out, str(k), str(threads)], capture_output=True, text=True, timeout=600)
+        dt = time.perf_counter() - t0
+        if p.returncode:
+            return None
+        return {"value": round((len(sample) + 1) / dt / 1e9, 6), "unit": "Gbp/s", "cores": threads, "kind": "reference",
+                "sample": f"first {len(sample)} bases of record 0 of the workload, k={k}, {dt:.1f} s (includes writing and "
+                          "parsing the k-mer dump that stands in for Jellyfish)"}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -148,6 +180,7 @@ def main():
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(recs, args.k)
+            line["cpu_reference"] = cpu_reference(recs, args.k)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -1,12 +1,12 @@
 // radix_sort.hip -- 8-bit LSD radix sort of 64-bit keys for gfx950 (wave64).
 //
 // Replaces the reference's edge sort (src/mySort.c:98-176, 203-238, 371-401).  Per pass:
-//   algo 1:  rs_hist (LDS histogram per chunk) -> rs_scan (one workgroup) -> rs_scatter
-//   algo 2:  rs_onesweep (chunk histograms of all passes up front, then one read + one write per pass,
-//            tile prefixes by decoupled look-back over agent-scope status words)
-// rs_scatter / rs_onesweep rank a tile of RS_TILE keys per iteration: wave-striped coalesced loads,
-// per-wave digit matching with ballots, per-wave LDS counters, a 256-wide digit scan, staging of the
-// tile in LDS in digit order, then coalesced stores of each digit's run.
+//   rs_hist (LDS histogram per chunk of consecutive tiles) -> rs_scan_* (digit-major exclusive scan) -> rs_scatter
+// rs_scatter ranks a tile of RS_TILE keys per iteration: coalesced loads (or keys rolled off the staged 2-bit text in
+// the first pass), per-wave digit matching through LDS peer masks, per-wave counters, a 256-wide digit scan, staging
+// of the tile in LDS in digit order, and stores of whole 128-byte lines out of per-digit carries.
+// The hybrid sort (algo 3, default) runs only the top digits that way and finishes every prefix bucket in registers
+// (rs_local_kernel); algo 1 runs all digits by LSD passes.
 #include "radix_sort.h"
 
 #include <algorithm>
@@ -80,21 +80,6 @@ __device__ __forceinline__ void rs_stage_text(const TextKeySrc &ts, u64 p0, Text
     st.tpos = wfirst << 5; st.spos = sfirst << 6;
     lds_barrier();
 }
-// key of tile item idx (text position ts.pos0 + idx) from the staged words
-__device__ __forceinline__ bool rs_staged_key(const TextKeySrc &ts, const TextStage &st, u64 idx, u64 end, u64 *key) {
-    *key = ~0ull;
-    if (idx >= end) return false;
-    idx += ts.pos0;
-    u64 sw = sep_window(st.ssep, idx - st.spos);
-    if (sw & ((1ull << ts.K) - 1ull)) return false;                       // window holds a separator: no node
-    u64 node = text_window(st.stext, idx - st.tpos) >> (64 - 2 * ts.K);
-    u32 pred = idx ? text_symbol(st.stext, idx - 1 - st.tpos) : 3u;       // 'T' stands at separators
-    u64 k = (node << 2) | pred;
-    if (k < ts.key_lo || (ts.key_hi && k >= ts.key_hi)) return false;     // not this shard's prefix range
-    *key = k;
-    return true;
-}
-
 // N consecutive tile items from idx0 on: the 64 symbols that start one symbol before the first item and the
 // separator bits are fetched once, the window rolls (every shift is a compile-time constant), so a key costs a
 // few ALU operations instead of five LDS reads.  Returns the mask of items that are keys.

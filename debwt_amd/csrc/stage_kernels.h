@@ -234,22 +234,6 @@ struct ClassifyFlagsF {
     ClassifyCommon c;
     int K;
     u8 *cf;
-    __device__ void count2(u64 e, u32 *a, u32 *b) const {
-        // fast path: a (K-1)-prefix group of one key is one node with one predecessor: it can only be
-        // multi-in as a record start, and it contributes no multi-out fact
-        const u64 k = c.dk[e], W = k >> 4;
-        const bool alone = (e == 0 || (c.dk[e - 1] >> 4) != W) && (e + 1 >= c.D || (c.dk[e + 1] >> 4) != W);
-        u32 mi, mo;
-        if (alone) {
-            mi = ((k & 3) == 3 && c.is_head(k >> 2)) ? 1u : 0u;
-            mo = 0;
-        } else {
-            mi = eval_multi_in(c, e, nullptr) ? 1u : 0u;
-            mo = eval_multi_out(c, K, e, nullptr);
-        }
-        cf[e] = (u8)(mi | (mo << 1));
-        *a = mi; *b = mo;
-    }
 };
 // The same sweep as a kernel of its own: a thread takes 4 consecutive distinct keys with two 16-byte loads, the
 // keys before and behind come from the neighbouring lanes; a key whose (K-1)-prefix group is just itself (the bulk:
