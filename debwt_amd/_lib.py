@@ -64,6 +64,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C debwt_amd/csrc` "
                            "(or __graft_entry__.build()); there is no CPU fallback")
+    try:
+        import torch  # noqa: F401  (its bundled HIP runtime must be the one in the process, see __graft_entry__.build)
+    except Exception:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)
     L.debwt_create.restype = ctypes.c_int
