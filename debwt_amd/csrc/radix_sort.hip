@@ -496,6 +496,11 @@ __global__ __launch_bounds__(NT) void rs_local_kernel(u64 *__restrict__ keys, u6
     if (s >= e) return;
     const u64 cnt64 = e - s;
     if (cnt64 > CAP) {
+        // a stretch that does not fit is often one long run of equal keys (a repeat family's k-mer in a collection of
+        // many genomes): nothing to do when it is in order already
+        u32 bad = 0;
+        for (u64 i = s + tid; i + 1 < e && !bad; i += NT) bad = keys[i] > keys[i + 1] ? 1u : 0u;
+        if (NT == 64 ? (__ballot(bad != 0) == 0ull) : !__syncthreads_or((int)bad)) return;
         if (NT == 64) {
             // hand the stretch to the 4096-key tiles that can overlap it
             u64 t0 = s / RL_H, t1 = (e - 1) / RL_H;
@@ -516,6 +521,13 @@ __global__ __launch_bounds__(NT) void rs_local_kernel(u64 *__restrict__ keys, u6
     u64 k[KPT];
 #pragma unroll
     for (int r = 0; r < KPT; r++) k[r] = A[RL_PAD(tid * KPT + r)];
+    {   // in order already (the padding behind cnt is ~0): leave the keys where they are
+        u32 bad = 0;
+#pragma unroll
+        for (int r = 0; r + 1 < KPT; r++) bad |= k[r] > k[r + 1] ? 1u : 0u;
+        if (tid + 1 < NT) bad |= k[KPT - 1] > A[RL_PAD((tid + 1) * KPT)] ? 1u : 0u;
+        if (NT == 64 ? (__ballot(bad != 0) == 0ull) : !__syncthreads_or((int)bad)) return;
+    }
     __syncthreads();
     // Wave tiles first try a network sized for what the data looks like here: the keys arrive ordered by bucket and a
     // bucket holds ~16 keys, so after sorting every lane's 16 keys a key is at most a few lanes from its place.
