@@ -12,7 +12,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "radix_sort.h"
@@ -1319,7 +1321,10 @@ extern "C" int debwt_radix_sort_u64(debwt_ctx *c, uint64_t *d_keys, uint64_t *d_
 extern "C" int debwt_verify_inverse(const uint64_t *bwt, uint64_t n, const uint64_t *hash_rows, uint64_t nrec,
                                     uint64_t dollar_row, uint8_t *sym_out) {
     // LF(i) = C[c] + occ(c, i); '#' rows map in order to rows n-nrec.., '$' row to row n-1
-    // (src/LFsearch.c:49-166, src/insertCase3.c:141-194)
+    // (src/LFsearch.c:49-166, src/insertCase3.c:141-194).  The reference walks the whole text as one chain of n
+    // dependent steps; here every record is walked by its own thread: the walk that starts at the row of
+    // the j-th '#' suffix (row n - nrec + j) spells the record in front of that '#' backwards and stops at the row that
+    // carries the previous separator, which names the walk that precedes it in the text.
     if (!bwt || !sym_out || n < 2 || nrec < 1 || dollar_row >= n) return DEBWT_EINVAL;
     std::vector<uint8_t> L(n);
     for (uint64_t j = 0; j < n; j++) L[j] = (uint8_t)((bwt[j >> 5] >> ((31 - (j & 31)) << 1)) & 3);
@@ -1328,15 +1333,45 @@ extern "C" int debwt_verify_inverse(const uint64_t *bwt, uint64_t n, const uint6
     uint64_t C[7] = {0}, cnt[6] = {0}, seen[6] = {0};
     for (uint64_t i = 0; i < n; i++) cnt[L[i]]++;
     for (int s = 0; s < 6; s++) C[s + 1] = C[s] + cnt[s];
+    if (cnt[4] != nrec - 1 || cnt[5] != 1) return DEBWT_EINTERNAL;
     std::vector<uint64_t> lf(n);
     for (uint64_t i = 0; i < n; i++) lf[i] = C[L[i]] + seen[L[i]]++;
-    uint64_t row = n - 1;
-    sym_out[n - 1] = 5;
-    for (uint64_t p = n - 1; p > 0; p--) {
-        uint8_t s = L[row];
-        if (s == 5) return DEBWT_EINTERNAL;
-        sym_out[p - 1] = s;
-        row = lf[row];
+    // walk w (0 .. nrec-1) starts at row C[4] + w: the '#' suffixes in row order, then the '$' suffix (row n-1)
+    struct Walk { std::vector<uint8_t> rev; int64_t prev = -2; bool ok = false; };
+    std::vector<Walk> walks(nrec);
+    std::atomic<uint64_t> next_walk{0};
+    auto worker = [&]() {
+        for (;;) {
+            uint64_t w = next_walk.fetch_add(1);
+            if (w >= nrec) return;
+            Walk &wk = walks[w];
+            uint64_t row = C[4] + w;
+            for (uint64_t steps = 0; steps <= n; steps++) {
+                uint8_t sy = L[row];
+                if (sy == 5) { wk.prev = -1; wk.ok = true; break; }                    // the text's first record
+                if (sy == 4) { wk.prev = (int64_t)(lf[row] - C[4]); wk.ok = true; break; }
+                wk.rev.push_back(sy);
+                row = lf[row];
+            }
+        }
+    };
+    {
+        unsigned nt = std::max(1u, std::min<unsigned>((unsigned)std::min<uint64_t>(nrec, 64), std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(worker);
+        worker();
+        for (auto &x : th) x.join();
     }
-    return L[row] == 5 ? DEBWT_OK : DEBWT_EINTERNAL;
+    // chain the records from the last one (the '$' walk) to the first
+    uint64_t p = n;
+    int64_t w = (int64_t)nrec - 1;
+    for (uint64_t r = 0; r < nrec; r++) {
+        if (w < 0 || (uint64_t)w >= nrec || !walks[w].ok) return DEBWT_EINTERNAL;
+        const Walk &wk = walks[w];
+        if (p < wk.rev.size() + 1) return DEBWT_EINTERNAL;
+        sym_out[--p] = (r == 0) ? 5 : 4;                                               // the separator behind the record
+        for (size_t i = 0; i < wk.rev.size(); i++) sym_out[--p] = wk.rev[i];
+        w = wk.prev;
+    }
+    return (p == 0 && w == -1) ? DEBWT_OK : DEBWT_EINTERNAL;
 }
