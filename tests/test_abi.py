@@ -62,3 +62,22 @@ def test_write_outputs_format(tmp_path, oracle):
     api.write_outputs(p, w, h, d)
     assert os.path.getsize(p) == 8 * ((len(sym) + 31) // 32)                # src/insertCase3.c:115-119
     assert os.path.getsize(p + ".#") == 8 * 3 and os.path.getsize(p + ".$") == 8
+
+
+def test_verify_inverse_walks_records_in_parallel(oracle):
+    """debwt_verify_inverse (host tool, the job of the reference's dead LFsearch path, src/LFsearch.c:14-48): one walk
+    per record started from the '#' rows, chained afterwards -- against the oracle's BWT of multi-record texts."""
+    import numpy as np
+    from debwt_amd import api, synth
+    rng = np.random.default_rng(9)
+    cases = [synth.pan_genome(20000, 7), synth.pan_genome(30000, 1),
+             [rng.integers(0, 4, size=int(L)).astype(np.uint8) for L in (40, 33, 1000, 77, 5000, 34)]]
+    for recs in cases:
+        sym = oracle.sym_from_codes(recs)
+        w, h, d, _ = oracle.build_bwt(sym, 32)
+        rc, inv = api.verify_inverse(w, len(sym), h, d)
+        assert rc == 0 and np.array_equal(inv, sym)
+        # a damaged BWT does not close
+        w2 = w.copy(); w2[len(w2) // 2] ^= np.uint64(1 << 20)
+        rc2, inv2 = api.verify_inverse(w2, len(sym), h, d)
+        assert rc2 != 0 or not np.array_equal(inv2, sym)
