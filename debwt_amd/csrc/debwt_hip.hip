@@ -1318,6 +1318,22 @@ extern "C" int debwt_radix_sort_u64(debwt_ctx *c, uint64_t *d_keys, uint64_t *d_
     return DEBWT_OK;
 }
 
+extern "C" int debwt_special_digest(const uint64_t *packed, uint64_t n, const uint64_t *sep, uint64_t nrec, int k,
+                                    uint64_t digest[4]) {
+    if (!packed || !sep || !digest || nrec == 0 || k < 12 || k > 32) return DEBWT_EINVAL;
+    SpecialTables t;
+    build_special_tables(packed, n, sep, nrec, k - 1, &t);
+    auto mix = [](uint64_t h, uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h * 0xBF58476D1CE4E5B9ull; };
+    uint64_t d[4] = {1, 2, 3, 4};
+    for (uint64_t v : t.pos) d[0] = mix(d[0], v);
+    for (size_t i = 0; i < t.key.size(); i++) d[1] = mix(mix(d[1], t.key[i]), t.chr[i]);
+    for (uint64_t v : t.branch) d[2] = mix(d[2], v);
+    for (uint64_t v : t.head_keys) d[3] = mix(d[3], v);
+    for (uint64_t v : t.tail_facts) d[3] = mix(d[3], v);
+    for (int i = 0; i < 4; i++) digest[i] = d[i];
+    return DEBWT_OK;
+}
+
 extern "C" int debwt_verify_inverse(const uint64_t *bwt, uint64_t n, const uint64_t *hash_rows, uint64_t nrec,
                                     uint64_t dollar_row, uint8_t *sym_out) {
     // LF(i) = C[c] + occ(c, i); '#' rows map in order to rows n-nrec.., '$' row to row n-1

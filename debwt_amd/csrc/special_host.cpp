@@ -2,6 +2,10 @@
 #include "special_host.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <functional>
+#include <thread>
 
 namespace {
 
@@ -53,6 +57,29 @@ struct Text {
     }
 };
 
+// Host threads for the module: the reference sorts the N*K special suffixes with one qsort; collections of many
+// records (contigs, reads) make that the long pole, so above a few thousand suffixes the work is cut into chunks.
+// DEBWT_SPECIAL_THREADS / DEBWT_SPECIAL_PAR_MIN override the thread count / the threshold (tests).
+unsigned special_threads(uint64_t NS) {
+    const char *e = getenv("DEBWT_SPECIAL_PAR_MIN");
+    const uint64_t par_min = e ? strtoull(e, nullptr, 10) : (1ull << 14);
+    if (NS < par_min) return 1;
+    const char *t = getenv("DEBWT_SPECIAL_THREADS");
+    unsigned nt = t ? (unsigned)atoi(t) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return std::max(1u, nt);
+}
+
+// fn(chunk) for chunk = 0 .. nchunks-1 on nt threads (dynamic hand-out)
+void parallel_chunks(unsigned nt, uint64_t nchunks, const std::function<void(uint64_t)> &fn) {
+    if (nt <= 1 || nchunks <= 1) { for (uint64_t c = 0; c < nchunks; c++) fn(c); return; }
+    std::atomic<uint64_t> next{0};
+    auto worker = [&]() { for (;;) { uint64_t c = next.fetch_add(1); if (c >= nchunks) return; fn(c); } };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(worker);
+    worker();
+    for (auto &x : th) x.join();
+}
+
 }  // namespace
 
 void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep, uint64_t nrec, int K,
@@ -66,9 +93,12 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
     // at a fraction of its comparisons.
     struct Item { uint64_t key, pos; };
     std::vector<Item> items(NS);
-    {
-        uint64_t m = 0;
-        for (uint64_t r = 0; r < nrec; r++)
+    const unsigned nt = special_threads(NS);
+    const uint64_t nchunks = nt > 1 ? (uint64_t)nt * 4 : 1;
+    auto cut = [&](uint64_t total, uint64_t c) { return total / nchunks * c + std::min<uint64_t>(c, total % nchunks); };
+    parallel_chunks(nt, nchunks, [&](uint64_t c) {
+        for (uint64_t r = cut(nrec, c); r < cut(nrec, c + 1); r++) {
+            uint64_t m = r * (uint64_t)K;
             for (int d = K - 1; d >= 0; d--) {
                 uint64_t p = sep[r] - (uint64_t)d;
                 // key: the d bases, then 'T' up to K symbols (src/collect#$.c:428-446)
@@ -78,16 +108,38 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
                 items[m].pos = p;
                 m++;
             }
+        }
+    });
+    // by key (ties by position, so that the result is the same for every thread count): chunks sorted on their
+    // own, then merged pairwise
+    auto by_key = [](const Item &a, const Item &b) { return a.key != b.key ? a.key < b.key : a.pos < b.pos; };
+    parallel_chunks(nt, nchunks, [&](uint64_t c) { std::sort(items.begin() + cut(NS, c), items.begin() + cut(NS, c + 1), by_key); });
+    for (uint64_t width = 1; width < nchunks; width *= 2) {
+        const uint64_t pairs = (nchunks + 2 * width - 1) / (2 * width);
+        parallel_chunks(nt, pairs, [&](uint64_t q) {
+            const uint64_t a = q * 2 * width, b = std::min(nchunks, a + width), e = std::min(nchunks, a + 2 * width);
+            if (b < e) std::inplace_merge(items.begin() + cut(NS, a), items.begin() + cut(NS, b), items.begin() + cut(NS, e), by_key);
+        });
     }
-    std::sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.key < b.key; });
+    // runs of equal keys: true suffix order inside each (independent of each other)
+    std::vector<uint64_t> runs;                      // starts of the runs of length > 1
     for (uint64_t i = 0; i < NS;) {
         uint64_t j = i + 1;
         while (j < NS && items[j].key == items[i].key) j++;
-        if (j - i > 1)
-            std::sort(items.begin() + i, items.begin() + j,
-                      [&](const Item &a, const Item &b) { return a.pos != b.pos && T.less(a.pos, b.pos); });
+        if (j - i > 1) runs.push_back(i);
         i = j;
     }
+    const uint64_t rchunks = nt > 1 ? std::min<uint64_t>(runs.size(), (uint64_t)nt * 16) : 1;
+    parallel_chunks(nt, rchunks ? rchunks : 0, [&](uint64_t c) {
+        const uint64_t r0 = runs.size() / rchunks * c + std::min<uint64_t>(c, runs.size() % rchunks);
+        const uint64_t r1 = runs.size() / rchunks * (c + 1) + std::min<uint64_t>(c + 1, runs.size() % rchunks);
+        for (uint64_t r = r0; r < r1; r++) {
+            uint64_t i = runs[r], j = i + 1;
+            while (j < NS && items[j].key == items[i].key) j++;
+            std::sort(items.begin() + i, items.begin() + j,
+                      [&](const Item &a, const Item &b) { return a.pos != b.pos && T.less(a.pos, b.pos); });
+        }
+    });
     std::vector<uint64_t> order(NS);
     out->key.resize(NS);
     out->chr.resize(NS);
@@ -100,17 +152,27 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
 
     // special branches (src/collect#$.c:534-598)
     out->branch.clear();
-    for (uint64_t i = 0; i < NS;) {
-        uint64_t j = i + 1;
-        while (j < NS && T.same_window(order[i], order[j], K)) j++;
-        if (j - i >= 2) {
-            bool differ = false;
-            for (uint64_t q = i + 1; q < j; q++)
-                if (T.base(order[q] + K) != T.base(order[i] + K)) differ = true;
-            if (differ)
-                for (uint64_t q = i; q < j; q++) out->branch.push_back(order[q]);
-        }
-        i = j;
+    {
+        // groups of equal windows are consecutive in `order`; a chunk takes the groups that START inside it
+        std::vector<std::vector<uint64_t>> part(nchunks);
+        parallel_chunks(nt, nchunks, [&](uint64_t c) {
+            uint64_t i = cut(NS, c);
+            const uint64_t end = cut(NS, c + 1);
+            while (i < end && i > 0 && T.same_window(order[i - 1], order[i], K)) i++;      // inside a group of the chunk before
+            while (i < end) {
+                uint64_t j = i + 1;
+                while (j < NS && T.same_window(order[i], order[j], K)) j++;
+                if (j - i >= 2) {
+                    bool differ = false;
+                    for (uint64_t q = i + 1; q < j; q++)
+                        if (T.base(order[q] + K) != T.base(order[i] + K)) differ = true;
+                    if (differ)
+                        for (uint64_t q = i; q < j; q++) part[c].push_back(order[q]);
+                }
+                i = j;
+            }
+        });
+        for (auto &v : part) out->branch.insert(out->branch.end(), v.begin(), v.end());
     }
     std::sort(out->branch.begin(), out->branch.end());
 

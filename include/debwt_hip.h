@@ -207,6 +207,12 @@ int debwt_kmer_count_sorted(debwt_ctx *ctx, uint64_t *kmers, uint64_t *counts, u
 int debwt_radix_sort_u64(debwt_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t count, int key_bits,
                          float *ms_per_pass);
 
+/* Host-only: checksums of the special-region tables (`collect`'s specialSA / specialBwt / specialBranch / head / tail
+ * tables, src/collect#$.c:118-157,348-602) that debwt_kmer_sort_rle builds on host threads for the loaded text layout;
+ * digest[0..3] = order of the special suffixes, their keys + BWT symbols, the special branches, the head/tail nodes.
+ * Lets tests compare the threaded module with its single-threaded run (DEBWT_SPECIAL_THREADS / DEBWT_SPECIAL_PAR_MIN). */
+int debwt_special_digest(const uint64_t *packed, uint64_t n, const uint64_t *sep, uint64_t nrec, int k, uint64_t digest[4]);
+
 /* Verification tool standing in for the dead LFsearch path (src/LFsearch.c:14-48): inverse BWT
  * by LF walk on the host from a fetched result; writes the n symbols (0..5).  Returns 0 when the
  * walk closes. */

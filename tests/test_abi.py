@@ -81,3 +81,35 @@ def test_verify_inverse_walks_records_in_parallel(oracle):
         w2 = w.copy(); w2[len(w2) // 2] ^= np.uint64(1 << 20)
         rc2, inv2 = api.verify_inverse(w2, len(sym), h, d)
         assert rc2 != 0 or not np.array_equal(inv2, sym)
+
+
+def test_special_region_module_threads_agree(monkeypatch):
+    """The host special-region module (src/collect#$.c:118-157,348-602) cut over threads gives the tables of its
+    single-threaded run: many short records from a small motif pool, so that special suffixes tie in long runs."""
+    import ctypes
+    import numpy as np
+    from debwt_amd import _lib, api
+    rng = np.random.default_rng(4)
+    pool = [rng.integers(0, 4, size=150).astype(np.uint8) for _ in range(30)]
+    recs = []
+    for _ in range(3000):
+        p = pool[int(rng.integers(0, len(pool)))]
+        off, L = int(rng.integers(0, 30)), int(rng.integers(40, 120))
+        x = p[off:off + L].copy()
+        flip = rng.random(L) < 0.02
+        x[flip] = rng.integers(0, 4, size=int(flip.sum()))
+        recs.append(x)
+    words, n, sep = api.pack_records(recs)
+    L_ = _lib.lib()
+    p64 = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+    def digest(threads, k):
+        monkeypatch.setenv("DEBWT_SPECIAL_THREADS", str(threads))
+        monkeypatch.setenv("DEBWT_SPECIAL_PAR_MIN", "0")
+        out = np.zeros(4, dtype=np.uint64)
+        assert L_.debwt_special_digest(p64(words), n, p64(sep), len(sep), k, p64(out)) == 0
+        return out.tolist()
+
+    for k in (32, 16):
+        ref = digest(1, k)
+        assert digest(3, k) == ref and digest(8, k) == ref
