@@ -152,7 +152,7 @@ def main():
         achieved = 16.0 * keys / (mean_pass_ms * 1e-3) / 1e9 if mean_pass_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.workload == "chr1_250M" and args.k == 32:      # the PMC passes were run on this workload
             try:
                 traffic = json.load(open(pmc)).get("rs_scatter_bytes_per_launch")
             except Exception:
