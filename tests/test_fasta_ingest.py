@@ -103,3 +103,22 @@ def test_golden_fasta_files_pack_like_the_python_reader():
             continue
         path = os.path.join(GOLDEN, e["name"] + ".fa")
         _check(path, fasta.read_fasta(path)[1], 4)
+
+
+def test_pack_fasta_no_trailing_newline_and_empty_lines_at_end(tmp_path, recs):
+    p = str(tmp_path / "n.fa")
+    with open(p, "wb") as f:
+        for i, r in enumerate(recs[:5]):
+            f.write(b">r%d\n" % i + bytes(ASC[c] for c in r) + (b"" if i == 4 else b"\n"))
+    _check(p, recs[:5], 3)
+    with open(p, "ab") as f:
+        f.write(b"\n\n\n")
+    _check(p, recs[:5], 3)
+
+
+def test_pack_fasta_empty_record_is_an_error(tmp_path):
+    p = str(tmp_path / "e.fa")
+    open(p, "wb").write(b">a\n" + b"ACGT" * 20 + b"\n>empty\n>b\n" + b"ACGT" * 20 + b"\n")
+    with pytest.raises(api.DebwtError) as ei:
+        api.pack_fasta(p, 2)
+    assert "Length <= 32" in str(ei.value)
