@@ -68,7 +68,8 @@ struct debwt_ctx {
     u64 Mctx = 0;               // node instances of this context (sum over its ranges)
     u64 nfacts_acc = 0;         // facts accumulated over the ranges
     bool local_done = false;    // classify_local already ran per range (multi-range build)
-    DevBuf blk_j0, blk_freq, blk_start, facts_acc, large_tmp, blue_tmp, sub_start, sub_j0, sub_freq, sub_depth;
+    bool plan_valid = false;    // `ranges` holds the cuts of the loaded text (several ranges)
+    DevBuf blk_j0, blk_freq, blk_start, facts_acc, large_tmp, blue_tmp, sub_start, sub_j0, sub_freq, sub_depth, range_hist;
     // k-mer-prefix shard of a multi-GPU build (world == 1: the whole key space)
     int shard_rank = 0, shard_world = 1;
     u64 Mfull = 0;              // node instances of the whole text
@@ -263,7 +264,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
                      &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
-                     &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0, &c->sub_freq, &c->sub_depth};
+                     &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0, &c->sub_freq, &c->sub_depth, &c->range_hist};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -292,7 +293,7 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     c->n = n; c->nrec = nrec; c->M = M; c->Mfull = M; c->Mctx = M; c->NS = nrec * (uint64_t)K;
     c->shard_rank = 0; c->shard_world = 1; c->key_lo = c->key_hi = 0; c->Mbase = 0; c->qbase = 0;
     c->keys_imported = false;
-    c->ranges.clear();
+    c->ranges.clear(); c->plan_valid = false;
     size_t tw = (size_t)((n + 63) >> 5) + 2, bw = (size_t)(n >> 6) + 3;
     ENSURE(c, c->text, tw * 8);
     ENSURE(c, c->sepbits, bw * 8);
@@ -342,6 +343,7 @@ extern "C" int debwt_load_fasta(debwt_ctx *c, const char *path, int threads) {
 extern "C" int debwt_set_range_cap(debwt_ctx *c, uint64_t max_instances) {
     if (!c || max_instances < 4096) return DEBWT_EINVAL;
     c->range_cap = std::min<uint64_t>(max_instances, 0xFFFFFFF0ull - 1);
+    c->plan_valid = false;
     return DEBWT_OK;
 }
 
@@ -381,8 +383,14 @@ extern "C" int debwt_load_ascii(debwt_ctx *c, const char *seq, const uint64_t *r
 // reference balances its sort threads on, src/mySort.c:98-110).  A sharded or key-importing context has exactly
 // the range it was given.
 static int plan_ranges(debwt_ctx *c) {
-    c->ranges.clear();
     c->local_done = false;
+    if (c->plan_valid && c->ranges.size() > 1 && c->shard_world == 1 && !c->keys_imported) {
+        // the census of this text was taken by an earlier build: same cuts
+        for (auto &r : c->ranges) { r.Q = r.qbase = r.B = r.Bbase = r.s0 = r.s1 = 0; }
+        c->Mctx = c->Mfull;
+        return DEBWT_OK;
+    }
+    c->ranges.clear();
     debwt_ctx::KeyRange r{};
     u64 range_cap = c->range_cap;
     if (!range_cap) {
@@ -436,6 +444,7 @@ static int plan_ranges(debwt_ctx *c) {
     push(lo, SHARD_BINS, acc, base);
     if (total != c->Mfull) { c->err = "prefix census differs from the number of node instances"; return DEBWT_EINTERNAL; }
     c->Mctx = c->Mfull;
+    c->plan_valid = true;
     return DEBWT_OK;
 }
 
@@ -464,10 +473,31 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     // the keys (node << 2 | pred) are read off the text inside the first radix pass: no unsorted key array
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    // several ranges: the chunk histograms of every range's first pass from ONE scan of the text
+    const bool shared_hist = P > 1 && P <= RS_MAX_RANGES && !c->keys_imported && c->shard_world == 1;
+    if (shared_hist) {
+        const int kb = 2 * c->cfg.k;
+        std::vector<u8> rob(SHARD_BINS, 0xFF);
+        int shifts[RS_MAX_RANGES];
+        for (size_t i = 0; i < P; i++) {
+            const u32 lo = (u32)(c->ranges[i].key_lo >> (kb - 12));
+            const u32 hi = c->ranges[i].key_hi ? (u32)(c->ranges[i].key_hi >> (kb - 12)) : SHARD_BINS;
+            for (u32 b = lo; b < hi; b++) rob[b] = (u8)i;
+            shifts[i] = radix_first_shift(c->ranges[i].M, kb, c->cfg.sort_algo);
+        }
+        ENSURE(c, c->dest_tab, SHARD_BINS);
+        ENSURE(c, c->range_hist, P * radix_text_hist_stride() * sizeof(u32));
+        HIPCHK(c, hipMemcpyAsync(c->dest_tab.p, rob.data(), SHARD_BINS, hipMemcpyHostToDevice, c->stream));
+        TextKeySrc all{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, 0, 0, 0, nullptr};
+        hipError_t e = radix_text_hist_ranges(c->stream, all, c->dest_tab.as<u8>(), kb, shifts, (int)P, c->range_hist.as<u32>());
+        if (e != hipSuccess) { c->err = std::string("range histograms: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // rob is host memory
+    }
     for (size_t i = 0; i < P; i++) {
         debwt_ctx::KeyRange &r = c->ranges[i];
         c->key_lo = r.key_lo; c->key_hi = r.key_hi; c->M = r.M;
-        TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, c->key_lo, c->key_hi};
+        TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, c->key_lo, c->key_hi, 0,
+                      shared_hist ? c->range_hist.as<u32>() + i * radix_text_hist_stride() : nullptr};
         // exchange mode of a sharded build: the shard's keys are already in keysA (alltoallv), sort them from there
         rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), r.M, 2 * c->cfg.k, &c->sk, i == 0,
                        c->keys_imported ? nullptr : &ts, true);
@@ -972,7 +1002,7 @@ extern "C" int debwt_shard_begin(debwt_ctx *c, int rank, int world) {
     if (c->stage < ST_LOADED) return DEBWT_ESTATE;
     c->shard_rank = rank; c->shard_world = world; c->keys_imported = false;
     c->key_lo = c->key_hi = 0; c->M = c->Mctx = c->Mfull; c->Mbase = 0; c->qbase = 0; c->s0 = 0; c->s1 = c->NS;
-    c->ranges.clear();
+    c->ranges.clear(); c->plan_valid = false;
     c->stage = ST_LOADED;
     return DEBWT_OK;
 }

@@ -29,7 +29,19 @@ struct TextKeySrc {
     int K;                // node length
     u64 key_lo, key_hi;   // only keys in [key_lo, key_hi) are produced (a k-mer-prefix shard); hi = 0: no upper bound
     u64 pos0;             // item i of a pass is text position pos0 + i
+    const u32 *pre_counts;  // optional: the chunk histograms of the first pass, digit-major as rs_hist writes them
+                            // (radix_text_hist_ranges computed them for all key ranges in one scan of the text)
 };
+
+// One scan of the text for the first-pass chunk histograms of up to RS_MAX_RANGES key ranges at once: range r holds
+// the keys whose top 12 bits map to r in range_of_bin (4096 bytes, device), its first pass buckets by the digit at
+// shift[r].  counts: RS_MAX_RANGES-or-fewer blocks of radix_text_hist_stride() words, range r's histograms in block r.
+#define RS_MAX_RANGES 16
+size_t radix_text_hist_stride();
+// bit position of the digit the first pass of radix_sort_u64(n keys, key_bits, algo) buckets by
+int radix_first_shift(u64 n, int key_bits, int algo);
+hipError_t radix_text_hist_ranges(hipStream_t stream, const TextKeySrc &text, const u8 *range_of_bin, int key_bits,
+                                  const int *shift, int nranges, u32 *counts);
 
 // bucket function of a pass (see rs_digit)
 struct RsDigit {

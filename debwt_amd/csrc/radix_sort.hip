@@ -157,6 +157,36 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict
     counts[(u64)threadIdx.x * nchunks + blockIdx.x] = h[threadIdx.x];
 }
 
+// first-pass histograms of several key ranges in one scan of the text (see radix_sort.h)
+struct RangeShifts { int s[RS_MAX_RANGES]; };
+__global__ __launch_bounds__(RS_BLOCK) void rs_hist_ranges_kernel(TextKeySrc ts, u64 chunk, const u8 *__restrict__ range_of_bin,
+                                                                   int bin_shift, RangeShifts sh, int nranges,
+                                                                   u32 *__restrict__ counts, u64 stride, u32 nchunks) {
+    __shared__ u32 h[RS_MAX_RANGES][RS_RADIX];
+    __shared__ u8 rob[4096];
+    __shared__ u64 stext[RS_STEXT], ssep[RS_SSEP];
+    for (u32 i = threadIdx.x; i < RS_MAX_RANGES * RS_RADIX; i += RS_BLOCK) (&h[0][0])[i] = 0;
+    for (u32 i = threadIdx.x; i < 4096; i += RS_BLOCK) rob[i] = range_of_bin[i];
+    __syncthreads();
+    u64 beg = (u64)blockIdx.x * chunk;
+    u64 end = beg + chunk < ts.n ? beg + chunk : ts.n;
+    TextStage st{stext, ssep, 0, 0};
+    for (u64 tile = beg; tile < end; tile += RS_TILE) {
+        rs_stage_text(ts, ts.pos0 + tile, st);
+        u64 k[RS_ITEMS];
+        u32 vm = rs_staged_keys<RS_ITEMS>(ts, st, tile + (u64)threadIdx.x * RS_ITEMS, end, k);
+#pragma unroll
+        for (u32 r = 0; r < RS_ITEMS; r++)
+            if ((vm >> r) & 1u) {
+                const u32 g = rob[(u32)(k[r] >> bin_shift) & 4095u];
+                if (g < (u32)nranges) atomicAdd(&h[g][(u32)(k[r] >> sh.s[g]) & 255u], 1u);
+            }
+    }
+    __syncthreads();
+    for (int g = 0; g < nranges; g++)
+        counts[(u64)g * stride + (u64)threadIdx.x * nchunks + blockIdx.x] = h[g][threadIdx.x];
+}
+
 // exclusive scan of one digit's chunk counts in place (workgroup d <-> digit d), digit total to tot[d]
 __global__ __launch_bounds__(1024) void rs_scan_digit_kernel(u32 *__restrict__ counts, u32 nchunks,
                                                               u32 *__restrict__ tot) {
@@ -678,7 +708,10 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
         rs_plan(from_text ? text->n : n, &nchunks, &chunk);
         u32 *digit_tot = ws.counts + (size_t)RS_RADIX * RS_MAXCHUNKS;
         if (from_text) {
-            rs_hist_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, text->n, chunk, dg, ws.counts, nchunks);
+            if (text->pre_counts)
+                (void)hipMemcpyAsync(ws.counts, text->pre_counts, (size_t)RS_RADIX * nchunks * sizeof(u32), hipMemcpyDeviceToDevice, stream);
+            else
+                rs_hist_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, text->n, chunk, dg, ws.counts, nchunks);
             rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
             rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
             if (shift >= 32) rs_scatter_kernel<1, 0, 1><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
@@ -699,6 +732,31 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
         u64 *t = src; src = dst; dst = t;
     }
     return src;
+}
+
+size_t radix_text_hist_stride() { return (size_t)RS_RADIX * RS_MAXCHUNKS; }
+
+int radix_first_shift(u64 n, int key_bits, int algo) {
+    algo &= 15;
+    if (key_bits > 64) key_bits = 64;
+    int T = 0;
+    while ((n >> (8 * T)) > 16 && T < 4) T++;
+    if (algo != 3 || T == 0 || key_bits - 8 * T < 1) return 0;
+    return key_bits - 8 * T;
+}
+
+hipError_t radix_text_hist_ranges(hipStream_t stream, const TextKeySrc &text, const u8 *range_of_bin, int key_bits,
+                                  const int *shift, int nranges, u32 *counts) {
+    if (nranges < 1 || nranges > RS_MAX_RANGES) return hipErrorInvalidValue;
+    u32 nchunks; u64 chunk;
+    rs_plan(text.n, &nchunks, &chunk);
+    RangeShifts sh{};
+    for (int i = 0; i < nranges; i++) sh.s[i] = shift[i];
+    TextKeySrc all = text;
+    all.key_lo = 0; all.key_hi = 0; all.pre_counts = nullptr;            // every key: the range comes from the bin table
+    rs_hist_ranges_kernel<<<nchunks, RS_BLOCK, 0, stream>>>(all, chunk, range_of_bin, key_bits - 12, sh, nranges, counts,
+                                                             (u64)radix_text_hist_stride(), nchunks);
+    return hipGetLastError();
 }
 
 u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
