@@ -285,7 +285,7 @@ __device__ __forceinline__ void rs_clear_rank_state(ScShared &sh) {
 // FULL: every item of the tile is a key (the common case of the array passes): no per-item predicates.
 template <int FIXED0, int FULL>
 __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmask, const RsDigit &dg, ScShared &sh,
-                                            u32 oalign) {
+                                            u32 oalign, u32 nrounds = SC_ITEMS) {
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     u64 *wmask = sh.skeys + w * RS_RADIX;
     // counters and peer masks are clear: rs_clear_rank_state ran during the previous tile's flush
@@ -293,6 +293,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
     const u64 lbit = 1ull << lane;
 #pragma unroll
     for (int r = 0; r < SC_ITEMS; r++) {
+        if (!FULL && (u32)r >= nrounds) { pk[r] = 0; continue; }       // (workgroup-uniform) no keys in this round
         const bool valid = FULL || ((vmask >> r) & 1u);
         const u32 d = rs_digit<FIXED0>(dg, key[r]);
         if (valid) __hip_atomic_fetch_or(&wmask[d], lbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -448,6 +449,106 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
         const u32 p = i * SC_NT + tid, d = p / SC_LINE, s = p % SC_LINE;
         const u32 cc = sh.cc[d];
         if (s < cc) out[sh.run[d] - cc + s] = sh.carry[d][s];
+    }
+}
+
+// First pass of a key RANGE (a build in key ranges, or a shard that scans the whole text): only a fraction of the
+// positions yields a key of the range, but a tile costs nearly the same whatever it holds -- its barrier-separated
+// phases are latency-bound with two workgroups per CU.  So the keys of consecutive position tiles are collected (in the
+// upper half of skeys, which the peer masks do not use) until the next tile would not fit, and ranked and flushed
+// together; a position tile that alone holds more than half a tile of keys is ranked as it is.
+template <int HI>
+__global__ __launch_bounds__(SC_NT) __attribute__((amdgpu_waves_per_eu(RS_WAVES_EU, RS_WAVES_EU)))
+void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 chunk, RsDigit dg,
+                              const u32 *__restrict__ offsets, const u32 *__restrict__ digit_base, u32 nchunks) {
+    constexpr int DG = HI ? 2 : 1;
+    constexpr u32 CAP = RS_TILE / 2;
+    __shared__ ScShared sh;
+    __shared__ u64 stext[RS_STEXT], ssep[RS_SSEP];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid < RS_RADIX) {
+        sh.run[tid] = offsets[(u64)tid * nchunks + blockIdx.x] + digit_base[tid];
+        sh.cc[tid] = 0;
+    }
+    const u32 oalign = (u32)(reinterpret_cast<uintptr_t>(out) >> 3) & (SC_LINE - 1u);
+    const u64 beg = (u64)blockIdx.x * chunk;
+    const u64 end = beg + chunk < n ? beg + chunk : n;
+    TextStage st{stext, ssep, 0, 0};
+    rs_clear_rank_state(sh);
+    lds_barrier();
+    u64 *dense = sh.skeys + CAP;
+    u64 pos = beg;
+    u32 ndense = 0;                               // keys collected in dense[]
+    u64 pend[SC_ITEMS];                           // the position tile that did not fit (this thread's 8 positions)
+    u32 pend_mask = 0, pend_off = 0, pend_total = 0;
+    bool have_pend = false;
+    for (;;) {
+        while (!have_pend && pos < end) {
+            rs_stage_text(ts, ts.pos0 + pos, st);
+            pend_mask = rs_staged_keys<SC_ITEMS>(ts, st, pos + (u64)tid * SC_ITEMS, end, pend);
+            pos += RS_TILE;
+            const u32 mine = (u32)__popc(pend_mask);
+            const u32 incl = wave_scan_incl(mine);
+            if (lane == 63) sh.scan_tmp[w] = incl;
+            lds_barrier();
+            pend_off = incl - mine; pend_total = 0;
+#pragma unroll
+            for (u32 i = 0; i < SC_WAVES; i++) { const u32 t = sh.scan_tmp[i]; if (i < w) pend_off += t; pend_total += t; }
+            lds_barrier();                                         // scan_tmp is free again
+            have_pend = true;
+            if (ndense + pend_total <= CAP) {
+                u32 o = ndense + pend_off;
+#pragma unroll
+                for (int r = 0; r < SC_ITEMS; r++)
+                    if ((pend_mask >> r) & 1u) dense[o++] = pend[r];
+                ndense += pend_total;
+                have_pend = false;
+            }
+        }
+        if (ndense == 0 && !have_pend) break;
+        u64 key[SC_ITEMS];
+        int tot;
+        if (ndense == 0) {
+            // the pending position tile holds more than CAP keys: rank it where it is
+            tot = (int)rs_rank_tile<DG, 0>(pend, pend_mask, dg, sh, oalign);
+            have_pend = false;
+        } else {
+            lds_barrier();                                         // every append is visible
+            const u32 R = (ndense + SC_NT - 1) / SC_NT;           // rounds: wave w takes keys [(w*R)*64, (w*R + R)*64)
+            u32 vmask = 0;
+#pragma unroll
+            for (int r = 0; r < SC_ITEMS; r++) {
+                const u32 idx = (w * R + (u32)r) * 64u + lane;
+                const bool have = (u32)r < R && idx < ndense;
+                key[r] = have ? dense[idx] : ~0ull;
+                vmask |= (have ? 1u : 0u) << r;
+            }
+            lds_barrier();                                         // the staging step writes skeys
+            tot = (int)rs_rank_tile<DG, 0>(key, vmask, dg, sh, oalign, R);
+            ndense = 0;
+        }
+        rs_flush_heads(sh, out);
+        u64 k[SC_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SC_ITEMS; r++) k[r] = sh.skeys[tid + r * SC_NT];
+        lds_barrier();
+        rs_flush_body<DG>(sh, dg, out, k, tot);
+        rs_clear_rank_state(sh);
+        lds_barrier();
+        if (have_pend && pend_total <= CAP) {                      // the tile that did not fit opens the next collection
+            u32 o = pend_off;
+#pragma unroll
+            for (int r = 0; r < SC_ITEMS; r++)
+                if ((pend_mask >> r) & 1u) dense[o++] = pend[r];
+            ndense = pend_total;
+            have_pend = false;
+        }
+    }
+#pragma unroll
+    for (u32 i = 0; i < RS_RADIX * SC_LINE / SC_NT; i++) {
+        const u32 p = i * SC_NT + tid, d = p / SC_LINE, s2 = p % SC_LINE;
+        const u32 cc = sh.cc[d];
+        if (s2 < cc) out[sh.run[d] - cc + s2] = sh.carry[d][s2];
     }
 }
 
@@ -714,7 +815,10 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
                 rs_hist_kernel<1, 0><<<nchunks, RS_BLOCK, 0, stream>>>(nullptr, *text, text->n, chunk, dg, ws.counts, nchunks);
             rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
             rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
-            if (shift >= 32) rs_scatter_kernel<1, 0, 1><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
+            const bool sparse = text->key_lo || text->key_hi;                  // a key range: most positions yield nothing
+            if (sparse && shift >= 32) rs_scatter_sparse_kernel<1><<<nchunks, SC_NT, 0, stream>>>(*text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
+            else if (sparse) rs_scatter_sparse_kernel<0><<<nchunks, SC_NT, 0, stream>>>(*text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
+            else if (shift >= 32) rs_scatter_kernel<1, 0, 1><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
             else rs_scatter_kernel<1, 0, 0><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
             src = a; dst = b;
             continue;
