@@ -708,7 +708,10 @@ static int sp_prepare(debwt_ctx *c) {
     // node table: 2..4 slots per red node; prefilter: ~8 bits per red node (tuning knob: reserved = delta+8)
     int hbits = 10;
     while ((1ull << hbits) < 2 * c->R) hbits++;
-    int pb = hbits + ((c->cfg.reserved & 15) ? (c->cfg.reserved & 15) - 8 : 3);
+    // prefilter: 8 bits per red node while the bitmap stays L2-sized (2 MB), fewer -- down to 2..4 -- for larger red
+    // tables: a probe that leaves L2 costs more than the extra table lookups of a fuller bitmap (measured at 3 Gbp:
+    // 57.8 ms with 2 MB, 75.8 ms with 16 MB).  cfg.reserved & 15 = delta + 8 overrides (tuning).
+    int pb = (c->cfg.reserved & 15) ? hbits + (c->cfg.reserved & 15) - 8 : std::max(hbits, std::min(hbits + 3, 24));
     if (pb < 10) pb = 10;
     if (pb > 31 || hbits > 31) { c->err = "red table too large for 32-bit slots"; return DEBWT_ERANGE; }
     c->hbits = hbits; c->pbits = pb;

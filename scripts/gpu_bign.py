@@ -24,7 +24,7 @@ del recs
 print(f"packed in {tp:.0f}s", flush=True)
 res = {}
 for k in ((32,) if "--k32only" in sys.argv else (32, 24)):
-    d = api.DeBWT(k=k)
+    d = api.DeBWT(k=k, tune=int(__import__("os").environ.get("TUNE", "0")))
     if cap: d.set_range_cap(cap)
     t0 = time.time(); d.load_packed(words, n, sep); tl = time.time() - t0
     t0 = time.time(); d.build(); t1 = time.time() - t0      # first build allocates
