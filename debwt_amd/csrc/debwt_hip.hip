@@ -708,10 +708,13 @@ static int sp_prepare(debwt_ctx *c) {
     // node table: 2..4 slots per red node; prefilter: ~8 bits per red node (tuning knob: reserved = delta+8)
     int hbits = 10;
     while ((1ull << hbits) < 2 * c->R) hbits++;
-    // prefilter: 8 bits per red node while the bitmap stays L2-sized (2 MB), fewer -- down to 2..4 -- for larger red
-    // tables: a probe that leaves L2 costs more than the extra table lookups of a fuller bitmap (measured at 3 Gbp:
-    // 57.8 ms with 2 MB, 75.8 ms with 16 MB).  cfg.reserved & 15 = delta + 8 overrides (tuning).
-    int pb = (c->cfg.reserved & 15) ? hbits + (c->cfg.reserved & 15) - 8 : std::max(hbits, std::min(hbits + 3, 24));
+    // prefilter: 8 bits per red node; while the node table still fits the Infinity Cache (<= 256 MB) the bitmap is
+    // held at L2 size (2 MB, down to 2..4 bits per node): a probe that leaves L2 then costs more than the extra table
+    // lookups of a fuller bitmap (3 Gbp: SP stage 57.8 ms with 2 MB, 75.8 ms with 16 MB).  Beyond that a false positive
+    // is a random HBM access and the full 8 bits win again (30 Gbp: 0.93 s against 0.97 s).
+    // cfg.reserved & 15 = delta + 8 overrides (tuning).
+    int pb = (c->cfg.reserved & 15) ? hbits + (c->cfg.reserved & 15) - 8
+                                     : (hbits <= 24 ? std::max(hbits, std::min(hbits + 3, 24)) : hbits + 3);
     if (pb < 10) pb = 10;
     if (pb > 31 || hbits > 31) { c->err = "red table too large for 32-bit slots"; return DEBWT_ERANGE; }
     c->hbits = hbits; c->pbits = pb;
