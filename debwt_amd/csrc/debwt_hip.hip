@@ -58,6 +58,7 @@ struct debwt_ctx {
     u32 *h_scalars = nullptr;   // pinned read-back area
     u64 D = 0, Q = 0, Rmo = 0, R = 0, B = 0, S = 0, nlarge = 0, nfacts = 0;
     u64 rQ = 0, rB = 0, rnlarge = 0;   // blocks, blue rows, large blocks of the range just classified
+    u64 rn1024 = 0, n1024 = 0;         // blocks of 513..1024 rows (range / context)
     // Key ranges of this context, sorted and classified one after the other over the resident text (one range unless
     // the node instances exceed range_cap: "bucket streaming" for texts whose keys do not fit HBM at once).
     // D, Rmo and the buffers keysA/keysB/dk/dstart/pflag/mi_*/bstart/facts belong to the range being processed;
@@ -467,7 +468,7 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
     ENSURE(c, c->dstart, maxM * 4 + 64);
     ENSURE(c, c->pflag, maxM + 64);                      // classification byte per distinct key of a range
     ENSURE(c, c->mchar, c->Mctx + 64);
-    c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0;
+    c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0;
     const size_t P = c->ranges.size();
     u64 Dsum = 0;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -608,9 +609,16 @@ static int classify_local(debwt_ctx *c) {
     LargeBlockF fl{c->mi_freq.as<u32>(), BLUE_LDS_CAP, c->large_tmp.as<u32>()};
     if ((rc = cp_count(c, fl, Q, cp_area(c, 5), 5))) return rc;
     if ((rc = cp_emit(c, fl, Q, cp_area(c, 5)))) return rc;
+    {
+        u32 *cnt = cp_area(c, 6) + CP_MAXCHUNKS + 8;              // a free word behind the area's scan total
+        HIPCHK(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+        if (Q) k_count_blocks<<<grid_for(Q, 256), 256, 0, c->stream>>>(c->mi_freq.as<u32>(), Q, 512u, 1024u, cnt);
+        HIPCHK(c, hipMemcpyAsync(&c->h_scalars[11], cnt, 4, hipMemcpyDeviceToHost, c->stream));
+    }
     if ((rc = sync_check(c))) return rc;
     c->rB = c->h_scalars[4];
     c->rnlarge = c->h_scalars[5];
+    c->rn1024 = c->h_scalars[11];
     return DEBWT_OK;
 }
 
@@ -633,7 +641,7 @@ static int append_range(debwt_ctx *c, debwt_ctx::KeyRange &r) {
         if (r.qbase)
             k_offset_u32<<<grid_for(c->rnlarge, 256), 256, 0, c->stream>>>(c->large_q.as<u32>() + c->nlarge, c->rnlarge, (u32)r.qbase);
     }
-    c->nfacts_acc += nf; c->Q += Q; c->B += c->rB; c->nlarge += c->rnlarge;
+    c->nfacts_acc += nf; c->Q += Q; c->B += c->rB; c->nlarge += c->rnlarge; c->n1024 += c->rn1024;
     if (c->Q >= 0xFFFFFFF0ull) { c->err = "more than 2^32 multi-in blocks"; return DEBWT_ERANGE; }
     c->facts_ready = true;
     return sync_check(c);
@@ -865,9 +873,17 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
                                                                      128u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(),
                                                                      nullptr, nullptr, sub);
         u32 g2 = (u32)std::min<u64>(Q, 1u << 12);
+        // collections of many genomes put most rows into blocks of 513..1024 rows: those get a kernel of their own
+        // with half the LDS footprint (four workgroups per CU instead of two); otherwise one kernel for 513..2048
+        const bool split1024 = c->n1024 >= 1024;
+        if (split1024)
+            k_blue_refine<256, 1024, BLUE_WAVE_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
+                                                                          c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
+                                                                          (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
+                                                                          c->mchar.as<u8>(), nullptr, nullptr, sub);
         k_blue_refine<256, BLUE_LDS_CAP, BLUE_WAVE_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
                                                                       c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
-                                                                      (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
+                                                                      split1024 ? 1024u : (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
                                                                       c->mchar.as<u8>(), nullptr, nullptr, sub);
         // the queued groups: blocks of their own that start `depth` windows in (<= 128 rows from the 512 class,
         // <= 512 rows from the 2048 class)

@@ -460,6 +460,13 @@ __global__ void k_append_blocks(const u32 *__restrict__ mi_j0, const u32 *__rest
     blk_freq[q] = mi_freq[q];
     blk_start[q] = bbase + bstart[q];
 }
+// blocks of a range with lo < rows <= hi (sizes the launch plan of the blue sort)
+__global__ void k_count_blocks(const u32 *__restrict__ mi_freq, u64 Q, u32 lo, u32 hi, u32 *__restrict__ counter) {
+    u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = q < Q && mi_freq[q] > lo && mi_freq[q] <= hi;
+    const u64 m = __ballot(in);
+    if (m && (threadIdx.x & 63u) == 0) atomicAdd(counter, (u32)__popcll(m));
+}
 // large blocks of a range: local block ids -> context-wide ids
 __global__ void k_offset_u32(u32 *__restrict__ v, u64 n, u32 add) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
