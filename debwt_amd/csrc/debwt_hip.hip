@@ -438,7 +438,8 @@ static int plan_ranges(debwt_ctx *c) {
     u64 acc = 0, base = 0, total = 0;
     u32 lo = 0;
     for (u32 b = 0; b < SHARD_BINS; b++) {
-        if (hist[b] > cap) { c->err = "one 12-mer prefix bin holds more node instances than a key range may"; return DEBWT_ERANGE; }
+        // a bin above the cap becomes a range of its own (the cap is a target; 2^32 instances is the hard limit)
+        if (hist[b] >= 0xFFFFFFF0ull - (1ull << 20)) { c->err = "one 12-mer prefix bin holds 2^32 node instances or more"; return DEBWT_ERANGE; }
         if (acc && acc + hist[b] > limit) { push(lo, b, acc, base); base += acc; acc = 0; lo = b; }
         acc += hist[b]; total += hist[b];
     }

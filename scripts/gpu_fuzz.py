@@ -1,0 +1,49 @@
+"""Randomised parity run against the oracle: random small collections (the generator of tests/test_gpu_parity.py plus
+larger repeat-heavy ones), random k, random key-range caps and the alternative device paths (cursor atomics, 64-bit
+cursors, no tie-group hand-off).  python scripts/gpu_fuzz.py [cases=300] [seed=1]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+from debwt_amd import api, synth
+from oracle import oracle as O
+from test_gpu_parity import _adversarial
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time(); bad = 0
+for c in range(cases):
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        recs = _adversarial(rng)
+    elif kind == 1:
+        recs = synth.pan_genome(int(rng.integers(2000, 60000)), int(rng.integers(1, 9)), seed=int(rng.integers(1, 1 << 30)))
+    elif kind == 2:
+        unit = rng.integers(0, 4, size=int(rng.integers(34, 60))).astype(np.uint8)
+        parts = []
+        for _ in range(int(rng.integers(50, 3000))):
+            parts.append(unit); parts.append(rng.integers(0, 4, size=int(rng.integers(1, 9))).astype(np.uint8))
+        recs = [np.concatenate(parts)] + [rng.integers(0, 4, size=int(rng.integers(33, 500))).astype(np.uint8) for _ in range(int(rng.integers(0, 4)))]
+    else:
+        recs = [rng.integers(0, 4, size=int(rng.integers(33, 3000))).astype(np.uint8) for _ in range(int(rng.integers(1, 40)))]
+    k = int(rng.choice([12, 13, 16, 20, 24, 27, 31, 32]))
+    tune = int(rng.choice([0, 0, 32, 48, 128, 160]))
+    cap = int(rng.choice([0, 0, 4096, 20000, 300000]))
+    sym = O.sym_from_codes(recs)
+    ow, oh, od, ost = O.build_bwt(sym, k)
+    d = api.DeBWT(k=k, tune=tune)
+    if cap: d.set_range_cap(cap)
+    d.load_records(recs)
+    for rep in range(2):                     # a context is reusable
+        d.build()
+        w, h, dr = d.fetch()
+        ok = np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od
+        if not ok:
+            bad += 1
+            print(f"MISMATCH case {c} kind {kind} k {k} tune {tune} cap {cap} n {len(sym)} rep {rep}", flush=True)
+            break
+    d.close()
+    if c % 50 == 49: print(f"{c+1} cases, {bad} mismatches, {time.time()-t0:.0f}s", flush=True)
+print(f"done: {cases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
