@@ -357,3 +357,37 @@ def test_pan_genome_deep_tie_groups(api, oracle, tune):
     ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), 32)
     assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
     d.close()
+
+
+def test_randomised_parity_sweep(api, oracle):
+    """200 random small collections x random k x random key-range caps x the alternative device paths (cursor atomics,
+    64-bit cursors, no tie-group hand-off), two builds per context, against the oracle (scripts/gpu_fuzz.py runs the
+    same sweep for thousands of cases)."""
+    from debwt_amd import synth
+    rng = np.random.default_rng(31337)
+    for c in range(200):
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            recs = _adversarial(rng)
+        elif kind == 1:
+            recs = synth.pan_genome(int(rng.integers(2000, 30000)), int(rng.integers(1, 9)), seed=int(rng.integers(1, 1 << 30)))
+        else:
+            unit = rng.integers(0, 4, size=int(rng.integers(34, 60))).astype(np.uint8)
+            parts = []
+            for _ in range(int(rng.integers(50, 1500))):
+                parts.append(unit)
+                parts.append(rng.integers(0, 4, size=int(rng.integers(1, 9))).astype(np.uint8))
+            recs = [np.concatenate(parts), rng.integers(0, 4, size=int(rng.integers(33, 500))).astype(np.uint8)]
+        k = int(rng.choice([12, 13, 16, 20, 24, 27, 31, 32]))
+        tune = int(rng.choice([0, 0, 32, 48, 128, 160]))
+        cap = int(rng.choice([0, 0, 4096, 20000]))
+        ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), k)
+        d = api.DeBWT(k=k, tune=tune)
+        if cap:
+            d.set_range_cap(cap)
+        d.load_records(recs)
+        for rep in range(2):
+            d.build()
+            w, h, dr = d.fetch()
+            assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od, (c, kind, k, tune, cap, rep)
+        d.close()
