@@ -805,7 +805,9 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     int qbits = 1;
     while ((1ull << qbits) < c->Q) qbits++;
     const int qshift = 64 - qbits;
-    const bool route_sort = c->shard_world == 1 && c->Q > 0 && c->n < (1ull << (qshift - 3)) && !(c->cfg.reserved & 32);
+    const bool route_sort = c->shard_world == 1 && c->Q > 0 && c->n < (1ull << (qshift - 3)) &&
+                            c->B < 0xFFFFFFF0ull - (1ull << 20) &&      // the radix passes index with 32 bits
+                            !(c->cfg.reserved & 32);
     for (u64 g0 = 0; g0 < ngroups; g0 += SP_SLICE_GROUPS) {
         const u64 g1 = std::min(ngroups, g0 + SP_SLICE_GROUPS);
         if ((rc = sp_flags(c, g0, g1))) return rc;
