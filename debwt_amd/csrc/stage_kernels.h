@@ -785,6 +785,9 @@ struct BlueSub {
     u32 *count; u32 cap;                              // entries reserved / capacity
 };
 
+#ifndef BLUE_SAMPLE_SPLIT
+#define BLUE_SAMPLE_SPLIT 1
+#endif
 template <int NT, int CAP, int SPLIT>
 __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, const u64 *__restrict__ bstart,
                                                      const u32 *__restrict__ mi_freq, const u64 *__restrict__ mi_j0,
@@ -801,6 +804,10 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
     __shared__ u32 flag;
     __shared__ u32 smax;
     __shared__ u32 sub_n, sub_i, sub_base;
+    // sample-sort split of a large block (workgroup classes): 64 sampled rows, BLUE_BINS - 1 splitters
+    constexpr int SAMPLES = 64, BINS = (SPLIT && NT == 256) ? (CAP > 1024 ? 32 : 16) : 1;
+    __shared__ u64 smp_w[SAMPLES], smp_x[SAMPLES], spl_w[BINS], spl_x[BINS];
+    __shared__ u32 bin_cnt[BINS], bin_start[BINS], bin_cur[BINS];
     const u32 tid = threadIdx.x;
     if (Qdev) { u32 qd = *Qdev; Q = qd < Q ? qd : Q; }           // sub-block table: entries written so far (<= its capacity)
     for (u32 q = blockIdx.x; q < Q; q += gridDim.x) {
@@ -826,6 +833,82 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
         __syncthreads();
         bool active = (flag & (flag - 1)) != 0;               // >= 2 distinct symbols in the block
         __syncthreads();
+        bool handed = false;
+        if (BLUE_SAMPLE_SPLIT && SPLIT && NT == 256 && active && sub.cap) {
+            // Sample-sort split: instead of sorting up to 2048 rows with workgroup-wide bitonic rounds, cut the block
+            // into BINS ranges of the first 42 SP symbols (splitters from a sorted sample of 64 rows) and queue every
+            // range as a block of its own for the wave-per-block kernels -- ranges are ordered among themselves and
+            // rows with equal windows share a range, so sorting the ranges sorts the block.
+            for (u32 x = tid; x < m; x += NT) {
+                const u64 pos = (se[x] >> 4) + d0 * (2 * SP_WIN);
+                const bool live = pos < S;
+                sw[x] = live ? sp_window(spn, pos) : 0ull;
+                sx[x] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
+            }
+            if (tid < BINS) { bin_cnt[tid] = 0; bin_cur[tid] = 0; }
+            __syncthreads();
+            if (tid < SAMPLES) { const u32 i = (u32)(((u64)tid * m) / SAMPLES); smp_w[tid] = sw[i]; smp_x[tid] = sx[i]; }
+            __syncthreads();
+            if (tid < SAMPLES) {                                // rank of the sample among the samples (counting)
+                const u64 w = smp_w[tid], x2 = smp_x[tid];
+                u32 rank = 0;
+                for (u32 j = 0; j < SAMPLES; j++) {
+                    const u64 wj = smp_w[j], xj = smp_x[j];
+                    rank += (wj != w ? wj < w : (xj != x2 ? xj < x2 : j < tid)) ? 1u : 0u;
+                }
+                // splitter b = sorted sample (b+1)*SAMPLES/BINS - 1, for b < BINS-1
+                if ((rank + 1) % (SAMPLES / BINS) == 0 && (rank + 1) / (SAMPLES / BINS) <= BINS - 1) {
+                    const u32 b = (rank + 1) / (SAMPLES / BINS) - 1;
+                    spl_w[b] = w; spl_x[b] = x2;
+                }
+            }
+            __syncthreads();
+            for (u32 x = tid; x < m; x += NT) {                // range = number of splitters below the row's windows
+                const u64 w = sw[x], x2 = sx[x];
+                u32 lo = 0, hi = BINS - 1;
+                while (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    const bool below = spl_w[mid] != w ? spl_w[mid] < w : spl_x[mid] < x2;   // splitter < row
+                    if (below) lo = mid + 1; else hi = mid;
+                }
+                sg[x] = lo;
+                atomicAdd(&bin_cnt[lo], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                u32 acc = 0, big = 0, nonempty = 0;
+                for (int b = 0; b < BINS; b++) {
+                    bin_start[b] = acc; acc += bin_cnt[b];
+                    big = bin_cnt[b] > big ? bin_cnt[b] : big;
+                    nonempty += bin_cnt[b] ? 1u : 0u;
+                }
+                sub_n = 0;                                      // 0: no hand-off
+                if (big <= (u32)SPLIT) {
+                    const u32 base = atomicAdd(sub.count, nonempty);
+                    if ((u64)base + nonempty <= (u64)sub.cap) { sub_n = nonempty; sub_base = base; }
+                }
+            }
+            __syncthreads();
+            if (sub_n) {
+                for (u32 x = tid; x < m; x += NT) {
+                    const u32 b = sg[x];
+                    blue[b0 + bin_start[b] + atomicAdd(&bin_cur[b], 1u)] = se[x];
+                }
+                if (tid == 0) {
+                    u32 e = sub_base;
+                    for (int b = 0; b < BINS; b++)
+                        if (bin_cnt[b]) {
+                            sub.start[e] = b0 + bin_start[b]; sub.freq[e] = bin_cnt[b]; sub.j0[e] = j0 + bin_start[b];
+                            sub.depth[e] = (u32)d0;
+                            e++;
+                        }
+                }
+                handed = true; active = false;
+            } else {
+                for (u32 x = tid; x < m; x += NT) sg[x] = 0;   // too skewed (or the table is full): the rounds below
+            }
+            __syncthreads();
+        }
         for (u64 depth = 0; active; depth++) {
             // 1. next window of every unresolved row
             for (u32 x = tid; x < m; x += NT) {
@@ -972,11 +1055,12 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                 __syncthreads();
             }
         }
-        for (u32 x = tid; x < m; x += NT) {
-            u64 e = se[x];
-            blue[b0 + x] = e;
-            mchar[j0 + x] = (u8)(e & 15);
-        }
+        if (!handed)
+            for (u32 x = tid; x < m; x += NT) {
+                u64 e = se[x];
+                blue[b0 + x] = e;
+                mchar[j0 + x] = (u8)(e & 15);
+            }
         __syncthreads();
     }
 }
