@@ -50,7 +50,7 @@ struct debwt_ctx {
     SpecialTables special;
 
     // device buffers
-    DevBuf text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
+    DevBuf rs_rle, text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
         hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist, dest_tab, qbounds, qcursor;
     u32 *h_over = nullptr;      // pinned mirror of rs_over
@@ -193,18 +193,18 @@ RadixWorkspace radix_ws(debwt_ctx *c) {
 // main: the key sort of a range (kernels named for the profile, keys possibly read off the text); otherwise one of
 // the small auxiliary sorts.  Pass events are recorded when `record_passes`.
 int sort_keys(debwt_ctx *c, u64 *a, u64 *b, u64 count, int key_bits, u64 **result, bool record_passes,
-              const TextKeySrc *text = nullptr, bool main_sort = false) {
+              const TextKeySrc *text = nullptr, bool main_sort = false, RleSink *sink = nullptr) {
     ENSURE(c, c->rs_over, radix_over_bytes(count));      // one list entry per 4096-key tile can be oversize
     RadixWorkspace ws = radix_ws(c);
     hipError_t e = hipSuccess;
     const bool main = main_sort || record_passes;
     if (record_passes) {
         *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo, &c->ev_pass[0][0], 16,
-                                 &c->n_pass_events, &e, text);
+                                 &c->n_pass_events, &e, text, sink);
         c->st.radix_pass_keys = count;
     } else {
         *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo | (main ? 0 : 16), nullptr, 0,
-                                 nullptr, &e, text);
+                                 nullptr, &e, text, sink);
     }
     if (e != hipSuccess) { c->err = std::string("radix sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
     return DEBWT_OK;
@@ -465,6 +465,7 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
     ENSURE(c, c->keysA, maxM * 8 + 64);
     ENSURE(c, c->keysB, maxM * 8 + 64);
     ENSURE(c, c->rs_skew, (maxM / 2048 + 2) * 4);
+    ENSURE(c, c->rs_rle, radix_rle_ws_bytes(maxM));
     ENSURE(c, c->dk, maxM * 8 + 64);
     ENSURE(c, c->dstart, maxM * 4 + 64);
     ENSURE(c, c->pflag, maxM + 64);                      // classification byte per distinct key of a range
@@ -501,13 +502,18 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
         TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, c->key_lo, c->key_hi, 0,
                       shared_hist ? c->range_hist.as<u32>() + i * radix_text_hist_stride() : nullptr};
         // exchange mode of a sharded build: the shard's keys are already in keysA (alltoallv), sort them from there
+        // the bucket finish of the sort counts the distinct keys of its tiles and the encoding follows tile by tile
+        // (tune bit 8 = 256: separate count and emit passes over the sorted keys instead)
+        RleSink sink{c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase, c->rs_rle.p, &c->h_scalars[0], false};
         rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), r.M, 2 * c->cfg.k, &c->sk, i == 0,
-                       c->keys_imported ? nullptr : &ts, true);
+                       c->keys_imported ? nullptr : &ts, true, (c->cfg.reserved & 256) ? nullptr : &sink);
         if (rc) return rc;
         if (P == 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-        RleF f{c->sk, c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase};
-        if ((rc = cp_count(c, f, r.M, cp_area(c, 0), 0))) return rc;
-        if ((rc = cp_emit(c, f, r.M, cp_area(c, 0)))) return rc;
+        if (!sink.done) {
+            RleF f{c->sk, c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase};
+            if ((rc = cp_count(c, f, r.M, cp_area(c, 0), 0))) return rc;
+            if ((rc = cp_emit(c, f, r.M, cp_area(c, 0)))) return rc;
+        }
         if (i == 0) {
             // host special-region module while the GPU sorts (src/collect#$.c:118-157,348-602)
             auto t0 = std::chrono::steady_clock::now();
@@ -530,13 +536,14 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
                 s1 = r.key_hi ? (u64)(std::lower_bound(key.begin(), key.end(), r.key_hi >> 2) - key.begin()) : c->NS;
             }
             r.s0 = s0; r.s1 = s1;
-            if (s1 > s0)
-                k_special_rows<<<grid_for(s1 - s0, 256), 256, 0, c->stream>>>(
-                    c->sk, r.M, c->spkey.as<u64>() + s0, s1 - s0, r.Mbase + (s0 - c->ranges[0].s0), c->sprow.as<u64>() + s0);
         }
         if ((rc = sync_check(c))) return rc;
         c->D = c->h_scalars[0];
         Dsum += c->D;
+        if (r.s1 > r.s0)
+            k_special_rows<<<grid_for(r.s1 - r.s0, 256), 256, 0, c->stream>>>(
+                c->dk.as<u64>(), c->dstart.as<u32>(), c->D, r.M, c->spkey.as<u64>() + r.s0, r.s1 - r.s0,
+                r.Mbase + (r.s0 - c->ranges[0].s0), c->sprow.as<u64>() + r.s0);
         if (P > 1) {
             // the range's keys are gone after this iteration: classify them now
             if ((rc = classify_local(c))) return rc;

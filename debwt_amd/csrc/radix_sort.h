@@ -69,6 +69,17 @@ hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const Te
 // returns the buffer that holds the result.
 u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
                      hipError_t *err);
+// sink (optional): when the hybrid path runs, the bucket finish also counts the distinct keys of every tile it has
+// in registers and writes the row symbols key & 3, and the run-length encoding of the sorted keys -- distinct keys,
+// first row of each (row = index in sorted order) -- follows tile by tile without a counting pass over the keys.
+// `done` tells the caller whether that happened; if not, it encodes the returned keys itself.
+struct RleSink {
+    u64 *dk; u32 *dstart; u8 *mchar;   // out: distinct keys, their first rows, one symbol per row
+    void *ws;                          // radix_rle_ws_bytes(n) bytes of device scratch
+    u32 *h_total;                      // pinned host word: number of distinct keys, valid once the stream drained
+    bool done;
+};
+size_t radix_rle_ws_bytes(u64 n);
 u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, const RadixWorkspace &ws,
                     int algo, hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err,
-                    const TextKeySrc *text = nullptr);
+                    const TextKeySrc *text = nullptr, RleSink *sink = nullptr);

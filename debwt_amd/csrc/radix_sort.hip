@@ -761,6 +761,272 @@ __global__ __launch_bounds__(NT) void rs_local_kernel(u64 *__restrict__ keys, u6
     for (u32 i = tid; i < cnt; i += NT) keys[s + i] = A[RL_PAD(i)];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bucket finish that also prepares the run-length encoding of the sorted keys (RleSink)
+//
+//   rs_local_count  one wave per wave tile: stretch start -> bnd; a fit tile is sorted in registers, written back,
+//                   its distinct keys counted -> tcnt and its row symbols (key & 3) written; a stretch above RLW_CAP
+//                   keys ("unfit") is listed and, unless in order already, handed to the 4096-key tiles
+//   rs_local<256> + the HBM path sort the unfit stretches in place (unchanged)
+//   rs_unfit_rle<0> counts the distinct keys of every unfit stretch -> tcnt
+//   rs_tile_scan    exclusive scan of tcnt -> tex, total
+//   rs_tile_emit / rs_unfit_rle<1>  distinct keys and their first rows, tile by tile at tex
+// The separate count pass over the sorted keys (and its 8 bytes per key of reads) is gone.
+
+// sorts the 1024 keys a wave holds 16 per lane (blocked layout) ascending; see rs_local_kernel for the method
+__device__ __forceinline__ void rlw_sort(u64 (&k)[16], const u32 lane) {
+    constexpr int KPT = 16;
+    bool sorted;
+    {
+        u32 bad = 0;
+#pragma unroll
+        for (int r = 0; r + 1 < KPT; r++) bad |= k[r] > k[r + 1] ? 1u : 0u;
+        const u64 nxt = __shfl_down(k[0], 1, 64);
+        if (lane < 63) bad |= k[KPT - 1] > nxt ? 1u : 0u;
+        sorted = __ballot(bad != 0) == 0ull;
+    }
+    if (!sorted) {
+#pragma unroll
+        for (int lk = 1; lk <= 4; lk++) {
+#pragma unroll
+            for (int lj = lk - 1; lj >= 0; lj--) {
+                const int jj = 1 << lj;
+#pragma unroll
+                for (int r = 0; r < KPT; r++)
+                    if ((r & jj) == 0) rl_cex(k[r], k[r | jj], (r & (1 << lk)) == 0);
+            }
+        }
+        for (int round = 0; round < RL_MAX_ROUNDS; round++) {
+            const u64 nxt = __shfl_down(k[0], 1, 64);
+            const bool ok = lane == 63 || k[KPT - 1] <= nxt;
+            if (__ballot(!ok) == 0ull) { sorted = true; break; }
+            const bool odd = round & 1;
+            const bool lower = ((lane ^ (u32)odd) & 1u) == 0;
+            const int partner = lower ? (int)lane + 1 : (int)lane - 1;
+            const bool active = partner >= 0 && partner < 64;
+            const int src = active ? partner : (int)lane;
+            u64 t[KPT];
+#pragma unroll
+            for (int r = 0; r < KPT; r++) t[r] = __shfl(k[KPT - 1 - r], src, 64);
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < KPT; r++) {
+                    const bool pless = t[r] < k[r];
+                    k[r] = (lower == pless) ? t[r] : k[r];
+                }
+#pragma unroll
+                for (int lj = 3; lj >= 0; lj--) {
+                    const int jj = 1 << lj;
+#pragma unroll
+                    for (int r = 0; r < KPT; r++)
+                        if ((r & jj) == 0) rl_cex(k[r], k[r | jj], true);
+                }
+            }
+        }
+        if (!sorted) {
+            const u64 nxt = __shfl_down(k[0], 1, 64);
+            const bool ok = lane == 63 || k[KPT - 1] <= nxt;
+            sorted = __ballot(!ok) == 0ull;
+        }
+    }
+    if (!sorted) {
+#pragma unroll
+        for (int lk = 1; lk <= 10; lk++) {                        // full bitonic network over the wave
+            const u32 kk = 1u << lk;
+#pragma unroll
+            for (int lj = lk - 1; lj >= 0; lj--) {
+                if (lj < 4) {
+                    const int jj = 1 << lj;
+#pragma unroll
+                    for (int r = 0; r < KPT; r++)
+                        if ((r & jj) == 0) rl_cex(k[r], k[r | jj], ((lane * KPT + r) & kk) == 0);
+                } else {
+                    const int dl = 1 << (lj - 4);
+                    const bool lower = (lane & dl) == 0;
+#pragma unroll
+                    for (int r = 0; r < KPT; r++) {
+                        const u64 pk = __shfl_xor(k[r], dl, 64);
+                        const bool up = ((lane * KPT + r) & kk) == 0;
+                        const bool take_min = lower == up;
+                        const bool pless = pk < k[r];
+                        k[r] = (take_min == pless) ? pk : k[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ keys, u64 n, int pshift,
+                                                            u8 *__restrict__ mark, u64 *__restrict__ bnd,
+                                                            u32 *__restrict__ unfit, u32 *__restrict__ nunfit,
+                                                            u32 *__restrict__ tcnt, u8 *__restrict__ mchar) {
+    constexpr int KPT = 16;
+    constexpr u32 CAP = RLW_CAP;
+    __shared__ u64 A[CAP + CAP / 16];
+    const u32 lane = threadIdx.x;
+    const u64 x0 = (u64)blockIdx.x * RLW_H, x1 = x0 + RLW_H;
+    const u64 s = x0 == 0 ? 0 : rl_boundary(keys, n, x0, pshift, RLW_CAP - RLW_H);
+    const u64 e = x1 >= n ? n : rl_boundary(keys, n, x1, pshift, RLW_CAP - RLW_H);
+    if (lane == 0) bnd[blockIdx.x] = s;
+    if (s >= e) { if (lane == 0) tcnt[blockIdx.x] = 0; return; }
+    if (e - s > CAP) {
+        if (lane == 0) unfit[atomicAdd(nunfit, 1u)] = blockIdx.x;              // counted by rs_unfit_rle<0>
+        u32 bad = 0;
+        for (u64 i = s + lane; i + 1 < e && !bad; i += 64) bad = keys[i] > keys[i + 1] ? 1u : 0u;
+        if (__ballot(bad != 0) == 0ull) return;
+        u64 t0 = s / RL_H, t1 = (e - 1) / RL_H;
+        if (t0 > 0) t0--;
+        for (u64 t = t0 + lane; t <= t1; t += 64) mark[t] = 1;
+        return;
+    }
+    const u32 cnt = (u32)(e - s);
+    // LDS operations of one wave execute in order: no barrier between the writes and the reads of its own tile
+    for (u32 i = lane; i < CAP; i += 64) A[RL_PAD(i)] = i < cnt ? keys[s + i] : ~0ull;
+    u64 k[KPT];
+#pragma unroll
+    for (int r = 0; r < KPT; r++) k[r] = A[RL_PAD(lane * KPT + r)];
+    rlw_sort(k, lane);
+#pragma unroll
+    for (int r = 0; r < KPT; r++) A[RL_PAD(lane * KPT + r)] = k[r];
+    // a key is a head when it differs from the key before it; the stretch starts at a bucket boundary
+    const u64 before = __shfl_up(k[KPT - 1], 1, 64);
+    u32 c = 0;
+#pragma unroll
+    for (int r = 0; r < KPT; r++) {
+        const u64 p = r ? k[r - 1] : before;
+        c += (lane * KPT + r < cnt && ((lane == 0 && r == 0) || k[r] != p)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if (lane == 0) tcnt[blockIdx.x] = c;
+    if (lane * KPT < cnt) {                                       // row symbols: 16 bytes per lane
+        u8 *dst = mchar + s + lane * KPT;
+        if (lane * KPT + KPT <= cnt) {
+            u32 wv[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < KPT; r++) wv[r >> 2] |= ((u32)k[r] & 3u) << (8 * (r & 3));
+            __builtin_memcpy(dst, wv, 16);
+        } else {
+#pragma unroll
+            for (int r = 0; r < KPT; r++) if (lane * KPT + r < cnt) dst[r] = (u8)(k[r] & 3ull);
+        }
+    }
+    for (u32 i = lane; i < cnt; i += 64) keys[s + i] = A[RL_PAD(i)];
+}
+
+// exclusive scan of the tile counts: within blocks of 4096 tiles (tex) + the block offsets (boff), added by the readers
+#define RLT_BLOCK 4096
+__global__ __launch_bounds__(256) void rs_tile_scan1_kernel(const u32 *__restrict__ tcnt, u32 nwtiles,
+                                                            u32 *__restrict__ tex, u32 *__restrict__ bsum) {
+    __shared__ u32 wsum[4];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 i0 = blockIdx.x * RLT_BLOCK + tid * 16u;
+    u32 v[16], sum = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { v[r] = i0 + r < nwtiles ? tcnt[i0 + r] : 0u; sum += v[r]; }
+    u32 inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 x = __shfl_up(inc, d, 64); if (lane >= (u32)d) inc += x; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    u32 run = inc - sum;
+    for (u32 x = 0; x < w; x++) run += wsum[x];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { if (i0 + r < nwtiles) tex[i0 + r] = run; run += v[r]; }
+    if (tid == 255) bsum[blockIdx.x] = run;
+}
+__global__ __launch_bounds__(1024) void rs_tile_scan2_kernel(const u32 *__restrict__ bsum, u32 nb, u32 *__restrict__ boff,
+                                                             u32 *__restrict__ total) {
+    __shared__ u32 part[1024];
+    const u32 tid = threadIdx.x;
+    const u32 per = (nb + 1023u) / 1024u;
+    const u32 lo = tid * per < nb ? tid * per : nb, hi = lo + per < nb ? lo + per : nb;
+    u32 sum = 0;
+    for (u32 i = lo; i < hi; i++) sum += bsum[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {
+        const u32 v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = part[tid] - sum;
+    for (u32 i = lo; i < hi; i++) { const u32 c = bsum[i]; boff[i] = run; run += c; }
+    if (tid == 1023) *total = part[1023];
+}
+
+// distinct keys and first rows of the fit tiles (sorted in place by rs_local_count): one wave per tile
+__global__ __launch_bounds__(256) void rs_tile_emit_kernel(const u64 *__restrict__ keys, u64 n,
+                                                           const u64 *__restrict__ bnd, u32 nwtiles,
+                                                           const u32 *__restrict__ tex, const u32 *__restrict__ boff,
+                                                           u64 *__restrict__ dk, u32 *__restrict__ dstart) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 t = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (t >= nwtiles) return;
+    const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
+    if (s >= e || e - s > RLW_CAP) return;
+    u64 off = (u64)tex[t] + boff[t / RLT_BLOCK];
+    for (u64 p = s; p < e; p += 64) {
+        const u64 j = p + lane;
+        const bool valid = j < e;
+        const u64 k = valid ? keys[j] : 0ull;
+        const bool head = valid && (j == s || keys[j - 1] != k);
+        const u64 bm = __ballot(head);
+        if (head) {
+            const u64 o = off + (u32)__popcll(bm & ((1ull << lane) - 1ull));
+            dk[o] = k; dstart[o] = (u32)j;
+        }
+        off += (u32)__popcll(bm);
+    }
+}
+
+template <int EMIT>
+__global__ __launch_bounds__(256) void rs_unfit_rle_kernel(const u64 *__restrict__ keys, u64 n,
+                                                           const u64 *__restrict__ bnd, u32 nwtiles,
+                                                           const u32 *__restrict__ unfit, const u32 *__restrict__ nunfit,
+                                                           u32 *__restrict__ tcnt, const u32 *__restrict__ tex,
+                                                           const u32 *__restrict__ boff, u64 *__restrict__ dk,
+                                                           u32 *__restrict__ dstart, u8 *__restrict__ mchar) {
+    __shared__ u32 wsum[4];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 nu = *nunfit;
+    for (u32 i = blockIdx.x; i < nu; i += gridDim.x) {
+        const u32 t = unfit[i];
+        const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
+        u32 run = EMIT ? tex[t] + boff[t / RLT_BLOCK] : 0u;                 // distinct keys before the tile
+        for (u64 p = s; p < e; p += 256) {
+            const u64 j = p + tid;
+            const bool valid = j < e;
+            const u64 k = valid ? keys[j] : 0ull;
+            const bool head = valid && (j == s || keys[j - 1] != k);
+            const u64 bm = __ballot(head);
+            if (lane == 0) wsum[w] = (u32)__popcll(bm);
+            __syncthreads();
+            u32 before = 0, tot = 0;
+#pragma unroll
+            for (u32 x = 0; x < 4; x++) { const u32 v = wsum[x]; before += x < w ? v : 0u; tot += v; }
+            if (EMIT && valid) {
+                mchar[j] = (u8)(k & 3);
+                if (head) {
+                    const u64 off = (u64)run + before + (u32)__popcll(bm & ((1ull << lane) - 1ull));
+                    dk[off] = k; dstart[off] = (u32)j;
+                }
+            }
+            run += tot;
+            __syncthreads();
+        }
+        if (!EMIT && tid == 0) tcnt[t] = run;
+    }
+}
+
+// workspace of the counting finish, nw tiles in nb scan blocks:
+//   [nunfit, total, pad, pad][bnd u64 x nw][tcnt u32 x nw][unfit u32 x nw][tex u32 x nw][bsum u32 x nb][boff u32 x nb]
+static size_t rle_nw(u64 n) { return (size_t)(n / RLW_H + 2); }
+static size_t rle_nb(u64 n) { return rle_nw(n) / RLT_BLOCK + 2; }
+size_t radix_rle_ws_bytes(u64 n) { return 16 + rle_nw(n) * (8 + 12) + rle_nb(n) * 8 + 64; }
+
 // oversize tiles: gather their keys into one contiguous scratch array / copy the sorted result back
 __global__ void rs_over_move(u64 *__restrict__ keys, u64 *__restrict__ scratch, const u64 *__restrict__ list,
                              const u64 *__restrict__ offs, u32 nranges, u64 total, int back) {
@@ -873,8 +1139,10 @@ u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int 
 }
 
 u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, const RadixWorkspace &ws, int algo,
-                    hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err, const TextKeySrc *text) {
+                    hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err, const TextKeySrc *text,
+                    RleSink *sink) {
     *err = hipSuccess;
+    if (sink) sink->done = false;
     if (npairs) *npairs = 0;
     const bool aux = (algo & 16) != 0;       // bit 4: auxiliary sort
     algo &= 15;
@@ -895,7 +1163,22 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
     u32 ntiles = (u32)((n + RL_H - 1) / RL_H), nwtiles = (u32)((n + RLW_H - 1) / RLW_H);
     u8 *mark = reinterpret_cast<u8 *>(ws.skew_list);          // one byte per 4096-key tile
     (void)hipMemsetAsync(mark, 0, ntiles + 1, stream);
-    rs_local_kernel<64><<<nwtiles, 64, 0, stream>>>(src, n, pshift, ws.over, ws.over_cap, mark);
+    u32 *rle_ctr = nullptr, *rle_tcnt = nullptr, *rle_unfit = nullptr, *rle_tex = nullptr, *rle_bsum = nullptr, *rle_boff = nullptr;
+    u64 *rle_bnd = nullptr;
+    if (sink) {
+        const size_t nw = rle_nw(n);
+        rle_ctr = static_cast<u32 *>(sink->ws);
+        rle_bnd = reinterpret_cast<u64 *>(rle_ctr + 4);
+        rle_tcnt = reinterpret_cast<u32 *>(rle_bnd + nw);
+        rle_unfit = rle_tcnt + nw;
+        rle_tex = rle_unfit + nw;
+        rle_bsum = rle_tex + nw;
+        rle_boff = rle_bsum + rle_nb(n);
+        (void)hipMemsetAsync(rle_ctr, 0, 16, stream);
+        rs_local_count_kernel<<<nwtiles, 64, 0, stream>>>(src, n, pshift, mark, rle_bnd, rle_unfit, rle_ctr, rle_tcnt, sink->mchar);
+    } else {
+        rs_local_kernel<64><<<nwtiles, 64, 0, stream>>>(src, n, pshift, ws.over, ws.over_cap, mark);
+    }
     rs_local_kernel<256><<<ntiles, 256, 0, stream>>>(src, n, pshift, ws.over, ws.over_cap, mark);
     (void)hipMemcpyAsync(ws.h_over, ws.over, 16, hipMemcpyDeviceToHost, stream);
     if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;
@@ -933,6 +1216,19 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
             rs_over_move<<<grid, 256, 0, stream>>>(src, r, d_list, d_offs, nover, total, 1);
             if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;   // offs is host memory
         }
+    }
+    if (sink) {
+        const u32 ug = nwtiles < 2048u ? nwtiles : 2048u;
+        const u32 nb = (nwtiles + RLT_BLOCK - 1) / RLT_BLOCK;
+        rs_unfit_rle_kernel<0><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
+                                                       rle_boff, sink->dk, sink->dstart, sink->mchar);
+        rs_tile_scan1_kernel<<<nb, 256, 0, stream>>>(rle_tcnt, nwtiles, rle_tex, rle_bsum);
+        rs_tile_scan2_kernel<<<1, 1024, 0, stream>>>(rle_bsum, nb, rle_boff, rle_ctr + 1);
+        rs_tile_emit_kernel<<<(nwtiles + 3) / 4, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_tex, rle_boff, sink->dk, sink->dstart);
+        rs_unfit_rle_kernel<1><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
+                                                       rle_boff, sink->dk, sink->dstart, sink->mchar);
+        (void)hipMemcpyAsync(sink->h_total, rle_ctr + 1, sizeof(u32), hipMemcpyDeviceToHost, stream);
+        sink->done = true;
     }
     *err = hipGetLastError();
     return src;

@@ -525,11 +525,13 @@ __device__ __forceinline__ u32 red_lookup(const HSlot *__restrict__ htab, int hb
 }
 
 // rows of the special suffixes: rank among the node instances + own rank (src/INandOut.c:419-439)
-__global__ void k_special_rows(const u64 *__restrict__ sk, u64 M, const u64 *__restrict__ spkey, u64 NS,
-                               u64 row_base, u64 *__restrict__ sprow) {
+// (number of instances with key <= X) = first row of the first distinct key above X
+__global__ void k_special_rows(const u64 *__restrict__ dk, const u32 *__restrict__ dstart, u64 D, u64 M,
+                               const u64 *__restrict__ spkey, u64 NS, u64 row_base, u64 *__restrict__ sprow) {
     u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= NS) return;
-    sprow[s] = row_base + s + upper_bound_dev<u64>(sk, 0, M, (spkey[s] << 2) | 3ull);
+    const u64 e = upper_bound_dev<u64>(dk, 0, D, (spkey[s] << 2) | 3ull);
+    sprow[s] = row_base + s + (e < D ? (u64)dstart[e] : M);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -359,9 +359,42 @@ def test_pan_genome_deep_tie_groups(api, oracle, tune):
     d.close()
 
 
+@pytest.mark.parametrize("kind", ["pan", "lowcomplexity"])
+def test_rle_paths_agree(api, kind):
+    """The bucket finish that counts distinct keys per tile (default) against the separate count + emit passes over the
+    sorted keys (tune 256): same sorted keys, distinct keys and BWT -- on repeat families (stretches above a wave tile)
+    and on low-complexity runs (buckets that go through the 4096-key tiles and the HBM path)."""
+    from debwt_amd import synth
+    if kind == "pan":
+        recs = synth.pan_genome(600_000, 6)
+    else:
+        rng = np.random.default_rng(5)
+        parts = []
+        for _ in range(300):
+            parts.append(np.full(int(rng.integers(200, 30000)), int(rng.integers(0, 4)), dtype=np.uint8))
+            parts.append(np.tile(rng.integers(0, 4, size=int(rng.integers(2, 7))).astype(np.uint8), int(rng.integers(50, 3000))))
+            parts.append(rng.integers(0, 4, size=int(rng.integers(100, 5000))).astype(np.uint8))
+        recs = [np.concatenate(parts)]
+    got = []
+    for tune in (0, 256):
+        d = api.DeBWT(k=32, tune=tune)
+        d.load_records(recs)
+        d.kmer_sort_rle()
+        sk = d.fetch_array(api.ARR_SORTED_KEYS)
+        dk = d.fetch_array(api.ARR_DISTINCT_KEYS)
+        assert bool((sk[1:] >= sk[:-1]).all())
+        assert np.array_equal(np.unique(sk), dk)
+        d.build()
+        got.append((sk, dk) + tuple(d.fetch()))
+        d.close()
+    a, b = got
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and a[4] == b[4]
+
+
 def test_randomised_parity_sweep(api, oracle):
     """200 random small collections x random k x random key-range caps x the alternative device paths (cursor atomics,
-    64-bit cursors, no tie-group hand-off), two builds per context, against the oracle (scripts/gpu_fuzz.py runs the
+    64-bit cursors, no tie-group hand-off, separate run-length passes), two builds per context, against the oracle (scripts/gpu_fuzz.py runs the
     same sweep for thousands of cases)."""
     from debwt_amd import synth
     rng = np.random.default_rng(31337)
@@ -379,7 +412,7 @@ def test_randomised_parity_sweep(api, oracle):
                 parts.append(rng.integers(0, 4, size=int(rng.integers(1, 9))).astype(np.uint8))
             recs = [np.concatenate(parts), rng.integers(0, 4, size=int(rng.integers(33, 500))).astype(np.uint8)]
         k = int(rng.choice([12, 13, 16, 20, 24, 27, 31, 32]))
-        tune = int(rng.choice([0, 0, 32, 48, 128, 160]))
+        tune = int(rng.choice([0, 0, 32, 48, 128, 160, 256]))
         cap = int(rng.choice([0, 0, 4096, 20000]))
         ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), k)
         d = api.DeBWT(k=k, tune=tune)
