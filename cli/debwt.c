@@ -26,6 +26,8 @@ static void usage(void) {
                     "-k (optional): k-mer length (from 12 to 32, default 32)\n"
                     "-j (optional): jellyfish directory (accepted, ignored)\n"
                     "--device (optional): GPU ordinal (default 0)\n"
+                    "--iupac (optional): seed; N and other ambiguity letters become pseudo-random bases of their sets\n"
+                    "                    (what otherTool/transferN does, reproducibly)\n"
                     "reference: sequence in fasta format (plain or gzip)\n");
 }
 
@@ -46,7 +48,8 @@ static int write_file(const char *path, const void *p, size_t bytes) {
 int main(int argc, char **argv) {
     if (argc < 4 || (argc & 1) == 1) { usage(); return 1; }            /* src/main.c:25 */
     const char *source = argv[argc - 1], *obj = NULL;
-    int k = 32, device = 0;
+    int k = 32, device = 0, iupac = 0;
+    unsigned long long iupac_seed = 0;
     long threads = 8;
     for (int i = 1; i < argc - 1; i += 2) {
         if (!strcmp(argv[i], "-o")) obj = argv[i + 1];
@@ -58,6 +61,7 @@ int main(int argc, char **argv) {
             k = atoi(argv[i + 1]);
             if (k < 12 || k > 32) { fprintf(stderr, "-k: k-mer length (from 12 to 32, default 32)\n"); return 1; }
         } else if (!strcmp(argv[i], "--device")) device = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--iupac")) { iupac = 1; iupac_seed = strtoull(argv[i + 1], NULL, 10); }
         else { usage(); return 1; }
     }
     if (!obj) { usage(); return 1; }
@@ -74,9 +78,9 @@ int main(int argc, char **argv) {
     if (rc) { fprintf(stderr, "debwt_create: %s\n", debwt_strerror(rc)); return 1; }
     double t1 = now();
     /* the reference's collect (src/collect#$.c:34-90): here `threads` host threads parse and pack the file */
-    rc = debwt_load_fasta(ctx, source, (int)(threads > 256 ? 256 : threads));
+    rc = debwt_load_fasta_opts(ctx, source, (int)(threads > 256 ? 256 : threads), iupac ? DEBWT_FASTA_IUPAC_RANDOM : 0u, iupac_seed);
     if (rc) {
-        fprintf(stderr, "%s (sequence must be ACGT only, records > 32 bases)\n", debwt_last_error(ctx));
+        fprintf(stderr, "%s (sequence must be ACGT only unless --iupac is given, records > 32 bases)\n", debwt_last_error(ctx));
         return 1;
     }
     double t2 = now();

@@ -43,7 +43,7 @@ SYMBOLS = [
     "debwt_shard_begin", "debwt_shard_histogram", "debwt_shard_set_range", "debwt_shard_classify_local",
     "debwt_shard_facts_export", "debwt_shard_classify_global", "debwt_shard_info", "debwt_shard_fetch",
     "debwt_shard_partition_keys", "debwt_shard_import_keys", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
-    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_special_digest",
+    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest",
 ]
 
 
@@ -140,6 +140,11 @@ def lib():
     L.debwt_free_packed.argtypes = [ctypes.POINTER(DebwtPackedText)]
     L.debwt_load_fasta.restype = ctypes.c_int
     L.debwt_load_fasta.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
+    L.debwt_pack_fasta_opts.restype = ctypes.c_int
+    L.debwt_pack_fasta_opts.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64,
+                                        ctypes.POINTER(DebwtPackedText), ctypes.c_char_p, ctypes.c_size_t]
+    L.debwt_load_fasta_opts.restype = ctypes.c_int
+    L.debwt_load_fasta_opts.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64]
     L.debwt_special_digest.restype = ctypes.c_int
     L.debwt_special_digest.argtypes = [u64p, ctypes.c_uint64, u64p, ctypes.c_uint64, ctypes.c_int, u64p]
     L.debwt_set_range_cap.restype = ctypes.c_int

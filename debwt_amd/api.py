@@ -99,9 +99,13 @@ class DeBWT:
         self._chk(self._L.debwt_load_ascii(self._h, b"".join(recs), _p64(lens), len(recs)))
         self.n, self.nrec = int(lens.sum()) + len(recs), len(recs)
 
-    def load_fasta(self, path, threads=8):
-        """FASTA (plain or gzip) parsed and packed by `threads` host threads, then loaded."""
-        self._chk(self._L.debwt_load_fasta(self._h, str(path).encode(), int(threads)))
+    def load_fasta(self, path, threads=8, iupac_seed=None):
+        """FASTA (plain or gzip) parsed and packed by `threads` host threads, then loaded.  iupac_seed: replace N and
+        the other ambiguity letters by pseudo-random bases of their sets (deterministic in seed and position)."""
+        if iupac_seed is None:
+            self._chk(self._L.debwt_load_fasta(self._h, str(path).encode(), int(threads)))
+        else:
+            self._chk(self._L.debwt_load_fasta_opts(self._h, str(path).encode(), int(threads), FASTA_IUPAC_RANDOM, int(iupac_seed)))
         st = self.stats()
         self.n, self.nrec = st["n"], st["nrec"]
 
@@ -192,12 +196,18 @@ def write_outputs(path, words, hash_rows, dollar_row):
     np.array([dollar_row], dtype=np.uint64).tofile(path + ".$")
 
 
-def pack_fasta(path, threads=8):
+FASTA_IUPAC_RANDOM = 1
+
+
+def pack_fasta(path, threads=8, iupac_seed=None):
     """Host-only: (words, n, sep, seconds_read, seconds_pack) of a FASTA file in the reference's 2-bit layout."""
     L = _lib.lib()
     pt = _lib.DebwtPackedText()
     err = ctypes.create_string_buffer(256)
-    rc = L.debwt_pack_fasta(str(path).encode(), int(threads), ctypes.byref(pt), err, 256)
+    if iupac_seed is None:
+        rc = L.debwt_pack_fasta(str(path).encode(), int(threads), ctypes.byref(pt), err, 256)
+    else:
+        rc = L.debwt_pack_fasta_opts(str(path).encode(), int(threads), FASTA_IUPAC_RANDOM, int(iupac_seed), ctypes.byref(pt), err, 256)
     if rc:
         raise DebwtError(rc, err.value.decode())
     try:

@@ -322,23 +322,31 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
 
 static_assert(sizeof(debwt_packed_text) == sizeof(PackedText), "C ABI mirror of PackedText");
 
-extern "C" int debwt_pack_fasta(const char *path, int threads, debwt_packed_text *out, char *errbuf, size_t errlen) {
-    if (!path || !out) return DEBWT_EINVAL;
+extern "C" int debwt_pack_fasta_opts(const char *path, int threads, unsigned flags, uint64_t seed, debwt_packed_text *out,
+                                     char *errbuf, size_t errlen) {
+    if (!path || !out || (flags & ~DEBWT_FASTA_IUPAC_RANDOM)) return DEBWT_EINVAL;
     memset(out, 0, sizeof *out);
-    return pack_fasta_file(path, threads, reinterpret_cast<PackedText *>(out), errbuf, errlen) ? DEBWT_EINVAL : DEBWT_OK;
+    return pack_fasta_file(path, threads, reinterpret_cast<PackedText *>(out), errbuf, errlen, IngestOpts{flags, seed})
+               ? DEBWT_EINVAL : DEBWT_OK;
+}
+extern "C" int debwt_pack_fasta(const char *path, int threads, debwt_packed_text *out, char *errbuf, size_t errlen) {
+    return debwt_pack_fasta_opts(path, threads, 0, 0, out, errbuf, errlen);
 }
 extern "C" void debwt_free_packed(debwt_packed_text *p) { free_packed_text(reinterpret_cast<PackedText *>(p)); }
 
-extern "C" int debwt_load_fasta(debwt_ctx *c, const char *path, int threads) {
-    if (!c || !path) return DEBWT_EINVAL;
+extern "C" int debwt_load_fasta_opts(debwt_ctx *c, const char *path, int threads, unsigned flags, uint64_t seed) {
+    if (!c || !path || (flags & ~DEBWT_FASTA_IUPAC_RANDOM)) return DEBWT_EINVAL;
     PackedText pt{};
     char msg[256] = "";
-    if (pack_fasta_file(path, threads, &pt, msg, sizeof msg)) { c->err = msg; return DEBWT_EINVAL; }
+    if (pack_fasta_file(path, threads, &pt, msg, sizeof msg, IngestOpts{flags, seed})) { c->err = msg; return DEBWT_EINVAL; }
     c->own_text.assign(pt.words, pt.words + pt.nwords);
     std::vector<uint64_t> sep(pt.sep, pt.sep + pt.nrec);
     const uint64_t n = pt.n;
     free_packed_text(&pt);
     return debwt_load_text(c, c->own_text.data(), n, sep.data(), sep.size());
+}
+extern "C" int debwt_load_fasta(debwt_ctx *c, const char *path, int threads) {
+    return debwt_load_fasta_opts(c, path, threads, 0, 0);
 }
 
 extern "C" int debwt_set_range_cap(debwt_ctx *c, uint64_t max_instances) {

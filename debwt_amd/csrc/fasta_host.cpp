@@ -14,6 +14,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -39,6 +42,35 @@ struct Lut {
 };
 const Lut LUT;
 
+// IUPAC ambiguity letters and the bases they stand for, in the order of the reference's randTable
+// (otherTool/transferN.c:8-9,17-27)
+struct Iupac {
+    uint8_t len[256];
+    uint8_t set[256][4];
+    Iupac() {
+        memset(len, 0, sizeof len); memset(set, 0, sizeof set);
+        auto def = [&](char c, const char *bases) {
+            for (int u = 0; u < 2; u++) {
+                const int ch = u ? c | 0x20 : c;
+                len[ch] = (uint8_t)strlen(bases);
+                for (int i = 0; bases[i]; i++) set[ch][i] = LUT.t[(unsigned char)bases[i]];
+            }
+        };
+        def('N', "ACGT"); def('V', "ACG"); def('D', "ATG"); def('B', "TCG"); def('H', "ATC"); def('W', "AT");
+        def('S', "CG"); def('K', "TG"); def('M', "AC"); def('Y', "CT"); def('R', "AG");
+    }
+};
+const Iupac IUPAC;
+inline uint64_t mix64(uint64_t x) {                      // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+inline uint8_t iupac_pick(unsigned char ch, uint64_t pos, uint64_t seed) {
+    return IUPAC.set[ch][mix64(seed ^ (pos * 0xD6E8FEB86659FD93ull)) % IUPAC.len[ch]];
+}
+
 struct Chunk {
     size_t beg = 0, end = 0;
     bool starts_in_header = false;
@@ -50,6 +82,137 @@ struct Chunk {
     long bad_at = -1;                     // offset of the first invalid character
 };
 
+// Eight characters at once: their 2-bit codes as 16 bits, first character in the top two bits; false when one of the
+// eight is not ACGTacgt.  code = bits (1 ^ 2, 2 ^ 3) of the upper-cased character (A 0x41, C 0x43, G 0x47, T 0x54 ->
+// 0, 1, 2, 3); the check rebuilds the character from its code and compares.
+inline bool swar8(const char *p, uint64_t *codes) {
+    uint64_t x;
+    memcpy(&x, p, 8);
+    x = __builtin_bswap64(x);                                        // first character in the most significant byte
+    const uint64_t y = x & 0xDFDFDFDFDFDFDFDFull;                    // upper case
+    const uint64_t c = ((y >> 1) ^ (y >> 2)) & 0x0303030303030303ull;
+    const uint64_t lo = c & 0x0101010101010101ull, hi = (c >> 1) & 0x0101010101010101ull;
+    const uint64_t back = 0x4141414141414141ull + 2 * lo + 6 * hi + 0x0B * (lo & hi);
+    uint64_t v = c;
+    v = (v | (v >> 6)) & 0x000F000F000F000Full;
+    v = (v | (v >> 12)) & 0x000000FF000000FFull;
+    v = (v | (v >> 24)) & 0xFFFFull;
+    *codes = v;
+    return back == y;
+}
+
+// pass 2 state: the word under construction is shifted left two bits per symbol; the first and the last word of a
+// chunk may be shared with the neighbouring chunks and are OR-ed in atomically, the words between belong to it alone
+struct Packer {
+    uint64_t *words;
+    uint64_t w_first, pos, acc;
+    inline void flush_full() {                // pos is a multiple of 32 here: word pos/32 - 1 is complete
+        const uint64_t w = (pos >> 5) - 1;
+        if (w == w_first) __atomic_fetch_or(&words[w], acc, __ATOMIC_RELAXED); else words[w] = acc;
+        acc = 0;
+    }
+    inline void put(uint64_t v, unsigned g) { // g <= 32 symbols, first symbol in the top bits of the 2g-bit value
+        const unsigned fill = (unsigned)(pos & 31);                  // symbols in the word under construction
+        if (fill + g < 32) { acc = (acc << (2 * g)) | v; pos += g; return; }
+        const unsigned head = 32 - fill, tail = g - head;            // head symbols complete the word
+        acc = (head == 32 ? 0ull : acc << (2 * head)) | (v >> (2 * tail));
+        pos += head; flush_full();
+        acc = tail ? v & ((1ull << (2 * tail)) - 1ull) : 0ull;
+        pos += tail;
+    }
+    inline void finish() {                    // the last, partial word of the chunk is shared with the next chunk
+        if (pos & 31) __atomic_fetch_or(&words[pos >> 5], acc << ((32 - (pos & 31)) << 1), __ATOMIC_RELAXED);
+    }
+};
+
+// Consumes sequence text from p[0, len): bases (counted in *bases; with PACK appended to pk) and the newlines between
+// sequence lines.  Returns the offset of the first character that needs the caller: white space other than such a
+// newline, an invalid character, a newline before a header or at the very end -- or len.
+template <bool PACK>
+size_t run_swar(const char *p, size_t len, Packer *pk, uint64_t *bases) {
+    size_t j = 0;
+    uint64_t nb = 0;
+    for (;;) {
+        uint64_t v;
+        for (; j + 8 <= len && swar8(p + j, &v); j += 8, nb += 8)
+            if (PACK) pk->put(v, 8);
+        for (; j < len; j++, nb++) {
+            const uint8_t c = LUT.t[(unsigned char)p[j]];
+            if (c > 3) break;
+            if (PACK) pk->put(c, 1);
+        }
+        if (j + 1 < len && p[j] == '\n' && p[j + 1] != '>') { j++; continue; }
+        break;
+    }
+    *bases += nb;
+    return j;
+}
+
+#if defined(__x86_64__)
+// 32 characters per step (AVX2, chosen at run time): same code arithmetic per byte, the check by a byte shuffle of
+// "ACGT", the 64-bit word by two multiply-adds (4 codes -> a byte) and a byte reversal.
+template <bool PACK>
+__attribute__((target("avx2"))) size_t run_avx2(const char *p, size_t len, Packer *pk, uint64_t *bases) {
+    const __m256i up_mask = _mm256_set1_epi8((char)0xDF), three = _mm256_set1_epi8(3);
+    const __m256i acgt = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                          'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i newline = _mm256_set1_epi8('\n');
+    size_t j = 0;
+    uint64_t nb = 0;
+    // Blocks sit at fixed offsets while the text is bases with at most one line break per block (any line of 32
+    // characters or more), so that the next block's address does not wait for this block's classification.
+    while (j + 32 <= len) {
+        const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + j));
+        const __m256i up = _mm256_and_si256(x, up_mask);
+        const __m256i c = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(up, 1), _mm256_srli_epi16(up, 2)), three);
+        const uint32_t ok = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_shuffle_epi8(acgt, c), up));
+        uint64_t v = 0;
+        if (PACK) {
+            const __m256i b4 = _mm256_maddubs_epi16(c, _mm256_set1_epi16(0x0104));        // 2 codes -> 4 bits
+            const __m256i b8 = _mm256_madd_epi16(b4, _mm256_set1_epi32(0x00010010));      // 4 codes -> 8 bits per dword
+            const __m256i w16 = _mm256_packs_epi32(b8, b8);
+            const __m256i w8 = _mm256_packus_epi16(w16, w16);
+            const uint64_t le = (uint32_t)_mm256_extract_epi32(w8, 0) | ((uint64_t)(uint32_t)_mm256_extract_epi32(w8, 4) << 32);
+            v = __builtin_bswap64(le);                                                    // first character on top
+        }
+        if (ok == 0xFFFFFFFFu) {
+            if (PACK) pk->put(v, 32);
+            j += 32; nb += 32;
+            continue;
+        }
+        const uint32_t nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, newline));
+        if ((ok | nl) == 0xFFFFFFFFu && (nl & (nl - 1)) == 0) {                            // one line break, bases around it
+            const unsigned f = (unsigned)__builtin_ctz(nl);
+            const bool header_next = f == 31 && (j + 32 >= len || p[j + 32] == '>');
+            if (!header_next) {
+                if (PACK) {
+                    if (f) pk->put(v >> (2 * (32 - f)), f);
+                    if (f < 31) pk->put(v & ((1ull << (2 * (31 - f))) - 1ull), 31 - f);
+                }
+                j += 32; nb += 31;
+                continue;
+            }
+        }
+        const unsigned g = (unsigned)__builtin_ctz(~ok);                                   // bases before the first other character
+        if (PACK && g) pk->put(v >> (2 * (32 - g)), g);
+        j += g; nb += g;
+        if (j + 1 < len && p[j] == '\n' && p[j + 1] != '>') { j++; continue; }            // next sequence line
+        *bases += nb;
+        return j;
+    }
+    *bases += nb;
+    return j + run_swar<PACK>(p + j, len - j, pk, bases);
+}
+#endif
+
+typedef size_t (*RunFn)(const char *, size_t, Packer *, uint64_t *);
+template <bool PACK> RunFn pick_run() {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2") && !getenv("DEBWT_INGEST_NO_AVX2")) return run_avx2<PACK>;
+#endif
+    return run_swar<PACK>;
+}
+
 // is the byte at `pos` inside a header line?  (the line's first character is '>')
 bool in_header_at(const char *buf, size_t pos) {
     const void *nl = pos ? memrchr(buf, '\n', pos) : nullptr;          // last newline before pos
@@ -57,88 +220,67 @@ bool in_header_at(const char *buf, size_t pos) {
     return buf[ls] == '>' && pos > ls;      // pos == ls: the '>' itself is seen by the chunk's own scan
 }
 
-// Walks the lines of a chunk: on_header() at every header start, on_seq(ptr, len) for every (piece of a) sequence
-// line.  Newlines are found with memchr; a header that runs past the chunk end is finished by the next chunk, which
-// knows that it starts inside one.
-template <class H, class S>
-void scan_lines(const char *buf, const Chunk &c, H on_header, S on_seq) {
+// Walks a chunk: on_header() at every header start (bases seen since the last call are in *bases), on_char(ptr) for
+// every character of a sequence line that `run` does not take (see there).  Sequence lines are not searched for their
+// end first: `run` classifies 32 (or 8) characters at a time.  A header that runs past the chunk end is finished by
+// the next chunk, which knows that it starts inside one.
+template <class H, class O>
+void scan_chunk(const char *buf, const Chunk &c, RunFn run, Packer *pk, uint64_t *bases, H on_header, O on_char) {
     size_t i = c.beg;
     if (c.starts_in_header) {
         const void *nl = memchr(buf + i, '\n', c.end - i);
         if (!nl) return;
         i = (size_t)((const char *)nl - buf) + 1;
     }
+    bool bol = i == 0 || buf[i - 1] == '\n';
     while (i < c.end) {
-        const void *nl = memchr(buf + i, '\n', c.end - i);
-        const size_t e = nl ? (size_t)((const char *)nl - buf) : c.end;
-        if (buf[i] == '>' && (i == 0 || buf[i - 1] == '\n')) on_header();
-        else if (e > i) on_seq(buf + i, e - i);
-        i = e + 1;
+        if (bol && buf[i] == '>') {
+            on_header();
+            const void *nl = memchr(buf + i, '\n', c.end - i);
+            if (!nl) return;
+            i = (size_t)((const char *)nl - buf) + 1;
+            continue;
+        }
+        bol = false;
+        i += run(buf + i, c.end - i, pk, bases);
+        if (i >= c.end) break;
+        if (buf[i] == '\n') bol = true; else on_char(buf + i);
+        i++;
     }
 }
 
-// pass 1: bases per record piece; a line of nothing but ACGTacgt is counted by its length
-void census(const char *buf, Chunk &c) {
+// pass 1: bases per record piece
+void census(const char *buf, Chunk &c, IngestOpts opts) {
     uint64_t cur = 0;
     bool any = false;
-    scan_lines(buf, c,
+    const bool iupac = (opts.flags & INGEST_IUPAC_RANDOM) != 0;
+    scan_chunk(buf, c, pick_run<false>(), nullptr, &cur,
         [&]() {
             if (any) c.rec_bases.push_back(cur); else c.head_bases = cur;
             any = true; cur = 0;
         },
-        [&](const char *p, size_t len) {
-            uint8_t acc = 0;
-            for (size_t j = 0; j < len; j++) acc |= LUT.t[(unsigned char)p[j]];
-            if (!(acc & 0x80)) { cur += len; return; }
-            for (size_t j = 0; j < len; j++) {                 // a line with white space in it, or an invalid character
-                const uint8_t v = LUT.t[(unsigned char)p[j]];
-                if (v <= 3) cur++;
-                else if (v == C_BAD && c.bad_at < 0) c.bad_at = (long)(p + j - buf);
-            }
+        [&](const char *p) {
+            if (LUT.t[(unsigned char)*p] != C_BAD) return;
+            if (iupac && IUPAC.len[(unsigned char)*p]) cur++;
+            else if (c.bad_at < 0) c.bad_at = (long)(p - buf);
         });
     if (any) c.rec_bases.push_back(cur); else c.head_bases = cur;
 }
 
-// pass 2: symbols of the chunk at their text positions; a header start closes the record before it with a 'T'.
-// The word under construction is shifted left two bits per symbol; the first and the last word of a chunk may be
-// shared with the neighbouring chunks and are OR-ed in atomically, the words between belong to this chunk alone.
-void pack(const char *buf, const Chunk &c, uint64_t *words, uint64_t *sep) {
-    uint64_t pos = c.sym0, rec = c.rec0;
-    const uint64_t w_first = pos >> 5;
-    uint64_t acc = 0;
-    auto flush_full = [&]() {                 // pos is a multiple of 32 here: word pos/32 - 1 is complete
-        const uint64_t w = (pos >> 5) - 1;
-        if (w == w_first) __atomic_fetch_or(&words[w], acc, __ATOMIC_RELAXED); else words[w] = acc;
-        acc = 0;
-    };
-    auto put = [&](uint64_t code) {
-        acc = (acc << 2) | code;
-        if ((++pos & 31) == 0) flush_full();
-    };
-    scan_lines(buf, c,
+// pass 2: symbols of the chunk at their text positions; a header start closes the record before it with a 'T'
+void pack(const char *buf, const Chunk &c, uint64_t *words, uint64_t *sep, IngestOpts opts) {
+    Packer pk{words, c.sym0 >> 5, c.sym0, 0};
+    uint64_t rec = c.rec0, bases = 0;
+    scan_chunk(buf, c, pick_run<true>(), &pk, &bases,
         [&]() {
-            if (rec > 0) { sep[rec - 1] = pos; put(3); }        // separator of the record that ends here
+            if (rec > 0) { sep[rec - 1] = pk.pos; pk.put(3, 1); }     // separator of the record that ends here
             rec++;
         },
-        [&](const char *p, size_t len) {
-            uint8_t any = 0;
-            for (size_t t = 0; t < len; t++) any |= LUT.t[(unsigned char)p[t]];
-            if (any & 0x80) {                 // white space inside the line (pass 1 has rejected anything else)
-                for (size_t t = 0; t < len; t++) { const uint8_t v = LUT.t[(unsigned char)p[t]]; if (v <= 3) put(v); }
-                return;
-            }
-            // symbols up to the next word boundary, whole words of 32 characters, the rest
-            size_t j = 0;
-            for (; j < len && (pos & 31); j++) put(LUT.t[(unsigned char)p[j]]);
-            for (; j + 32 <= len; j += 32) {
-                uint64_t w = 0;
-                for (int t = 0; t < 32; t++) w = (w << 2) | LUT.t[(unsigned char)p[j + t]];
-                acc = w; pos += 32; flush_full();
-            }
-            for (; j < len; j++) put(LUT.t[(unsigned char)p[j]]);
+        [&](const char *p) {                                          // white space, or (pass 1 has rejected anything
+            const unsigned char ch = (unsigned char)*p;               // else) an ambiguity letter to be replaced
+            if (LUT.t[ch] == C_BAD && IUPAC.len[ch]) pk.put(iupac_pick(ch, pk.pos, opts.seed), 1);
         });
-    // the last, partial word of the chunk is shared with the next chunk
-    if (pos & 31) __atomic_fetch_or(&words[pos >> 5], acc << ((32 - (pos & 31)) << 1), __ATOMIC_RELAXED);
+    pk.finish();
 }
 
 int fail(char *err, size_t errlen, const std::string &msg) {
@@ -148,7 +290,7 @@ int fail(char *err, size_t errlen, const std::string &msg) {
 
 }  // namespace
 
-int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out, char *err, size_t errlen) {
+int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out, char *err, size_t errlen, IngestOpts opts) {
     if (threads < 1) threads = 1;
     if (len == 0) return fail(err, errlen, "empty input");
     if (buf[0] == '@') return fail(err, errlen, "FASTQ input is not supported (FASTA expected)");
@@ -161,8 +303,8 @@ int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out,
     }
     {
         std::vector<std::thread> th;
-        for (size_t t = 1; t < nch; t++) th.emplace_back(census, buf, std::ref(ch[t]));
-        census(buf, ch[0]);
+        for (size_t t = 1; t < nch; t++) th.emplace_back(census, buf, std::ref(ch[t]), opts);
+        census(buf, ch[0], opts);
         for (auto &x : th) x.join();
     }
     // serial combine: record lengths, chunk offsets
@@ -171,8 +313,8 @@ int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out,
     for (size_t t = 0; t < nch; t++) {
         Chunk &c = ch[t];
         if (c.bad_at >= 0) {
-            char m[160];
-            snprintf(m, sizeof m, "character 0x%02x at byte %ld is not one of ACGTacgt (see otherTool/transferN for N)",
+            char m[200];
+            snprintf(m, sizeof m, "character 0x%02x at byte %ld is not one of ACGTacgt (N and other ambiguity letters: the IUPAC option, or otherTool/transferN)",
                      (unsigned)(unsigned char)buf[c.bad_at], c.bad_at);
             return fail(err, errlen, m);
         }
@@ -199,8 +341,8 @@ int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out,
     if (!words || !sep) { free(words); free(sep); return fail(err, errlen, "out of memory"); }
     {
         std::vector<std::thread> th;
-        for (size_t t = 1; t < nch; t++) th.emplace_back(pack, buf, std::cref(ch[t]), words, sep);
-        pack(buf, ch[0], words, sep);
+        for (size_t t = 1; t < nch; t++) th.emplace_back(pack, buf, std::cref(ch[t]), words, sep, opts);
+        pack(buf, ch[0], words, sep, opts);
         for (auto &x : th) x.join();
     }
     sep[nrec - 1] = n - 1;                                   // '$': 'T' there and 32 'T' behind (src/collect#$.c:85-90)
@@ -209,7 +351,7 @@ int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out,
     return 0;
 }
 
-int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, size_t errlen) {
+int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, size_t errlen, IngestOpts opts) {
     auto t0 = std::chrono::steady_clock::now();
     int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(err, errlen, "can not open ref file");                   // src/collect#$.c:36
@@ -242,17 +384,19 @@ int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, s
         gzclose(f);
         out->seconds_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         auto t1 = std::chrono::steady_clock::now();
-        rc = pack_fasta_buffer(buf, len, threads, out, err, errlen);
+        rc = pack_fasta_buffer(buf, len, threads, out, err, errlen, opts);
         out->seconds_pack = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
         free(buf);
         return rc;
     }
-    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+    // no MAP_POPULATE: the parser threads fault their own chunks in, in parallel
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (m == MAP_FAILED) return fail(err, errlen, "mmap failed");
+    (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
     out->seconds_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     auto t1 = std::chrono::steady_clock::now();
-    rc = pack_fasta_buffer((const char *)m, (size_t)st.st_size, threads, out, err, errlen);
+    rc = pack_fasta_buffer((const char *)m, (size_t)st.st_size, threads, out, err, errlen, opts);
     out->seconds_pack = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     munmap(m, (size_t)st.st_size);
     return rc;

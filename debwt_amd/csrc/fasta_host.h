@@ -13,7 +13,15 @@ struct PackedText {
     double seconds_pack;  // parse + pack
 };
 
+// flags: INGEST_IUPAC_RANDOM -- N and the other IUPAC ambiguity letters become one of the bases they stand for (the job
+// of the reference's otherTool/transferN.c:8-32,57-60, which draws with rand(); here the draw is a hash of `seed` and
+// the base's text position, so the packed text does not depend on the run or on the number of threads)
+enum : unsigned { INGEST_IUPAC_RANDOM = 1u };
+struct IngestOpts { unsigned flags; uint64_t seed; };
+
 // 0 on success; on failure -1 and a message in err
-int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out, char *err, size_t errlen);
-int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, size_t errlen);
+int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out, char *err, size_t errlen,
+                      IngestOpts opts = IngestOpts{0, 0});
+int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, size_t errlen,
+                    IngestOpts opts = IngestOpts{0, 0});
 void free_packed_text(PackedText *p);

@@ -96,6 +96,13 @@ typedef struct {
 int debwt_pack_fasta(const char *path, int threads, debwt_packed_text *out, char *errbuf, size_t errlen);
 void debwt_free_packed(debwt_packed_text *p);
 int debwt_load_fasta(debwt_ctx *ctx, const char *path, int threads);
+/* The same with options.  DEBWT_FASTA_IUPAC_RANDOM: N and the other IUPAC ambiguity letters are replaced by one of the
+ * bases they stand for -- what the reference leaves to otherTool/transferN.c (:8-32 tables, :57-60 draw with rand()),
+ * made deterministic: the draw is a hash of `seed` and the base's text position, independent of the thread count. */
+#define DEBWT_FASTA_IUPAC_RANDOM 1u
+int debwt_pack_fasta_opts(const char *path, int threads, unsigned flags, uint64_t seed, debwt_packed_text *out,
+                          char *errbuf, size_t errlen);
+int debwt_load_fasta_opts(debwt_ctx *ctx, const char *path, int threads, unsigned flags, uint64_t seed);
 
 /* Texts whose node instances (one 8-byte key per base) do not fit HBM at once, or number 2^32 or more, are built
  * in key ranges: prefix ranges of the k-mer space holding at most `max_instances` keys each, sorted and classified

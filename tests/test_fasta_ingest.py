@@ -122,3 +122,76 @@ def test_pack_fasta_empty_record_is_an_error(tmp_path):
     with pytest.raises(api.DebwtError) as ei:
         api.pack_fasta(p, 2)
     assert "Length <= 32" in str(ei.value)
+
+
+IUPAC_SETS = {"N": "ACGT", "V": "ACG", "D": "ATG", "B": "TCG", "H": "ATC", "W": "AT", "S": "CG", "K": "TG", "M": "AC",
+              "Y": "CT", "R": "AG"}           # otherTool/transferN.c:8-9,17-27
+
+
+def _unpack(words, n):
+    w = np.asarray(words, dtype=np.uint64)
+    sh = np.uint64(62) - np.uint64(2) * (np.arange(32, dtype=np.uint64))
+    return ((w[:, None] >> sh[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)[:n]
+
+
+@pytest.mark.parametrize("width", [60, 7, 200])
+def test_pack_fasta_iupac_replacement(tmp_path, width):
+    """transferN's job inside the ingest: every ambiguity letter becomes a base of its set, all other characters are
+    untouched, the result depends on the seed and the text position only (not on the thread count), and without the
+    option the same file is still an error."""
+    rng = np.random.default_rng(11)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    texts = []
+    for r in range(5):
+        s = letters[rng.integers(0, 4, size=int(rng.integers(200, 30000)))].copy()
+        for _ in range(int(rng.integers(1, 30))):
+            a = int(rng.integers(0, len(s) - 1)); b = min(len(s), a + int(rng.integers(1, 400)))
+            amb = list(IUPAC_SETS)[int(rng.integers(0, len(IUPAC_SETS)))]
+            s[a:b] = ord(amb.lower() if rng.integers(0, 2) else amb)
+        texts.append(s.tobytes())
+    p = str(tmp_path / "amb.fa")
+    with open(p, "wb") as f:
+        for i, t in enumerate(texts):
+            f.write(b">r%d\n" % i)
+            for a in range(0, len(t), width):
+                f.write(t[a:a + width] + b"\n")
+    with pytest.raises(api.DebwtError, match="not one of ACGTacgt"):
+        api.pack_fasta(p, 3)
+    w1, n1, sep1, _, _ = api.pack_fasta(p, 1, iupac_seed=5)
+    for threads in (2, 8, 64):
+        w, n, sep, _, _ = api.pack_fasta(p, threads, iupac_seed=5)
+        assert n == n1 and np.array_equal(sep, sep1) and np.array_equal(w, w1)
+    assert n1 == sum(len(t) for t in texts) + len(texts)
+    sym = _unpack(w1, n1)
+    pos = 0
+    for t in texts:
+        got = sym[pos:pos + len(t)]
+        src = np.frombuffer(t.upper(), dtype=np.uint8)
+        for ch, code in zip(b"ACGT", range(4)):
+            assert (got[src == ch] == code).all()
+        for amb, allowed in IUPAC_SETS.items():
+            m = src == ord(amb)
+            if m.any():
+                ok = np.isin(got[m], [b"ACGT".index(c) for c in allowed.encode()])
+                assert ok.all()
+                if m.sum() > 200:
+                    assert len(np.unique(got[m])) == len(allowed)           # every member of the set is drawn
+        pos += len(t)
+        assert sym[pos] == 3                                                 # separator
+        pos += 1
+    w2, _, _, _, _ = api.pack_fasta(p, 4, iupac_seed=6)
+    assert not np.array_equal(w2, w1)
+
+
+@pytest.mark.parametrize("width", [1, 2, 5, 16, 30, 31, 32, 33, 63, 64, 65])
+@pytest.mark.parametrize("novec", [False, True])
+def test_pack_fasta_line_widths_around_the_vector_block(tmp_path, recs, width, novec, monkeypatch):
+    """Lines shorter than, equal to and just above the 32-character block of the vectorised classifier (several line
+    breaks per block, a break at the block's last byte, a header right behind it), with and without AVX2."""
+    if novec:
+        monkeypatch.setenv("DEBWT_INGEST_NO_AVX2", "1")
+    sub = recs[:7]
+    p = str(tmp_path / "w.fa")
+    _write(p, sub, width=width)
+    for threads in (1, 5):
+        _check(p, sub, threads)
