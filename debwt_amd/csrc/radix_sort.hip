@@ -968,11 +968,15 @@ __global__ __launch_bounds__(256) void rs_tile_emit_kernel(const u64 *__restrict
     const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
     if (s >= e || e - s > RLW_CAP) return;
     u64 off = (u64)tex[t] + boff[t / RLT_BLOCK];
+    u64 carry = 0;
     for (u64 p = s; p < e; p += 64) {
         const u64 j = p + lane;
         const bool valid = j < e;
         const u64 k = valid ? keys[j] : 0ull;
-        const bool head = valid && (j == s || keys[j - 1] != k);
+        u64 before = __shfl_up(k, 1, 64);                 // the key before: lane below, or the last key of the previous step
+        if (lane == 0) before = carry;
+        carry = __shfl(k, 63, 64);
+        const bool head = valid && (j == s || before != k);
         const u64 bm = __ballot(head);
         if (head) {
             const u64 o = off + (u32)__popcll(bm & ((1ull << lane) - 1ull));

@@ -61,3 +61,31 @@ def test_cli_gzip_input(tmp_path):
     r = subprocess.run([CLI, "-o", out, str(gz)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert np.array_equal(np.fromfile(out, dtype=np.uint64), golden_outputs(entry)[0])
+
+
+@pytest.mark.gpu
+def test_cli_iupac_option(tmp_path):
+    """A FASTA with N runs: refused as the reference's reader refuses it, accepted with --iupac, and then the BWT is the
+    BWT of the text the ingest produced (same seed through the API)."""
+    from debwt_amd import api
+    assert _have_cli()
+    rng = np.random.default_rng(8)
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=20000)].copy()
+    s[3000:3400] = ord("N"); s[9000:9007] = ord("r"); s[15000] = ord("Y")
+    fa = tmp_path / "n.fa"
+    with open(fa, "wb") as f:
+        f.write(b">withN\n")
+        for a in range(0, len(s), 70):
+            f.write(s[a:a + 70].tobytes() + b"\n")
+    out = str(tmp_path / "OUT")
+    r = subprocess.run([CLI, "-o", out, str(fa)], capture_output=True, text=True)
+    assert r.returncode == 1 and "not one of ACGTacgt" in r.stderr
+    r = subprocess.run([CLI, "-o", out, "--iupac", "12345", str(fa)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = api.DeBWT(k=32)
+    d.load_fasta(str(fa), threads=3, iupac_seed=12345)
+    d.build()
+    words, hrows, drow = d.fetch()
+    d.close()
+    assert np.array_equal(np.fromfile(out, dtype=np.uint64), words)
+    assert int(np.fromfile(out + ".$", dtype=np.uint64)[0]) == drow
