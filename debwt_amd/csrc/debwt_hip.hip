@@ -70,7 +70,7 @@ struct debwt_ctx {
     u64 nfacts_acc = 0;         // facts accumulated over the ranges
     bool local_done = false;    // classify_local already ran per range (multi-range build)
     bool plan_valid = false;    // `ranges` holds the cuts of the loaded text (several ranges)
-    DevBuf blk_j0, blk_freq, blk_start, facts_acc, large_tmp, blue_tmp, sub_start, sub_j0, sub_freq, sub_depth, range_hist;
+    DevBuf ls_buf, blk_j0, blk_freq, blk_start, facts_acc, large_tmp, blue_tmp, sub_start, sub_j0, sub_freq, sub_depth, range_hist;
     // k-mer-prefix shard of a multi-GPU build (world == 1: the whole key space)
     int shard_rank = 0, shard_world = 1;
     u64 Mfull = 0;              // node instances of the whole text
@@ -265,7 +265,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
                      &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
                      &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
                      &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
-                     &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0, &c->sub_freq, &c->sub_depth, &c->range_hist};
+                     &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0, &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
@@ -861,6 +861,105 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
 // ---------------------------------------------------------------------------------------------------
 // stage 4: blue-block sort                                                                     (a-5)
 
+// blocks above BLUE_LDS_CAP rows (see LargeSplit)
+static int bitonic_large(debwt_ctx *c, u64 b0, u32 m, u64 j0) {
+    u64 P = 2;
+    while (P < m) P <<= 1;
+    ENSURE(c, c->large_k0, P * 8);
+    ENSURE(c, c->large_en, P * 8);
+    k_large_load<<<grid_for(P, 256), 256, 0, c->stream>>>(c->blue.as<u64>(), b0, m, P, c->spn.as<u64>(),
+                                                          c->large_k0.as<u64>(), c->large_en.as<u64>());
+    for (u64 kk = 2; kk <= P; kk <<= 1)
+        for (u64 jj = kk >> 1; jj > 0; jj >>= 1)
+            k_large_step<<<grid_for(P >> 1, 256), 256, 0, c->stream>>>(
+                c->large_k0.as<u64>(), c->large_en.as<u64>(), P, kk, jj, c->spn.as<u64>(), c->S);
+    k_large_store<<<grid_for(m, 256), 256, 0, c->stream>>>(c->blue.as<u64>(), b0, m, j0, c->large_en.as<u64>(), c->mchar.as<u8>());
+    return DEBWT_OK;
+}
+
+static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
+    int rc;
+    std::vector<u32> lq(c->nlarge), fr(c->nlarge);
+    std::vector<u64> bs(c->nlarge), j0(c->nlarge);
+    HIPCHK(c, hipMemcpyAsync(lq.data(), c->large_q.p, c->nlarge * 4, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = sync_check(c))) return rc;
+    for (u64 t = 0; t < c->nlarge; t++) {
+        HIPCHK(c, hipMemcpyAsync(&fr[t], c->blk_freq.as<u32>() + lq[t], 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&bs[t], c->blk_start.as<u64>() + lq[t], 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&j0[t], c->blk_j0.as<u64>() + lq[t], 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    if ((rc = sync_check(c))) return rc;
+    u32 maxm = 0;
+    for (u64 t = 0; t < c->nlarge; t++) maxm = std::max(maxm, fr[t]);
+    c->st.blue_max_block = maxm;
+    // rounds: every pending block is split in the same five launches (batches of at most LS_BATCH_ROWS rows of
+    // scratch), one synchronisation per batch; the ranges a batch reports as still too large are the next round's blocks
+    constexpr u64 LS_BATCH_ROWS = 1ull << 28;
+    struct Work { u64 b0, j0; u32 m; };
+    std::vector<Work> work, next;
+    for (u64 t = 0; t < c->nlarge; t++) work.push_back(Work{bs[t], j0[t], fr[t]});
+    if (c->cfg.reserved & 1024) {                                  // bit 10: bitonic network only (tests)
+        for (const Work &wk : work) if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc;
+        return DEBWT_OK;
+    }
+    std::vector<u32> res;
+    std::vector<LsBlock> desc;
+    while (!work.empty()) {
+        next.clear();
+        for (size_t w0 = 0; w0 < work.size();) {
+            desc.clear();
+            u64 rows = 0, wgs = 0;
+            size_t w1 = w0;
+            for (; w1 < work.size() && (desc.empty() || rows + work[w1].m <= LS_BATCH_ROWS) && wgs < 0x7FFF0000ull; w1++) {
+                const Work &wk = work[w1];
+                u32 nb = 8;
+                while (nb < LS_MAXBINS && (u64)nb * 384 < wk.m) nb <<= 1;
+                u32 ns = std::min<u32>(LS_SAMPLES, std::max<u32>(64u, nb * 8u));
+                desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs});
+                rows += (wk.m + 1u) & ~1u;
+                wgs += (wk.m + 255u) / 256u;
+            }
+            const size_t nblk = desc.size();
+            // scratch: w, x, en (u64 per row), bin (u32 per row); per block: splitters, range words, results, descriptor
+            const size_t per_blk = LS_MAXBINS * (16 + 12) + LS_RES * 4 + sizeof(LsBlock);
+            ENSURE(c, c->ls_buf, rows * 28 + nblk * per_blk + 256);
+            u64 *p64 = c->ls_buf.as<u64>();
+            LargeSplit ls{};
+            ls.nblk = (u32)nblk;
+            ls.w = p64; ls.x = p64 + rows; ls.en = p64 + 2 * rows;
+            ls.spl_w = p64 + 3 * rows; ls.spl_x = ls.spl_w + nblk * LS_MAXBINS;
+            LsBlock *dblk = reinterpret_cast<LsBlock *>(ls.spl_x + nblk * LS_MAXBINS);
+            ls.blk = dblk;
+            ls.bin = reinterpret_cast<u32 *>(dblk + nblk);
+            ls.cnt = ls.bin + rows; ls.start = ls.cnt + nblk * LS_MAXBINS; ls.cur = ls.start + nblk * LS_MAXBINS;
+            ls.res = ls.cur + nblk * LS_MAXBINS;
+            HIPCHK(c, hipMemcpyAsync(dblk, desc.data(), nblk * sizeof(LsBlock), hipMemcpyHostToDevice, c->stream));
+            k_ls_windows<<<(u32)wgs, 256, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
+            k_ls_splitters<<<(u32)nblk, 1024, 0, c->stream>>>(ls);
+            k_ls_bin<<<(u32)wgs, 256, 0, c->stream>>>(ls);
+            k_ls_plan<<<(u32)nblk, LS_MAXBINS, 0, c->stream>>>(ls, sub);
+            k_ls_scatter<<<(u32)wgs, 256, 0, c->stream>>>(c->blue.as<u64>(), ls);
+            res.resize(nblk * LS_RES);
+            HIPCHK(c, hipMemcpyAsync(res.data(), ls.res, res.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            if ((rc = sync_check(c))) return rc;                   // desc and res are host memory
+            for (size_t i = 0; i < nblk; i++) {
+                const Work &wk = work[w0 + i];
+                const u32 *r = res.data() + i * LS_RES;
+                if (r[0]) { if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc; continue; }   // queue full: nothing moved
+                for (u32 o = 0; o < r[1]; o++) {
+                    const u32 st = r[2 + 2 * o], cnt = r[3 + 2 * o];
+                    // a range that holds every row: the first two windows do not separate them -- the network compares deeper
+                    if (cnt == wk.m) { if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc; }
+                    else next.push_back(Work{wk.b0 + st, wk.j0 + st, cnt});
+                }
+            }
+            w0 = w1;
+        }
+        work.swap(next);
+    }
+    return DEBWT_OK;
+}
+
 extern "C" int debwt_blue_sort(debwt_ctx *c) {
     if (!c) return DEBWT_EINVAL;
     if (c->stage < ST_SP) return DEBWT_ESTATE;
@@ -868,6 +967,7 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
     int rc;
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     const u64 Q = c->Q;
+    c->st.blue_max_block = 0;
     if (Q) {
         // sub-block table for the deep tie groups of the larger size classes (BlueSub)
         const u32 sub_cap = (u32)std::min<u64>(std::max<u64>(c->B / 8, 1u << 16), 1u << 26);
@@ -903,6 +1003,9 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
                                                                       c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
                                                                       split1024 ? 1024u : (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
                                                                       c->mchar.as<u8>(), nullptr, nullptr, sub);
+        // heavy-tail blocks (satellite / poly-A nodes), before the queue is drained: split in HBM into ranges the LDS
+        // kernels take (queued like the tie groups); what a split cannot separate goes through the bitonic network
+        if (c->nlarge && (rc = sort_large_blocks(c, sub))) return rc;
         // the queued groups: blocks of their own that start `depth` windows in (<= 128 rows from the 512 class,
         // <= 512 rows from the 2048 class)
         const u32 gs = std::min<u32>(sub_cap, 1u << 16);
@@ -912,39 +1015,9 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
         k_blue_refine<64, BLUE_WAVE_CAP, 0><<<gs, 64, 0, c->stream>>>(
             c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 128u,
             c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
-    }
-    c->st.blue_max_block = 0;
-    if (c->nlarge) {
-        // heavy-tail blocks (satellite / poly-A nodes): bitonic network in HBM, one block at a time
-        std::vector<u32> lq(c->nlarge), fr(c->nlarge);
-        std::vector<u64> bs(c->nlarge), j0(c->nlarge);
-        HIPCHK(c, hipMemcpyAsync(lq.data(), c->large_q.p, c->nlarge * 4, hipMemcpyDeviceToHost, c->stream));
-        if ((rc = sync_check(c))) return rc;
-        for (u64 t = 0; t < c->nlarge; t++) {
-            HIPCHK(c, hipMemcpyAsync(&fr[t], c->blk_freq.as<u32>() + lq[t], 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(&bs[t], c->blk_start.as<u64>() + lq[t], 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(&j0[t], c->blk_j0.as<u64>() + lq[t], 8, hipMemcpyDeviceToHost, c->stream));
-        }
-        if ((rc = sync_check(c))) return rc;
-        u32 maxm = 0;
-        for (u64 t = 0; t < c->nlarge; t++) maxm = std::max(maxm, fr[t]);
-        c->st.blue_max_block = maxm;
-        u64 Pmax = 2;
-        while (Pmax < maxm) Pmax <<= 1;
-        ENSURE(c, c->large_k0, Pmax * 8);
-        ENSURE(c, c->large_en, Pmax * 8);
-        for (u64 t = 0; t < c->nlarge; t++) {
-            u64 P = 2;
-            while (P < fr[t]) P <<= 1;
-            k_large_load<<<grid_for(P, 256), 256, 0, c->stream>>>(c->blue.as<u64>(), bs[t], fr[t], P, c->spn.as<u64>(),
-                                                                  c->large_k0.as<u64>(), c->large_en.as<u64>());
-            for (u64 kk = 2; kk <= P; kk <<= 1)
-                for (u64 jj = kk >> 1; jj > 0; jj >>= 1)
-                    k_large_step<<<grid_for(P >> 1, 256), 256, 0, c->stream>>>(
-                        c->large_k0.as<u64>(), c->large_en.as<u64>(), P, kk, jj, c->spn.as<u64>(), c->S);
-            k_large_store<<<grid_for(fr[t], 256), 256, 0, c->stream>>>(c->blue.as<u64>(), bs[t], fr[t], j0[t],
-                                                                       c->large_en.as<u64>(), c->mchar.as<u8>());
-        }
+        k_blue_refine<256, BLUE_LDS_CAP, 0><<<std::min<u32>(gs, 1u << 12), 256, 0, c->stream>>>(
+            c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, (u32)BLUE_WAVE_CAP,
+            c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
     }
     c->stage = ST_BLUE;
     return DEBWT_OK;

@@ -1069,6 +1069,128 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
 
 #define BLUE_LDS_CAP 2048
 
+// Blocks above BLUE_LDS_CAP rows: one level of sample sort in HBM, all pending blocks in the same five launches.
+// Per block: the first 42 SP symbols (two windows) of `ns` evenly spaced rows are sorted by one workgroup, nb - 1 of
+// them become splitters, every row finds its range by bisection (rows with equal windows share a range) and is moved
+// there; ranges of <= BLUE_LDS_CAP rows are queued as blocks of their own for the LDS kernels, larger ones go back to
+// the host (split again, or the bitonic network when the split does not separate them).
+#define LS_SAMPLES 4096
+#define LS_MAXBINS 1024
+#define LS_RES (2 + 2 * LS_MAXBINS)
+struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0; };     // row0: first scratch row; wg0: first 256-row workgroup
+struct LargeSplit {
+    const LsBlock *blk; u32 nblk;
+    u64 *w, *x, *en;                  // per row: first two windows, entry (copy)
+    u32 *bin;                         // per row: its range
+    u64 *spl_w, *spl_x;               // per block: LS_MAXBINS splitters
+    u32 *cnt, *start, *cur;           // per block: LS_MAXBINS ranges
+    u32 *res;                         // per block: LS_RES words -- [0] = 1: sub-block table full (nothing queued, nothing
+};                                    // moved); [1] = oversize ranges, then their (start, rows) pairs
+__device__ __forceinline__ u32 ls_block_of(const LargeSplit &ls, u32 wg) {
+    u32 lo = 0, hi = ls.nblk;                                // last block whose first workgroup is <= wg
+    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (ls.blk[mid].wg0 <= wg) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_ls_windows(const u64 *__restrict__ blue, const u64 *__restrict__ spn, u64 S, LargeSplit ls) {
+    const u32 bi = ls_block_of(ls, blockIdx.x);
+    const LsBlock B = ls.blk[bi];
+    const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
+    if (i >= B.m) return;
+    const u64 e = blue[B.b0 + i];
+    const u64 pos = e >> 4;
+    const bool live = pos < S;
+    ls.en[B.row0 + i] = e;
+    ls.w[B.row0 + i] = live ? sp_window(spn, pos) : 0ull;
+    ls.x[B.row0 + i] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
+}
+__global__ __launch_bounds__(1024) void k_ls_splitters(LargeSplit ls) {
+    __shared__ u64 sw[LS_SAMPLES], sx[LS_SAMPLES];
+    const LsBlock B = ls.blk[blockIdx.x];
+    const u32 tid = threadIdx.x, ns = B.ns;
+    for (u32 i = tid; i < ns; i += 1024) {
+        const u64 r = B.row0 + ((u64)i * B.m) / ns;
+        sw[i] = ls.w[r]; sx[i] = ls.x[r];
+    }
+    if (tid < LS_MAXBINS) { ls.cnt[blockIdx.x * LS_MAXBINS + tid] = 0; ls.cur[blockIdx.x * LS_MAXBINS + tid] = 0; }
+    __syncthreads();
+    for (u32 kk = 2; kk <= ns; kk <<= 1)
+        for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (u32 t = tid; t < ns / 2; t += 1024) {
+                const u32 i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), l = i | jj;
+                const u64 wi = sw[i], wl = sw[l], xi = sx[i], xl = sx[l];
+                const bool l_less = wl != wi ? wl < wi : xl < xi;
+                const bool i_less = wl != wi ? wi < wl : xi < xl;
+                if (((i & kk) == 0) ? l_less : i_less) { sw[i] = wl; sw[l] = wi; sx[i] = xl; sx[l] = xi; }
+            }
+            __syncthreads();
+        }
+    // splitter b = sorted sample (b + 1) * ns / nb - 1, b < nb - 1
+    for (u32 b = tid; b + 1 < B.nb; b += 1024) {
+        const u32 i = (b + 1) * (ns / B.nb) - 1;
+        ls.spl_w[blockIdx.x * LS_MAXBINS + b] = sw[i]; ls.spl_x[blockIdx.x * LS_MAXBINS + b] = sx[i];
+    }
+}
+__global__ __launch_bounds__(256) void k_ls_bin(LargeSplit ls) {
+    const u32 bi = ls_block_of(ls, blockIdx.x);
+    const LsBlock B = ls.blk[bi];
+    const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
+    if (i >= B.m) return;
+    const u64 w = ls.w[B.row0 + i], x = ls.x[B.row0 + i];
+    const u64 *spw = ls.spl_w + (size_t)bi * LS_MAXBINS, *spx = ls.spl_x + (size_t)bi * LS_MAXBINS;
+    u32 lo = 0, hi = B.nb - 1;                               // range = number of splitters below the row's windows
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        const u64 sw = spw[mid], sx = spx[mid];
+        if (sw != w ? sw < w : sx < x) lo = mid + 1; else hi = mid;
+    }
+    ls.bin[B.row0 + i] = lo;
+    atomicAdd(&ls.cnt[bi * LS_MAXBINS + lo], 1u);
+}
+// one workgroup per block: range starts; ranges of <= BLUE_LDS_CAP rows become sub-blocks, larger ones are reported
+__global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub sub) {
+    __shared__ u32 part[LS_MAXBINS];
+    __shared__ u32 nsub, nover, base, full;
+    const LsBlock B = ls.blk[blockIdx.x];
+    u32 *res = ls.res + (size_t)blockIdx.x * LS_RES;
+    const u32 tid = threadIdx.x;
+    const u32 c = tid < B.nb ? ls.cnt[blockIdx.x * LS_MAXBINS + tid] : 0u;
+    part[tid] = c;
+    if (tid == 0) { nsub = 0; nover = 0; full = 0; }
+    __syncthreads();
+    for (u32 d = 1; d < LS_MAXBINS; d <<= 1) {
+        const u32 v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const u32 st = part[tid] - c;
+    if (tid < B.nb) ls.start[blockIdx.x * LS_MAXBINS + tid] = st;
+    const bool small = c >= 1 && c <= BLUE_LDS_CAP, big = c > BLUE_LDS_CAP;
+    u32 my = 0;
+    if (small) my = atomicAdd(&nsub, 1u);
+    if (big) { const u32 o = atomicAdd(&nover, 1u); res[2 + 2 * o] = st; res[3 + 2 * o] = c; }
+    __syncthreads();
+    if (tid == 0) {
+        base = atomicAdd(sub.count, nsub);
+        full = (u64)base + nsub > (u64)sub.cap ? 1u : 0u;
+        res[0] = full; res[1] = nover;
+    }
+    __syncthreads();
+    if (small && !full) {
+        const u32 e = base + my;
+        sub.start[e] = B.b0 + st; sub.freq[e] = c; sub.j0[e] = B.j0 + st; sub.depth[e] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_ls_scatter(u64 *__restrict__ blue, LargeSplit ls) {
+    const u32 bi = ls_block_of(ls, blockIdx.x);
+    const LsBlock B = ls.blk[bi];
+    const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
+    if (i >= B.m) return;
+    if (ls.res[(size_t)bi * LS_RES]) return;                 // nothing was queued: the rows stay for the network
+    const u32 b = ls.bin[B.row0 + i];
+    blue[B.b0 + ls.start[bi * LS_MAXBINS + b] + atomicAdd(&ls.cur[bi * LS_MAXBINS + b], 1u)] = ls.en[B.row0 + i];
+}
+
 // large blocks: bitonic network in global memory, one launch per compare-exchange distance
 __global__ void k_large_load(const u64 *__restrict__ blue, u64 b0, u32 m, u64 P, const u64 *__restrict__ spn,
                              u64 *__restrict__ k0, u64 *__restrict__ en) {

@@ -11,7 +11,7 @@ parts = []
 for i in range(copies):
     parts.append(unit); parts.append(rng.integers(0, 4, size=int(rng.integers(3, 9))).astype(np.uint8))
 recs = [np.concatenate(parts), rng.integers(0, 4, size=500).astype(np.uint8)]
-d = api.DeBWT(k=32); d.load_records(recs)
+d = api.DeBWT(k=32, tune=int(__import__("os").environ.get("TUNE", "0"))); d.load_records(recs)
 d.build(); t0 = time.time(); d.build(); dt = time.time() - t0
 st = d.stats()
 print(f"copies={copies} n={st['n']} build {dt*1e3:.1f} ms, blue stage {st['ms_blue']:.1f} ms, large blocks {st['blue_large_blocks']} max {st['blue_max_block']}")

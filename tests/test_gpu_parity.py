@@ -151,8 +151,10 @@ def test_hip_block_size_classes(api, oracle):
     d.close()
 
 
-def test_hip_large_block_path(api, oracle):
-    """A node with more occurrences than one workgroup's LDS holds goes through the HBM bitonic path."""
+@pytest.mark.parametrize("tune", [0, 1024, 128])
+def test_hip_large_block_path(api, oracle, tune):
+    """A node with more occurrences than one workgroup's LDS holds: split in HBM into ranges for the LDS kernels (0),
+    the bitonic network in HBM alone (1024), and the network as the fall-back when nothing can be queued (128)."""
     rng = np.random.default_rng(5)
     unit = rng.integers(0, 4, size=40).astype(np.uint8)
     parts = []
@@ -162,10 +164,42 @@ def test_hip_large_block_path(api, oracle):
     recs = [np.concatenate(parts), rng.integers(0, 4, size=500).astype(np.uint8)]
     sym = oracle.sym_from_codes(recs)
     ow, oh, od, _ = oracle.build_bwt(sym, 32)
-    d, (words, hrows, drow), st = _run(api, recs, 32)
+    d = api.DeBWT(k=32, tune=tune)
+    d.load_records(recs)
+    d.build()
+    words, hrows, drow = d.fetch()
+    st = d.stats()
     assert st["blue_large_blocks"] >= 1 and st["blue_max_block"] > 2048
     assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
     d.close()
+
+
+def test_hip_large_blocks_with_long_ties(api, oracle):
+    """Large blocks whose rows stay tied beyond the first two SP windows (long exact repeats of a branching unit): the
+    split queues what it separates and hands ranges it cannot separate to the network."""
+    rng = np.random.default_rng(9)
+    core = rng.integers(0, 4, size=36).astype(np.uint8)
+    # a long segment built from the core with small variable spacers: many branching nodes, repeated exactly
+    seg_parts = []
+    for _ in range(60):
+        seg_parts.append(core)
+        seg_parts.append(rng.integers(0, 4, size=int(rng.integers(2, 6))).astype(np.uint8))
+    seg = np.concatenate(seg_parts)
+    parts = []
+    for i in range(70):                                       # 70 exact copies of the segment: 4200 copies of the core
+        parts.append(seg)
+        parts.append(rng.integers(0, 4, size=int(rng.integers(40, 90))).astype(np.uint8))
+    recs = [np.concatenate(parts), rng.integers(0, 4, size=300).astype(np.uint8)]
+    ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), 32)
+    for tune in (0, 1024):
+        d = api.DeBWT(k=32, tune=tune)
+        d.load_records(recs)
+        d.build()
+        words, hrows, drow = d.fetch()
+        st = d.stats()
+        assert st["blue_large_blocks"] >= 1
+        assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od, tune
+        d.close()
 
 
 def test_hip_properties_at_bench_size(api):
