@@ -895,9 +895,12 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
     // rounds: every pending block is split in the same five launches (batches of at most LS_BATCH_ROWS rows of
     // scratch), one synchronisation per batch; the ranges a batch reports as still too large are the next round's blocks
     constexpr u64 LS_BATCH_ROWS = 1ull << 28;
-    struct Work { u64 b0, j0; u32 m; };
+    // ties that outlast this many pairs of windows (runs of one symbol, tandem repeats: the tie shrinks by a window
+    // per round) go to the network, whose comparator walks as far as it has to
+    constexpr u32 LS_MAX_DEPTH = 3;
+    struct Work { u64 b0, j0; u32 m, depth; };
     std::vector<Work> work, next;
-    for (u64 t = 0; t < c->nlarge; t++) work.push_back(Work{bs[t], j0[t], fr[t]});
+    for (u64 t = 0; t < c->nlarge; t++) work.push_back(Work{bs[t], j0[t], fr[t], 0u});
     if (c->cfg.reserved & 1024) {                                  // bit 10: bitonic network only (tests)
         for (const Work &wk : work) if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc;
         return DEBWT_OK;
@@ -915,13 +918,13 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
                 u32 nb = 8;
                 while (nb < LS_MAXBINS && (u64)nb * 384 < wk.m) nb <<= 1;
                 u32 ns = std::min<u32>(LS_SAMPLES, std::max<u32>(64u, nb * 8u));
-                desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs});
+                desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs, wk.depth, 0u});
                 rows += (wk.m + 1u) & ~1u;
                 wgs += (wk.m + 255u) / 256u;
             }
             const size_t nblk = desc.size();
             // scratch: w, x, en (u64 per row), bin (u32 per row); per block: splitters, range words, results, descriptor
-            const size_t per_blk = LS_MAXBINS * (16 + 12) + LS_RES * 4 + sizeof(LsBlock);
+            const size_t per_blk = LS_MAXBINS * 16 + LS_MAXR * 12 + LS_RES * 4 + sizeof(LsBlock);
             ENSURE(c, c->ls_buf, rows * 28 + nblk * per_blk + 256);
             u64 *p64 = c->ls_buf.as<u64>();
             LargeSplit ls{};
@@ -931,8 +934,8 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
             LsBlock *dblk = reinterpret_cast<LsBlock *>(ls.spl_x + nblk * LS_MAXBINS);
             ls.blk = dblk;
             ls.bin = reinterpret_cast<u32 *>(dblk + nblk);
-            ls.cnt = ls.bin + rows; ls.start = ls.cnt + nblk * LS_MAXBINS; ls.cur = ls.start + nblk * LS_MAXBINS;
-            ls.res = ls.cur + nblk * LS_MAXBINS;
+            ls.cnt = ls.bin + rows; ls.start = ls.cnt + nblk * LS_MAXR; ls.cur = ls.start + nblk * LS_MAXR;
+            ls.res = ls.cur + nblk * LS_MAXR;
             HIPCHK(c, hipMemcpyAsync(dblk, desc.data(), nblk * sizeof(LsBlock), hipMemcpyHostToDevice, c->stream));
             k_ls_windows<<<(u32)wgs, 256, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
             k_ls_splitters<<<(u32)nblk, 1024, 0, c->stream>>>(ls);
@@ -946,14 +949,30 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
                 const Work &wk = work[w0 + i];
                 const u32 *r = res.data() + i * LS_RES;
                 if (r[0]) { if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc; continue; }   // queue full: nothing moved
+                // a range of ties that is most of the block: a run of one symbol or a tandem repeat -- the tie shrinks by
+                // one window per round; the whole block goes to the network as it is (the ranges already queued are
+                // ranges of the sorted block too, the LDS kernels find them in order)
+                bool low_complexity = false;
+                for (u32 o = 0; o < r[1]; o++) low_complexity |= r[4 + 3 * o] && (u64)r[3 + 3 * o] * 2 > wk.m;
+                if (low_complexity) { if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc; continue; }
                 for (u32 o = 0; o < r[1]; o++) {
-                    const u32 st = r[2 + 2 * o], cnt = r[3 + 2 * o];
-                    // a range that holds every row: the first two windows do not separate them -- the network compares deeper
-                    if (cnt == wk.m) { if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc; }
-                    else next.push_back(Work{wk.b0 + st, wk.j0 + st, cnt});
+                    const u32 st = r[2 + 3 * o], cnt = r[3 + 3 * o], ties = r[4 + 3 * o];
+                    // a range of ties is split on the next pair of windows, any other on finer splitters (it cannot
+                    // hold every row: the splitters are rows)
+                    const u64 deeper = ((u64)wk.depth + 2) * (2 * SP_WIN);
+                    if (ties && wk.depth < LS_MAX_DEPTH && deeper < c->S + 2 * SP_WIN)
+                        next.push_back(Work{wk.b0 + st, wk.j0 + st, cnt, wk.depth + 1});
+                    else if (!ties && cnt < wk.m) next.push_back(Work{wk.b0 + st, wk.j0 + st, cnt, wk.depth});
+                    else if ((rc = bitonic_large(c, wk.b0 + st, cnt, wk.j0 + st))) return rc;
                 }
             }
             w0 = w1;
+        }
+        if (getenv("DEBWT_TRACE_LARGE")) {
+            u32 dmax = 0; u64 rows = 0;
+            for (const Work &wk : next) { dmax = std::max(dmax, wk.depth); rows += wk.m; }
+            fprintf(stderr, "large blocks: round of %zu blocks -> %zu ranges to split again (%llu rows, deepest %u)\n",
+                    work.size(), next.size(), (unsigned long long)rows, dmax);
         }
         work.swap(next);
     }

@@ -1070,22 +1070,42 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
 #define BLUE_LDS_CAP 2048
 
 // Blocks above BLUE_LDS_CAP rows: one level of sample sort in HBM, all pending blocks in the same five launches.
-// Per block: the first 42 SP symbols (two windows) of `ns` evenly spaced rows are sorted by one workgroup, nb - 1 of
-// them become splitters, every row finds its range by bisection (rows with equal windows share a range) and is moved
-// there; ranges of <= BLUE_LDS_CAP rows are queued as blocks of their own for the LDS kernels, larger ones go back to
-// the host (split again, or the bitonic network when the split does not separate them).
+// Per block: the next 42 SP symbols (two windows, `depth` pairs in) of `ns` evenly spaced rows are sorted by one
+// workgroup, nb - 1 of them become splitters, every row finds its range by bisection -- below a splitter, or equal
+// to it: the rows that tie with a splitter form a range of their own -- and is moved there; ranges of <= BLUE_LDS_CAP
+// rows are queued as blocks of their own for the LDS kernels, larger ones go back to the host: split again, one pair
+// of windows deeper when it is a range of ties.
 #define LS_SAMPLES 4096
-#define LS_MAXBINS 1024
-#define LS_RES (2 + 2 * LS_MAXBINS)
-struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0; };     // row0: first scratch row; wg0: first 256-row workgroup
+#define LS_MAXBINS 1024                // splitters + 1
+#define LS_MAXR (2 * LS_MAXBINS)       // ranges: below splitter 0, equal to it, between 0 and 1, equal to 1, ...
+#define LS_RES (2 + 3 * LS_MAXR)
+struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0, depth, pad; };   // row0: first scratch row; wg0: first 256-row
+                                                                        // workgroup; depth: windows already equal
 struct LargeSplit {
     const LsBlock *blk; u32 nblk;
     u64 *w, *x, *en;                  // per row: first two windows, entry (copy)
     u32 *bin;                         // per row: its range
     u64 *spl_w, *spl_x;               // per block: LS_MAXBINS splitters
-    u32 *cnt, *start, *cur;           // per block: LS_MAXBINS ranges
+    u32 *cnt, *start, *cur;           // per block: LS_MAXR ranges
     u32 *res;                         // per block: LS_RES words -- [0] = 1: sub-block table full (nothing queued, nothing
-};                                    // moved); [1] = oversize ranges, then their (start, rows) pairs
+};                                    // moved); [1] = oversize ranges, then their (start, rows, ties) triples
+// atomicAdd(&ctr[r], 1) for every active lane; returns what it returned.  When the whole wave names the same counter
+// (most rows of a low-complexity block share a range) one lane adds for all.  All lanes of the wave must call it;
+// lanes with !active take no part.
+__device__ __forceinline__ u32 ls_wave_add(u32 *__restrict__ ctr, u32 r, bool active) {
+    const u64 todo = __ballot(active);
+    if (!todo) return 0;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 leader = (u32)__builtin_ctzll(todo);
+    const u32 r0 = __shfl(r, (int)leader, 64);
+    if (__ballot(active && r == r0) == todo) {
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&ctr[r0], (u32)__popcll(todo));
+        base = __shfl(base, (int)leader, 64);
+        return base + (u32)__popcll(todo & ((1ull << lane) - 1ull));
+    }
+    return active ? atomicAdd(&ctr[r], 1u) : 0u;
+}
 __device__ __forceinline__ u32 ls_block_of(const LargeSplit &ls, u32 wg) {
     u32 lo = 0, hi = ls.nblk;                                // last block whose first workgroup is <= wg
     while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (ls.blk[mid].wg0 <= wg) lo = mid; else hi = mid; }
@@ -1097,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_ls_windows(const u64 *__restrict__ blue
     const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
     if (i >= B.m) return;
     const u64 e = blue[B.b0 + i];
-    const u64 pos = e >> 4;
+    const u64 pos = (e >> 4) + (u64)B.depth * (2 * SP_WIN);
     const bool live = pos < S;
     ls.en[B.row0 + i] = e;
     ls.w[B.row0 + i] = live ? sp_window(spn, pos) : 0ull;
@@ -1111,7 +1131,7 @@ __global__ __launch_bounds__(1024) void k_ls_splitters(LargeSplit ls) {
         const u64 r = B.row0 + ((u64)i * B.m) / ns;
         sw[i] = ls.w[r]; sx[i] = ls.x[r];
     }
-    if (tid < LS_MAXBINS) { ls.cnt[blockIdx.x * LS_MAXBINS + tid] = 0; ls.cur[blockIdx.x * LS_MAXBINS + tid] = 0; }
+    for (u32 i = tid; i < LS_MAXR; i += 1024) { ls.cnt[blockIdx.x * LS_MAXR + i] = 0; ls.cur[blockIdx.x * LS_MAXR + i] = 0; }
     __syncthreads();
     for (u32 kk = 2; kk <= ns; kk <<= 1)
         for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
@@ -1134,17 +1154,22 @@ __global__ __launch_bounds__(256) void k_ls_bin(LargeSplit ls) {
     const u32 bi = ls_block_of(ls, blockIdx.x);
     const LsBlock B = ls.blk[bi];
     const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
-    if (i >= B.m) return;
-    const u64 w = ls.w[B.row0 + i], x = ls.x[B.row0 + i];
-    const u64 *spw = ls.spl_w + (size_t)bi * LS_MAXBINS, *spx = ls.spl_x + (size_t)bi * LS_MAXBINS;
-    u32 lo = 0, hi = B.nb - 1;                               // range = number of splitters below the row's windows
-    while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        const u64 sw = spw[mid], sx = spx[mid];
-        if (sw != w ? sw < w : sx < x) lo = mid + 1; else hi = mid;
+    const bool valid = i < B.m;
+    u32 r = 0;
+    if (valid) {
+        const u64 w = ls.w[B.row0 + i], x = ls.x[B.row0 + i];
+        const u64 *spw = ls.spl_w + (size_t)bi * LS_MAXBINS, *spx = ls.spl_x + (size_t)bi * LS_MAXBINS;
+        u32 lo = 0, hi = B.nb - 1;                           // number of splitters below the row's windows
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            const u64 sw = spw[mid], sx = spx[mid];
+            if (sw != w ? sw < w : sx < x) lo = mid + 1; else hi = mid;
+        }
+        const bool tie = lo + 1 < B.nb && spw[lo] == w && spx[lo] == x;
+        r = 2 * lo + (tie ? 1u : 0u);
+        ls.bin[B.row0 + i] = r;
     }
-    ls.bin[B.row0 + i] = lo;
-    atomicAdd(&ls.cnt[bi * LS_MAXBINS + lo], 1u);
+    (void)ls_wave_add(ls.cnt + (size_t)bi * LS_MAXR, r, valid);
 }
 // one workgroup per block: range starts; ranges of <= BLUE_LDS_CAP rows become sub-blocks, larger ones are reported
 __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub sub) {
@@ -1153,8 +1178,10 @@ __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub s
     const LsBlock B = ls.blk[blockIdx.x];
     u32 *res = ls.res + (size_t)blockIdx.x * LS_RES;
     const u32 tid = threadIdx.x;
-    const u32 c = tid < B.nb ? ls.cnt[blockIdx.x * LS_MAXBINS + tid] : 0u;
-    part[tid] = c;
+    const u32 nr = 2 * B.nb;
+    u32 c[2];
+    for (int h = 0; h < 2; h++) c[h] = 2 * tid + h < nr ? ls.cnt[blockIdx.x * LS_MAXR + 2 * tid + h] : 0u;
+    part[tid] = c[0] + c[1];
     if (tid == 0) { nsub = 0; nover = 0; full = 0; }
     __syncthreads();
     for (u32 d = 1; d < LS_MAXBINS; d <<= 1) {
@@ -1163,12 +1190,17 @@ __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub s
         part[tid] += v;
         __syncthreads();
     }
-    const u32 st = part[tid] - c;
-    if (tid < B.nb) ls.start[blockIdx.x * LS_MAXBINS + tid] = st;
-    const bool small = c >= 1 && c <= BLUE_LDS_CAP, big = c > BLUE_LDS_CAP;
-    u32 my = 0;
-    if (small) my = atomicAdd(&nsub, 1u);
-    if (big) { const u32 o = atomicAdd(&nover, 1u); res[2 + 2 * o] = st; res[3 + 2 * o] = c; }
+    u32 st[2];
+    st[0] = part[tid] - c[0] - c[1]; st[1] = st[0] + c[0];
+    u32 my[2] = {0, 0};
+    for (int h = 0; h < 2; h++) {
+        if (2 * tid + h < nr) ls.start[blockIdx.x * LS_MAXR + 2 * tid + h] = st[h];
+        if (c[h] >= 1 && c[h] <= BLUE_LDS_CAP) my[h] = atomicAdd(&nsub, 1u);
+        if (c[h] > BLUE_LDS_CAP) {
+            const u32 o = atomicAdd(&nover, 1u);
+            res[2 + 3 * o] = st[h]; res[3 + 3 * o] = c[h]; res[4 + 3 * o] = (u32)h;      // h = 1: a range of ties
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         base = atomicAdd(sub.count, nsub);
@@ -1176,19 +1208,21 @@ __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub s
         res[0] = full; res[1] = nover;
     }
     __syncthreads();
-    if (small && !full) {
-        const u32 e = base + my;
-        sub.start[e] = B.b0 + st; sub.freq[e] = c; sub.j0[e] = B.j0 + st; sub.depth[e] = 0;
-    }
+    for (int h = 0; h < 2; h++)
+        if (c[h] >= 1 && c[h] <= BLUE_LDS_CAP && !full) {
+            const u32 e = base + my[h];
+            sub.start[e] = B.b0 + st[h]; sub.freq[e] = c[h]; sub.j0[e] = B.j0 + st[h]; sub.depth[e] = B.depth;
+        }
 }
 __global__ __launch_bounds__(256) void k_ls_scatter(u64 *__restrict__ blue, LargeSplit ls) {
     const u32 bi = ls_block_of(ls, blockIdx.x);
     const LsBlock B = ls.blk[bi];
     const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
-    if (i >= B.m) return;
     if (ls.res[(size_t)bi * LS_RES]) return;                 // nothing was queued: the rows stay for the network
-    const u32 b = ls.bin[B.row0 + i];
-    blue[B.b0 + ls.start[bi * LS_MAXBINS + b] + atomicAdd(&ls.cur[bi * LS_MAXBINS + b], 1u)] = ls.en[B.row0 + i];
+    const bool valid = i < B.m;
+    const u32 b = valid ? ls.bin[B.row0 + i] : 0u;
+    const u32 slot = ls_wave_add(ls.cur + (size_t)bi * LS_MAXR, b, valid);
+    if (valid) blue[B.b0 + ls.start[bi * LS_MAXR + b] + slot] = ls.en[B.row0 + i];
 }
 
 // large blocks: bitonic network in global memory, one launch per compare-exchange distance

@@ -202,6 +202,34 @@ def test_hip_large_blocks_with_long_ties(api, oracle):
         d.close()
 
 
+def test_hip_large_tie_ranges_go_deeper(api, oracle):
+    """3000 exact copies of a segment full of branching nodes: the rows of a node early in the segment tie for more than
+    the 42 SP symbols a split looks at, in groups above the LDS capacity -- those ranges are split again one pair of
+    windows deeper (and must give what the network alone gives)."""
+    rng = np.random.default_rng(21)
+    core = rng.integers(0, 4, size=36).astype(np.uint8)
+    seg_parts = []
+    for _ in range(24):
+        seg_parts.append(core)
+        seg_parts.append(rng.integers(0, 4, size=int(rng.integers(2, 6))).astype(np.uint8))
+    seg = np.concatenate(seg_parts)
+    parts = []
+    for i in range(3000):
+        parts.append(seg)
+        parts.append(rng.integers(0, 4, size=int(rng.integers(40, 90))).astype(np.uint8))
+    recs = [np.concatenate(parts), rng.integers(0, 4, size=300).astype(np.uint8)]
+    ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), 32)
+    for tune in (0, 1024):
+        d = api.DeBWT(k=32, tune=tune)
+        d.load_records(recs)
+        d.build()
+        words, hrows, drow = d.fetch()
+        st = d.stats()
+        assert st["blue_large_blocks"] >= 1 and st["blue_max_block"] >= 3000 * 20
+        assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od, tune
+        d.close()
+
+
 def test_hip_properties_at_bench_size(api):
     """BASELINE configs[1]-sized input: inverse BWT reproduces the text, k-invariance, symbol census."""
     from debwt_amd import synth
