@@ -1034,7 +1034,8 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
         k_blue_refine<64, BLUE_WAVE_CAP, 0><<<gs, 64, 0, c->stream>>>(
             c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 128u,
             c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
-        k_blue_refine<256, BLUE_LDS_CAP, 0><<<std::min<u32>(gs, 1u << 12), 256, 0, c->stream>>>(
+        if (c->nlarge)                                             // only the split of large blocks queues more than 512 rows
+            k_blue_refine<256, BLUE_LDS_CAP, 0><<<std::min<u32>(gs, 1u << 12), 256, 0, c->stream>>>(
             c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, (u32)BLUE_WAVE_CAP,
             c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
     }
