@@ -596,6 +596,61 @@ __device__ __forceinline__ void rl_cex(u64 &a, u64 &b, bool up) {      // (a,b) 
     a = lo; b = hi;
 }
 
+// bitonic network over 2^LG keys held 16 per thread in registers (blocked layout: steps at distance < 16 never leave
+// the thread, distances < 1024 are lane shuffles, larger ones go through LDS).  Threads with !active (whole waves)
+// hold padding only and just keep the barriers.
+template <int LG>
+__device__ __forceinline__ void rl_network(u64 (&k)[16], u64 *A, const u32 tid, const bool active) {
+    constexpr int KPT = 16;
+#pragma unroll
+    for (int lk = 1; lk <= LG; lk++) {
+        const u32 kk = 1u << lk;
+#pragma unroll
+        for (int lj = lk - 1; lj >= 0; lj--) {
+            if (lj < 4) {                                         // partner in the same thread
+                const int jj = 1 << lj;
+                if (active) {
+#pragma unroll
+                    for (int r = 0; r < KPT; r++)
+                        if ((r & jj) == 0) rl_cex(k[r], k[r | jj], ((tid * KPT + r) & kk) == 0);
+                }
+            } else if (lj < 10) {                                 // partner lane in the same wave
+                const int dl = 1 << (lj - 4);
+                const bool lower = (tid & dl) == 0;
+                if (active) {
+#pragma unroll
+                    for (int r = 0; r < KPT; r++) {
+                        u64 pk = __shfl_xor(k[r], dl, 64);
+                        bool up = ((tid * KPT + r) & kk) == 0;
+                        bool take_min = lower == up;
+                        bool pless = pk < k[r];
+                        k[r] = (take_min == pless) ? pk : k[r];
+                    }
+                }
+            } else {                                              // partner in another wave: through LDS
+                const u32 dt = 1u << (lj - 4);
+                if (active) {
+#pragma unroll
+                    for (int r = 0; r < KPT; r++) A[RL_PAD(tid * KPT + r)] = k[r];
+                }
+                __syncthreads();
+                const bool lower = (tid & dt) == 0;
+                if (active) {
+#pragma unroll
+                    for (int r = 0; r < KPT; r++) {
+                        u64 pk = A[RL_PAD((tid ^ dt) * KPT + r)];
+                        bool up = ((tid * KPT + r) & kk) == 0;
+                        bool take_min = lower == up;
+                        bool pless = pk < k[r];
+                        k[r] = (take_min == pless) ? pk : k[r];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
 // keys are ordered by their top (key_bits - pshift) bits.  Tile j = [B(j*H), B((j+1)*H)) with B(x) the first
 // bucket boundary >= x, so tiles are disjoint and bucket-aligned, and hold <= CAP keys unless a bucket overshoots
 // a tile start by more than CAP - H.  A tile is finished by NT threads: a bitonic network over CAP = 16*NT keys
@@ -719,45 +774,9 @@ __global__ __launch_bounds__(NT) void rs_local_kernel(u64 *__restrict__ keys, u6
         }
     }
     if (!sorted) {
-#pragma unroll
-    for (int lk = 1; lk <= LOGN; lk++) {
-        const u32 kk = 1u << lk;
-#pragma unroll
-        for (int lj = lk - 1; lj >= 0; lj--) {
-            if (lj < 4) {                                         // partner in the same thread
-                const int jj = 1 << lj;
-#pragma unroll
-                for (int r = 0; r < KPT; r++)
-                    if ((r & jj) == 0) rl_cex(k[r], k[r | jj], ((tid * KPT + r) & kk) == 0);
-            } else if (lj < 10) {                                 // partner lane in the same wave
-                const int dl = 1 << (lj - 4);
-                const bool lower = (tid & dl) == 0;
-#pragma unroll
-                for (int r = 0; r < KPT; r++) {
-                    u64 pk = __shfl_xor(k[r], dl, 64);
-                    bool up = ((tid * KPT + r) & kk) == 0;
-                    bool take_min = lower == up;
-                    bool pless = pk < k[r];
-                    k[r] = (take_min == pless) ? pk : k[r];
-                }
-            } else {                                              // partner in another wave: through LDS
-                const u32 dt = 1u << (lj - 4);
-#pragma unroll
-                for (int r = 0; r < KPT; r++) A[RL_PAD(tid * KPT + r)] = k[r];
-                __syncthreads();
-                const bool lower = (tid & dt) == 0;
-#pragma unroll
-                for (int r = 0; r < KPT; r++) {
-                    u64 pk = A[RL_PAD((tid ^ dt) * KPT + r)];
-                    bool up = ((tid * KPT + r) & kk) == 0;
-                    bool take_min = lower == up;
-                    bool pless = pk < k[r];
-                    k[r] = (take_min == pless) ? pk : k[r];
-                }
-                __syncthreads();
-            }
-        }
-    }
+        // a workgroup tile of at most half the capacity: the network over the lower half of the threads only
+        if (NT == 256 && cnt <= CAP / 2) rl_network<LOGN - 1>(k, A, tid, tid < NT / 2);
+        else rl_network<LOGN>(k, A, tid, true);
     }
 #pragma unroll
     for (int r = 0; r < KPT; r++) A[RL_PAD(tid * KPT + r)] = k[r];
