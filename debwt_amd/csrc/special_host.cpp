@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <functional>
 #include <thread>
+#include <chrono>
+#include <cstdio>
 
 namespace {
 
@@ -25,8 +27,9 @@ struct Text {
     uint64_t first_sep_at_or_after(uint64_t i) const { return std::lower_bound(sep, sep + nrec, i) - sep; }
 
     // true suffix order of two different positions (src/collect#$.c:253-311)
-    bool less(uint64_t a, uint64_t b) const {
-        uint64_t ia = first_sep_at_or_after(a), ib = first_sep_at_or_after(b);
+    bool less(uint64_t a, uint64_t b) const { return less(a, first_sep_at_or_after(a), b, first_sep_at_or_after(b)); }
+    // the same with the records known: ia, ib = index of the first separator at or after a, b
+    bool less(uint64_t a, uint64_t ia, uint64_t b, uint64_t ib) const {
         for (;;) {
             uint64_t da = sep[ia] - a, db = sep[ib] - b;
             uint64_t m = da < db ? da : db;
@@ -45,15 +48,13 @@ struct Text {
     }
 
     // equal K-windows, separator of the same kind at the same offset (src/collect#$.c:603-634)
-    bool same_window(uint64_t a, uint64_t b, int K) const {
-        uint64_t ia = first_sep_at_or_after(a), ib = first_sep_at_or_after(b);
+    bool same_window(uint64_t a, uint64_t ia, uint64_t b, uint64_t ib, int K) const {
         uint64_t da = sep[ia] - a, db = sep[ib] - b;
         if (da != db || (ia == nrec - 1) != (ib == nrec - 1)) return false;
-        for (int t = 0; t < K; t++) {
-            if ((uint64_t)t == da) continue;
-            if (base(a + t) != base(b + t)) return false;
-        }
-        return true;
+        // K symbols from a and from b, the separator's slot (offset da < K) left out of the comparison
+        const uint64_t slot = 3ull << (2 * (31 - da));
+        const uint64_t keep = (~0ull << (64 - 2 * K)) & ~slot;
+        return ((window(a) ^ window(b)) & keep) == 0;
     }
 };
 
@@ -85,13 +86,23 @@ void parallel_chunks(unsigned nt, uint64_t nchunks, const std::function<void(uin
 void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep, uint64_t nrec, int K,
                           SpecialTables *out) {
     Text T{words, n, sep, nrec};
+    const bool trace = getenv("DEBWT_TRACE_SPECIAL") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "special module: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const uint64_t NS = nrec * (uint64_t)K;
     const uint64_t node_mask = (1ull << (2 * K)) - 1;
     // The T-padded key is monotone in the true suffix order (a separator ranks above every base and the
     // padding is the largest base), so ordering by key first and by the full suffix comparison only inside
     // runs of equal keys gives exactly the order of the reference's qsort (src/collect#$.c:118-157,253-311)
     // at a fraction of its comparisons.
-    struct Item { uint64_t key, pos; };
+    // rec: the record whose separator follows pos (index into sep); next: the 32 symbols behind that separator (every
+    // record is longer than 32), ~0 behind '$' -- where suffixes with equal keys differ first, as a rule
+    struct Item { uint64_t key, pos, rec, next; };
     std::vector<Item> items(NS);
     const unsigned nt = special_threads(NS);
     const uint64_t nchunks = nt > 1 ? (uint64_t)nt * 4 : 1;
@@ -99,6 +110,7 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
     parallel_chunks(nt, nchunks, [&](uint64_t c) {
         for (uint64_t r = cut(nrec, c); r < cut(nrec, c + 1); r++) {
             uint64_t m = r * (uint64_t)K;
+            const uint64_t next = r + 1 < nrec ? T.window(sep[r] + 1) : ~0ull;
             for (int d = K - 1; d >= 0; d--) {
                 uint64_t p = sep[r] - (uint64_t)d;
                 // key: the d bases, then 'T' up to K symbols (src/collect#$.c:428-446)
@@ -106,50 +118,105 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
                 uint64_t pad = (1ull << (2 * (K - d))) - 1;
                 items[m].key = ((win << (2 * (K - d))) | pad) & node_mask;
                 items[m].pos = p;
+                items[m].rec = r;
+                items[m].next = next;
                 m++;
             }
         }
     });
-    // by key (ties by position, so that the result is the same for every thread count): chunks sorted on their
-    // own, then merged pairwise
+    lap("keys");
+    // by key (ties by position, so that the result is the same for every thread count).  Many suffixes: one counting
+    // pass on the top 12 bits of the key cuts them into 4096 buckets that are then sorted independently on all threads
+    // (no merge levels); few: one sort.
     auto by_key = [](const Item &a, const Item &b) { return a.key != b.key ? a.key < b.key : a.pos < b.pos; };
-    parallel_chunks(nt, nchunks, [&](uint64_t c) { std::sort(items.begin() + cut(NS, c), items.begin() + cut(NS, c + 1), by_key); });
-    for (uint64_t width = 1; width < nchunks; width *= 2) {
-        const uint64_t pairs = (nchunks + 2 * width - 1) / (2 * width);
-        parallel_chunks(nt, pairs, [&](uint64_t q) {
-            const uint64_t a = q * 2 * width, b = std::min(nchunks, a + width), e = std::min(nchunks, a + 2 * width);
-            if (b < e) std::inplace_merge(items.begin() + cut(NS, a), items.begin() + cut(NS, b), items.begin() + cut(NS, e), by_key);
+    if (nt > 1) {
+        constexpr unsigned NB = 4096;
+        const int bshift = 2 * K > 12 ? 2 * K - 12 : 0;
+        std::vector<std::vector<uint64_t>> cnt(nchunks, std::vector<uint64_t>(NB, 0));
+        parallel_chunks(nt, nchunks, [&](uint64_t c) {
+            for (uint64_t i = cut(NS, c); i < cut(NS, c + 1); i++) cnt[c][(items[i].key >> bshift) & (NB - 1)]++;
         });
+        std::vector<uint64_t> bstart(NB + 1, 0);
+        for (unsigned b = 0; b < NB; b++) {                      // bucket-major, chunk-minor offsets
+            uint64_t acc = bstart[b];
+            for (uint64_t c = 0; c < nchunks; c++) { const uint64_t v = cnt[c][b]; cnt[c][b] = acc; acc += v; }
+            bstart[b + 1] = acc;
+        }
+        std::vector<Item> tmp(NS);
+        parallel_chunks(nt, nchunks, [&](uint64_t c) {
+            for (uint64_t i = cut(NS, c); i < cut(NS, c + 1); i++) tmp[cnt[c][(items[i].key >> bshift) & (NB - 1)]++] = items[i];
+        });
+        items.swap(tmp);
+        parallel_chunks(nt, NB, [&](uint64_t b) { std::sort(items.begin() + bstart[b], items.begin() + bstart[b + 1], by_key); });
+    } else {
+        std::sort(items.begin(), items.end(), by_key);
     }
+    lap("sort by key");
     // runs of equal keys: true suffix order inside each (independent of each other)
     std::vector<uint64_t> runs;                      // starts of the runs of length > 1
-    for (uint64_t i = 0; i < NS;) {
-        uint64_t j = i + 1;
-        while (j < NS && items[j].key == items[i].key) j++;
-        if (j - i > 1) runs.push_back(i);
-        i = j;
+    {
+        std::vector<std::vector<uint64_t>> part(nchunks);       // a chunk lists the runs that START inside it
+        parallel_chunks(nt, nchunks, [&](uint64_t c) {
+            uint64_t i = cut(NS, c);
+            const uint64_t end = cut(NS, c + 1);
+            while (i < end && i > 0 && items[i].key == items[i - 1].key) i++;
+            while (i < end) {
+                uint64_t j = i + 1;
+                while (j < NS && items[j].key == items[i].key) j++;
+                if (j - i > 1) part[c].push_back(i);
+                i = j;
+            }
+        });
+        for (auto &v : part) runs.insert(runs.end(), v.begin(), v.end());
     }
-    const uint64_t rchunks = nt > 1 ? std::min<uint64_t>(runs.size(), (uint64_t)nt * 16) : 1;
-    parallel_chunks(nt, rchunks ? rchunks : 0, [&](uint64_t c) {
-        const uint64_t r0 = runs.size() / rchunks * c + std::min<uint64_t>(c, runs.size() % rchunks);
-        const uint64_t r1 = runs.size() / rchunks * (c + 1) + std::min<uint64_t>(c + 1, runs.size() % rchunks);
-        for (uint64_t r = r0; r < r1; r++) {
-            uint64_t i = runs[r], j = i + 1;
-            while (j < NS && items[j].key == items[i].key) j++;
-            std::sort(items.begin() + i, items.begin() + j,
-                      [&](const Item &a, const Item &b) { return a.pos != b.pos && T.less(a.pos, b.pos); });
+    // equal keys with the separator at the same offset: '#' ties and the comparison goes on in the next records (32
+    // symbols of them are in the items); '$' is larger than '#'
+    auto by_suffix = [&](const Item &a, const Item &b) {
+        const bool enda = a.rec == nrec - 1, endb = b.rec == nrec - 1;
+        const bool same_offset = sep[a.rec] - a.pos == sep[b.rec] - b.pos;     // equal keys may still be "ACG#" and "ACGT#"
+        if (same_offset && !enda && !endb && a.next != b.next) return a.next < b.next;
+        return a.pos != b.pos && T.less(a.pos, a.rec, b.pos, b.rec);
+    };
+    auto run_end = [&](uint64_t i) { uint64_t j = i + 1; while (j < NS && items[j].key == items[i].key) j++; return j; };
+    // long runs first, each on all threads (pieces sorted, then merged pairwise): the suffixes a base or two before
+    // their separator share their key with a large part of the collection
+    constexpr uint64_t LONG_RUN = 1u << 15;
+    std::vector<uint64_t> short_runs;
+    for (uint64_t i : runs) {
+        const uint64_t j = run_end(i), len = j - i;
+        if (nt == 1 || len < LONG_RUN) { short_runs.push_back(i); continue; }
+        const uint64_t pieces = std::min<uint64_t>((uint64_t)nt * 2, len / 4096);
+        auto pcut = [&](uint64_t c) { return i + len / pieces * c + std::min<uint64_t>(c, len % pieces); };
+        parallel_chunks(nt, pieces, [&](uint64_t c) { std::sort(items.begin() + pcut(c), items.begin() + pcut(c + 1), by_suffix); });
+        for (uint64_t width = 1; width < pieces; width *= 2) {
+            const uint64_t pairs = (pieces + 2 * width - 1) / (2 * width);
+            parallel_chunks(nt, pairs, [&](uint64_t q) {
+                const uint64_t a = q * 2 * width, b = std::min(pieces, a + width), e = std::min(pieces, a + 2 * width);
+                if (b < e) std::inplace_merge(items.begin() + pcut(a), items.begin() + pcut(b), items.begin() + pcut(e), by_suffix);
+            });
         }
+    }
+    const uint64_t rchunks = nt > 1 ? std::min<uint64_t>(short_runs.size(), (uint64_t)nt * 16) : 1;
+    parallel_chunks(nt, short_runs.empty() ? 0 : rchunks, [&](uint64_t c) {
+        const uint64_t r0 = short_runs.size() / rchunks * c + std::min<uint64_t>(c, short_runs.size() % rchunks);
+        const uint64_t r1 = short_runs.size() / rchunks * (c + 1) + std::min<uint64_t>(c + 1, short_runs.size() % rchunks);
+        for (uint64_t r = r0; r < r1; r++) std::sort(items.begin() + short_runs[r], items.begin() + run_end(short_runs[r]), by_suffix);
     });
-    std::vector<uint64_t> order(NS);
+    lap("tie runs");
+    std::vector<uint64_t> order(NS), orec(NS);
     out->key.resize(NS);
     out->chr.resize(NS);
-    for (uint64_t s = 0; s < NS; s++) {
-        order[s] = items[s].pos;
-        out->key[s] = items[s].key;
-        out->chr[s] = (uint8_t)T.base(items[s].pos - 1);          // always a base: records are > K long
-    }
+    parallel_chunks(nt, nchunks, [&](uint64_t c) {
+        for (uint64_t s = cut(NS, c); s < cut(NS, c + 1); s++) {
+            order[s] = items[s].pos;
+            orec[s] = items[s].rec;
+            out->key[s] = items[s].key;
+            out->chr[s] = (uint8_t)T.base(items[s].pos - 1);      // always a base: records are > K long
+        }
+    });
     out->pos = order;
 
+    lap("tables");
     // special branches (src/collect#$.c:534-598)
     out->branch.clear();
     {
@@ -158,10 +225,10 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
         parallel_chunks(nt, nchunks, [&](uint64_t c) {
             uint64_t i = cut(NS, c);
             const uint64_t end = cut(NS, c + 1);
-            while (i < end && i > 0 && T.same_window(order[i - 1], order[i], K)) i++;      // inside a group of the chunk before
+            while (i < end && i > 0 && T.same_window(order[i - 1], orec[i - 1], order[i], orec[i], K)) i++;   // inside a group of the chunk before
             while (i < end) {
                 uint64_t j = i + 1;
-                while (j < NS && T.same_window(order[i], order[j], K)) j++;
+                while (j < NS && T.same_window(order[i], orec[i], order[j], orec[j], K)) j++;
                 if (j - i >= 2) {
                     bool differ = false;
                     for (uint64_t q = i + 1; q < j; q++)
@@ -176,6 +243,7 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
     }
     std::sort(out->branch.begin(), out->branch.end());
 
+    lap("branches");
     // head# / head$ and tail# nodes (src/collect#$.c:468-533)
     out->head_keys.resize(nrec);
     out->tail_facts.resize(nrec);
@@ -185,4 +253,5 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
         out->tail_facts[r] = ((T.window(sep[r] - (uint64_t)K) >> (64 - 2 * K)) << 2) | 1ull;
     }
     std::sort(out->head_keys.begin(), out->head_keys.end());
+    lap("heads and tails");
 }

@@ -113,3 +113,13 @@ def test_special_region_module_threads_agree(monkeypatch):
     for k in (32, 16):
         ref = digest(1, k)
         assert digest(3, k) == ref and digest(8, k) == ref
+    # enough records for the runs of the shortest special suffixes (one per record and length) to take the
+    # all-threads sort of long runs
+    recs = []
+    for _ in range(40000):
+        p = pool[int(rng.integers(0, len(pool)))]
+        off, L = int(rng.integers(0, 60)), int(rng.integers(34, 70))
+        recs.append(p[off:off + L].copy())
+    words, n, sep = api.pack_records(recs)
+    ref = digest(1, 32)
+    assert digest(5, 32) == ref and digest(8, 32) == ref
