@@ -4,19 +4,33 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--k 32]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the whole hot path (key extraction, radix sort, classification, SP code, blue-block
-sort, assembly) over one synthetic collection whose packed text is already resident in HBM.  At N=1 the
-workload is BASELINE.json configs[1] (chr1-sized, 250 Mbp, k=32).  At N>1 every rank builds the BWT of its
-own collection of that size (independent objects: weak scaling, no data-path collective); the timed region
-is bracketed by a barrier + device synchronisation on both sides and the slowest rank's time is used.
+Workload (default, every N): BASELINE.json configs[4], the configuration the metric is quoted on -- 10 genomes x
+3.0 Gbp = 30 Gbp of synthetic DNA in 240 chromosome-like records (distribution P of SURVEY 8d: repeat families,
+SNPs at 1e-3 between the genomes; /root/reference/README.md:19 "10 human genomes").  The text is produced by the
+native generator (include/debwt_synth.h) from the formula of debwt_amd/synth.py, straight into page-locked host
+memory in the reference's 2-bit layout.
 
-The one JSON line also carries
-  roofline     -- the dominant kernel (one radix scatter pass): algorithmic bytes (16 B per key moved:
-                  8 read + 8 written) / mean launch time from hipEvents recorded inside the timed region on
-                  the stream the kernel runs on, against the 8 TB/s HBM peak;
-  cpu_baseline -- the CPU oracle (a single-threaded port of the reference path) timed on this box's host
-                  cores on a bounded prefix of the same workload (rank 0, N=1 only);
-  cpu_reference -- the reference's own stage functions (oracle/_ref, 8 threads) on a shorter prefix, when built.
+A step = one pass of the whole hot path (key extraction, radix sort, classification, SP code, blue-block sort,
+assembly) over that collection.
+  N = 1   the one GPU builds the whole BWT: the key space is cut into k-mer-prefix ranges that are sorted one after
+          the other over the resident text.
+  N > 1   ONE collection, built by N k-mer-prefix shards (strong scaling: the same 30 Gbp at every N): census
+          all-reduce, all_to_all of the 8-byte k-mers to their bucket owners (RCCL over xGMI), local sort and
+          classification, all-gather of the branching-node facts and of the SP code, all_to_all of the blue entries,
+          local blue sort and assembly, final concatenation of the row ranges on rank 0.
+`value` = bases / wall time of a step with the packed text resident in HBM (on every GPU) and the result left in
+HBM (rank 0), barrier + device synchronisation on both sides, slowest rank.  Extra keys:
+  host_to_host  -- N = 1: the same build from the page-locked host text to the BWT and its '#'/'$' rows back in
+                   page-locked host memory (SURVEY 8d's region: load + build + fetch);
+  first_build_s -- the cold first build (allocates the workspace);
+  check         -- outside the timed region: symbol census of the result against the text's (device kernel), '#' rows
+                   ascending, and the inverse BWT on the device (one LF walk per text segment, debwt_verify_device);
+  roofline      -- the dominant kernel (one 8-bit radix scatter pass over the keys of a range): algorithmic bytes
+                   (16 B per key: 8 read + 8 written) / mean launch time from hipEvents recorded around every such
+                   launch of the first key range on the stream it runs on, against the 8 TB/s HBM peak;
+  cpu_baseline  -- the reference's own stage functions (oracle/_ref, compiled from /root/reference/src in the build
+                   container) on this box's host cores on a bounded prefix of record 0 (rank 0, N = 1 only);
+  cpu_port      -- the single-threaded CPU oracle on a prefix of the same record.
 """
 import argparse
 import json
@@ -31,24 +45,33 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 METRIC = "Gbp/sec BWT build (30 Gbp synthetic DNA); bit-exact vs CPU ref; 1/2/4/8-GPU"
+WORKLOAD_NOTE = {
+    "pan10x3G": "BASELINE configs[4]: 10 genomes x 3.0 Gbp in 240 chromosome-like records, repeat families, SNP 1e-3",
+    "pan4x3.1G": "BASELINE configs[3]: 4 x GRCh38-sized genomes in 96 records",
+    "grch38_3.1G": "BASELINE configs[2]: one GRCh38-sized genome in 24 records",
+    "chr1_250M": "BASELINE configs[1]: chr1-sized single record, repeat families",
+    "ecoli_4.6M": "BASELINE configs[0]: E. coli-sized single record",
+    "uniform_3.1G": "distribution U: uniform 3.1 Gbp in 24 records",
+    "real_3.1G": "distribution R: 3.1 Gbp in 24 records with an Alu-like family, satellite arrays, homopolymer tracts",
+}
 
 
-def cpu_baseline(recs, k, budget_bases=150_000_000):
-    """Oracle on a prefix of the first record (same generator, same repeat structure)."""
+def cpu_port(codes, k):
+    """The CPU oracle (single-threaded restatement of the reference path) on a sample."""
     from oracle import oracle as O
-    sample = [np.ascontiguousarray(recs[0][:budget_bases])]
-    sym = O.sym_from_codes(sample)
+    sym = O.sym_from_codes([codes])
     t0 = time.perf_counter()
     O.build_bwt(sym, k, threads=1)
     dt = time.perf_counter() - t0
     return {"value": round(len(sym) / dt / 1e9, 6), "unit": "Gbp/s", "cores": 1, "kind": "port",
-            "sample": f"first {len(sample[0])} bases of record 0 of the workload, k={k}, {dt:.1f} s"}
+            "sample": f"first {len(codes)} bases of record 0 of the workload, k={k}, {dt:.1f} s"}
 
 
-def cpu_reference(recs, k, budget_bases=10_000_000):
+def cpu_reference(codes, k, threads):
     """The reference's OWN stage functions (oracle/_ref/ref_driver: mySort ... insertCase3 compiled from the reference
-    sources where they lie; only the Jellyfish dump in front of them is supplied by the oracle's counter) on a short
-    prefix, with the reference's default of 8 threads.  None where the binary was not built."""
+    sources where they lie) with -t `threads`.  The k-mer dump in front of them stands in for Jellyfish (absent third
+    party tool) and is not timed; mySort's parse of that dump is reference code and is.  None where the binary was
+    not built."""
     import shutil
     import subprocess
     import tempfile
@@ -58,18 +81,24 @@ def cpu_reference(recs, k, budget_bases=10_000_000):
         return None
     d = tempfile.mkdtemp(prefix="debwt_ref_")
     try:
-        sample = np.ascontiguousarray(recs[0][:budget_bases])
         fa, out = os.path.join(d, "in.fa"), os.path.join(d, "OUT")
-        fasta.write_fasta(fa, [sample])
-        threads = min(8, os.cpu_count() or 1)
+        fasta.write_fasta(fa, [codes])
         t0 = time.perf_counter()
-        p = subprocess.run([driver, d, fa, out, str(k), str(threads)], capture_output=True, text=True, timeout=600)
+        p = subprocess.run([driver, d, fa, out, str(k), str(threads)], capture_output=True, text=True, timeout=900)
         dt = time.perf_counter() - t0
         if p.returncode:
             return None
-        return {"value": round((len(sample) + 1) / dt / 1e9, 6), "unit": "Gbp/s", "cores": threads, "kind": "reference",
-                "sample": f"first {len(sample)} bases of record 0 of the workload, k={k}, {dt:.1f} s (includes writing and "
-                          "parsing the k-mer dump that stands in for Jellyfish)"}
+        stages = {}
+        if os.path.exists(out + ".timing"):
+            for ln in open(out + ".timing"):
+                a, b = ln.split()
+                stages[a] = float(b)
+        ref_s = sum(v for s_, v in stages.items() if s_ != "kmer_dump_standin") if stages else dt
+        return {"value": round((len(codes) + 1) / ref_s / 1e9, 6), "unit": "Gbp/s", "cores": threads, "kind": "reference",
+                "sample": f"first {len(codes)} bases of record 0 of the workload, k={k}, -t {threads}: {ref_s:.1f} s in the "
+                          f"reference's stage functions (mySort incl. its ~3 s of lock/histogram set-up ... insertCase3); "
+                          f"the {stages.get('kmer_dump_standin', 0):.1f} s k-mer dump that stands in for Jellyfish is not counted",
+                "stages_s": {s_: round(v, 2) for s_, v in stages.items()}}
     except Exception:
         return None
     finally:
@@ -80,23 +109,27 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="chr1_250M")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="pan10x3G")
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--sort-algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--h2h-reps", type=int, default=2, help="host-to-host repetitions (N = 1); 0 = skip")
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bases of record 0 given to the reference")
+    ap.add_argument("--port-sample", type=int, default=100_000_000, help="bases of record 0 given to the oracle port")
     ap.add_argument("--tune", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # gloo: ranks may share one GPU (tests)
-    ap.add_argument("--mode", choices=["replicas", "sharded", "sharded-scan"], default="replicas",
-                    help="N>1: 'replicas' = one independent collection per GPU (default); 'sharded' = ONE "
-                         "collection of N x the per-GPU size built by all GPUs as k-mer-prefix shards with the "
-                         "key and blue-entry all_to_all exchanges; 'sharded-scan' = the same shards, every GPU "
-                         "scanning the whole text instead of exchanging")
+    ap.add_argument("--mode", choices=["exchange", "scan", "replicas"], default="exchange",
+                    help="N>1: 'exchange' (default) = ONE collection built by N k-mer-prefix shards with the key and "
+                         "blue-entry all_to_all exchanges; 'scan' = the same shards, every GPU scanning the whole text "
+                         "instead of exchanging keys; 'replicas' = N independent collections (no collective)")
     args = ap.parse_args()
 
     import torch
-    from debwt_amd import api, synth
+    from debwt_amd import api
     from debwt_amd import dist as D
+    from debwt_amd import synth_native as SN
 
     rank, local_rank, world = D.env_world()
     assert world == args.gpus or (world == 1 and args.gpus == 1), "launch one process per GPU"
@@ -105,30 +138,40 @@ def main():
     torch.cuda.set_device(local_rank)
     D.init(backend=args.backend, device_id=torch.device("cuda", local_rank))
     tdev = "cuda" if args.backend == "nccl" else "cpu"
+    device = torch.device("cuda", local_rank)
+    sharded = world > 1 and args.mode != "replicas"
 
-    sharded_mode = args.mode.startswith("sharded") and world > 1
-    shard_feed = "scan" if args.mode == "sharded-scan" else "exchange"
-    if sharded_mode:
-        # ONE collection, `world` records of the per-GPU size, the same text on every rank
+    # ---- the collection: formula-defined, generated natively into page-locked host memory --------------------------
+    t0 = time.perf_counter()
+    seed = None if (world == 1 or sharded) else D.collection_seed(0x5EEDBA5E, rank)
+    syn = SN.Synth.named(args.workload, seed=seed)
+    n, nrec, nwords = syn.n, syn.nrec, syn.nwords
+    sep = syn.sep()
+    text = SN.PinnedArray(nwords)
+    census = np.zeros(4, dtype=np.uint64)
+    if sharded:
         from debwt_amd import sharded as SH
-        recs = []
-        for r in range(world):
-            recs += _workload_for_rank(synth, args.workload, r)
+        census = SH.generate_text_all_gather(syn, text, device)       # every rank packs 1/world of the words
     else:
-        # every rank builds its own collection of the same shape (independent objects)
-        recs = _workload_for_rank(synth, args.workload, rank)
-    n = sum(len(r) for r in recs) + len(recs)
+        census = syn.words_into(text.ptr)
+    t_gen = time.perf_counter() - t0
 
     d = api.DeBWT(k=args.k, device=local_rank, sort_algo=args.sort_algo, tune=args.tune)
-    d.load_records(recs)                      # text -> HBM before the timed region
+    t0 = time.perf_counter()
+    d.load_packed(text.a, n, sep)                 # text -> HBM before the timed region
+    t_load = time.perf_counter() - t0
 
-    acc = {"pass_ms": 0.0, "pass_launches": 0, "stage": {}, "timed": False}
+    acc = {"pass_ms": 0.0, "pass_launches": 0, "stage": {}, "timed": False, "xfer": {}}
+    shard_ws = SH.Workspace(d, device, mode=args.mode) if sharded else None
 
     def step():
-        if sharded_mode:
-            SH.build_sharded(d, torch.device("cuda", local_rank), mode=shard_feed)   # collectives inside
+        if sharded:
+            info = SH.build_sharded(d, shard_ws)          # collectives and the final concat inside
+            if acc["timed"]:
+                for key, v in info.items():
+                    acc["xfer"][key] = acc["xfer"].get(key, 0.0) + v / args.steps
         else:
-            d.build()                         # synchronous: returns after the context's stream drained
+            d.build()                                     # synchronous: returns after the context's stream drained
         if acc["timed"]:
             st_ = d.stats()
             acc["pass_ms"] += st_["radix_pass_ms"]
@@ -136,13 +179,55 @@ def main():
             for key in ("ms_extract", "ms_sort", "ms_classify", "ms_sp", "ms_blue", "ms_assemble", "ms_total"):
                 acc["stage"][key] = acc["stage"].get(key, 0.0) + st_[key] / args.steps
 
-    for _ in range(args.warmup):
+    t0 = time.perf_counter()
+    step()                                                # cold build: allocates the workspace (reported, not timed)
+    torch.cuda.synchronize()
+    first_build_s = time.perf_counter() - t0
+    for _ in range(max(args.warmup - 1, 0)):
         step()
     acc["timed"] = True
     dt = D.timed_steps(step, steps=args.steps, warmup=0, device_sync=torch.cuda.synchronize, tensor_device=tdev)
-    total_bases = float(n) if sharded_mode else D.sum_over_ranks(n, tensor_device=tdev)
+    total_bases = float(n) if (sharded or world == 1) else D.sum_over_ranks(n, tensor_device=tdev)
     pass_ms, pass_launches, stage = acc["pass_ms"], acc["pass_launches"], acc["stage"]
     st = d.stats()
+
+    # ---- outside the timed region: checks, host-to-host figure, CPU baselines ----------------------------------------
+    check = None
+    if not args.no_check:
+        if sharded:
+            check = SH.check_result(d, shard_ws, census, n, nrec)
+        elif world == 1:
+            got = d.bwt_census().astype(np.int64)
+            want = census.astype(np.int64).copy()
+            want[3] += nrec                                # '#' and '$' rows are stored as 3
+            _, hrows, drow = d.fetch_small()
+            check = {"census_equals_text": bool((got == want).all()),
+                     "hash_rows_ascending": bool((np.diff(hrows.astype(np.int64)) > 0).all()) if nrec > 2 else True,
+                     "hash_rows": int(len(hrows)), "dollar_row": int(drow)}
+            if hasattr(d, "verify_device"):
+                check.update(d.verify_device())
+    h2h = None
+    if world == 1 and args.h2h_reps > 0:
+        out_words = SN.PinnedArray((n + 31) // 32)
+        out_hash = SN.PinnedArray(max(nrec - 1, 1))
+        out_dollar = SN.PinnedArray(1)
+        ts = []
+        for _ in range(args.h2h_reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d.load_packed(text.a, n, sep)
+            t1 = time.perf_counter()
+            d.build()
+            t2 = time.perf_counter()
+            d.fetch_into(out_words.a, out_hash.a, out_dollar.a)
+            t3 = time.perf_counter()
+            ts.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+        best = min(ts)
+        h2h = {"value": round(n / best[0] / 1e9, 4), "unit": "Gbp/s", "seconds": round(best[0], 4),
+               "load_s": round(best[1], 4), "build_s": round(best[2], 4), "fetch_s": round(best[3], 4),
+               "note": "page-locked host text -> BWT + '#'/'$' rows in page-locked host memory (SURVEY 8d); a fresh load "
+                       "also re-plans the key ranges (prefix census of the text)"}
+        out_words.free(); out_hash.free(); out_dollar.free()
 
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
@@ -152,55 +237,55 @@ def main():
         achieved = 16.0 * keys / (mean_pass_ms * 1e-3) / 1e9 if mean_pass_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc) and args.workload == "chr1_250M" and args.k == 32:      # the PMC passes were run on this workload
+        if os.path.exists(pmc) and args.k == 32 and world == 1:
             try:
-                traffic = json.load(open(pmc)).get("rs_scatter_bytes_per_launch")
+                j = json.load(open(pmc))
+                if j.get("workload") == args.workload:      # the PMC passes were run on this workload
+                    traffic = j.get("rs_scatter_bytes_per_launch")
             except Exception:
                 traffic = None
+        if sharded:
+            par = (f"one collection of {nrec} records ({n} bases) built by {world} k-mer-prefix shards "
+                   f"({args.mode} mode), text replicated in the HBM of every GPU, result concatenated on rank 0")
+        elif world > 1:
+            par = f"{world} independent collections, one per GPU"
+        else:
+            par = "one GPU, k-mer-prefix key ranges sorted one after the other over the resident text"
         line = {
             "metric": METRIC, "value": round(value, 4), "unit": "Gbp/s", "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
-            "data": "synthetic",
-            "config": {"workload": (f"{args.workload} (BASELINE configs[1]: chr1-sized synthetic, repeat families)"
-                                    if args.workload == "chr1_250M" else args.workload),
-                       "k": args.k, "bases_per_gpu": n // world if sharded_mode else n,
-                       "records_per_gpu": len(recs) // world if sharded_mode else len(recs),
-                       "parallelism": (f"one collection of {len(recs)} records ({n} bases) built by {world} "
-                                       f"k-mer-prefix shards ({shard_feed} mode)"
-                                       if sharded_mode else f"{args.gpus} independent collections, one per GPU")},
-            "roofline": {"bound": "hbm", "kernel": "rs_scatter_kernel (one 8-bit radix pass over the keys)",
+            "higher_is_better": True, "scaling": "weak" if (world > 1 and not sharded) else "strong",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{args.workload} ({WORKLOAD_NOTE.get(args.workload, 'custom')})",
+                       "k": args.k, "bases": n, "records": nrec, "bases_per_gpu": n // world if sharded else n,
+                       "parallelism": par},
+            "roofline": {"bound": "hbm", "kernel": "rs_scatter_kernel<0,0,1> (one 8-bit radix pass over the keys of a key range)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": 16 * keys, "mean_launch_ms": round(mean_pass_ms, 4),
                          "launches_timed": pass_launches},
             "stages_ms": {k_: round(v, 3) for k_, v in stage.items()},
             "counters": {k_: st[k_] for k_ in ("n", "nrec", "n_main", "distinct_keys", "red_capacity",
-                                              "blue_capacity", "blue_bound_num", "sp_len")},
+                                              "blue_capacity", "blue_bound_num", "sp_len", "blue_large_blocks")},
+            "first_build_s": round(first_build_s, 3),
+            "setup_s": {"generate_text": round(t_gen, 2), "load_to_hbm": round(t_load, 3)},
+            "check": check,
+            "host_to_host": h2h,
         }
+        if sharded:
+            line["exchange"] = {k_: round(v, 3) for k_, v in acc["xfer"].items()}
         if args.gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(recs, args.k)
-            line["cpu_reference"] = cpu_reference(recs, args.k)
+            threads = SN.default_threads()
+            ref = cpu_reference(syn.codes(0, 0, min(args.cpu_sample, int(syn._lens[0]))), args.k, threads)
+            port = cpu_port(syn.codes(0, 0, min(args.port_sample, int(syn._lens[0]))), args.k)
+            line["cpu_baseline"] = ref if ref else port
+            line["cpu_port"] = port
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     d.close()
+    text.free()
     D.finalize()
-
-
-def _workload_for_rank(synth, name, rank):
-    """Same shape as make_workload(name), different seed."""
-    from debwt_amd import dist as D
-    seed = D.collection_seed(synth.SEED_P, rank)
-    if name == "chr1_250M":
-        return synth.pan_genome(250_000_000, 1, seed=seed)
-    if name == "ecoli_4.6M":
-        return synth.pan_genome(4_600_000, 1, seed=seed)
-    if name == "pan_100M_4":
-        return synth.chromosomes(100_000_000, 4, seed=seed)
-    if name == "pan_16M_4":
-        return synth.pan_genome(4_000_000, 4, seed=seed)
-    return synth.make_workload(name)
 
 
 if __name__ == "__main__":

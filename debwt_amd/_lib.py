@@ -43,7 +43,7 @@ SYMBOLS = [
     "debwt_shard_begin", "debwt_shard_histogram", "debwt_shard_set_range", "debwt_shard_classify_local",
     "debwt_shard_facts_export", "debwt_shard_classify_global", "debwt_shard_info", "debwt_shard_fetch",
     "debwt_shard_partition_keys", "debwt_shard_import_keys", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
-    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest",
+    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_pinned_alloc", "debwt_pinned_free",
 ]
 
 
@@ -147,6 +147,10 @@ def lib():
     L.debwt_load_fasta_opts.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64]
     L.debwt_special_digest.restype = ctypes.c_int
     L.debwt_special_digest.argtypes = [u64p, ctypes.c_uint64, u64p, ctypes.c_uint64, ctypes.c_int, u64p]
+    L.debwt_fetch_rows.restype = ctypes.c_int
+    L.debwt_fetch_rows.argtypes = [vp, u64p, u64p]
+    L.debwt_bwt_census.restype = ctypes.c_int
+    L.debwt_bwt_census.argtypes = [vp, u64p]
     L.debwt_set_range_cap.restype = ctypes.c_int
     L.debwt_set_range_cap.argtypes = [vp, ctypes.c_uint64]
     _lib = L

@@ -140,6 +140,23 @@ class DeBWT:
         self._chk(self._L.debwt_fetch_bwt(self._h, _p64(words), _p64(hrows), _p64(drow)))
         return words, hrows[:self.nrec - 1], int(drow[0])
 
+    def fetch_into(self, words, hrows, drow):
+        """fetch() into caller-owned uint64 arrays (e.g. page-locked ones): ceil(n/32), nrec-1 (>= 1), 1 words."""
+        self._chk(self._L.debwt_fetch_bwt(self._h, _p64(words), _p64(hrows), _p64(drow)))
+
+    def fetch_small(self):
+        """(None, hash_rows, dollar_row): the row lists only, the BWT words stay in HBM."""
+        hrows = np.empty(max(self.nrec - 1, 1), dtype=np.uint64)
+        drow = np.empty(1, dtype=np.uint64)
+        self._chk(self._L.debwt_fetch_rows(self._h, _p64(hrows), _p64(drow)))
+        return None, hrows[:self.nrec - 1], int(drow[0])
+
+    def bwt_census(self):
+        """Rows of the result per 2-bit code (computed on the device)."""
+        c = np.zeros(4, dtype=np.uint64)
+        self._chk(self._L.debwt_bwt_census(self._h, _p64(c)))
+        return c
+
     def stats(self):
         st = _lib.DebwtStats()
         self._chk(self._L.debwt_get_stats(self._h, ctypes.byref(st)))

@@ -1118,6 +1118,29 @@ extern "C" int debwt_fetch_bwt(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_rows,
     return sync_check(c);
 }
 
+extern "C" int debwt_fetch_rows(debwt_ctx *c, uint64_t *hash_rows, uint64_t *dollar_row) {
+    if (!c || !dollar_row || (c->nrec > 1 && !hash_rows)) return DEBWT_EINVAL;
+    if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
+    if (c->shard_world > 1) { c->err = "sharded context: use debwt_shard_fetch"; return DEBWT_ESTATE; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->nrec > 1)
+        HIPCHK(c, hipMemcpyAsync(hash_rows, c->hash_rows.p, (c->nrec - 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dollar_row, c->dollar.p, 8, hipMemcpyDeviceToHost, c->stream));
+    return sync_check(c);
+}
+
+extern "C" int debwt_bwt_census(debwt_ctx *c, uint64_t counts[4]) {
+    if (!c || !counts) return DEBWT_EINVAL;
+    if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    ENSURE(c, c->dollar, 64);
+    u64 *d4 = c->dollar.as<u64>() + 1;                       // four spare words behind the '$' row
+    HIPCHK(c, hipMemsetAsync(d4, 0, 32, c->stream));
+    k_bwt_census<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->bwt.as<u64>(), shard_rows(c), d4);
+    HIPCHK(c, hipMemcpyAsync(counts, d4, 32, hipMemcpyDeviceToHost, c->stream));
+    return sync_check(c);
+}
+
 extern "C" int debwt_bwt_device_ptr(debwt_ctx *c, const uint64_t **d_words) {
     if (!c || !d_words) return DEBWT_EINVAL;
     if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
@@ -1342,6 +1365,13 @@ extern "C" int debwt_shard_fetch(debwt_ctx *c, uint64_t *words, uint64_t *hash_r
     if (*dollar_row != ~0ull) *dollar_row += base;
     return DEBWT_OK;
 }
+
+extern "C" int debwt_pinned_alloc(size_t bytes, void **out) {
+    if (!out || !bytes) return DEBWT_EINVAL;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? DEBWT_OK : DEBWT_ENOMEM;
+}
+extern "C" void debwt_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 
 extern "C" int debwt_get_stats(const debwt_ctx *c, debwt_stats *out) {
     if (!c || !out) return DEBWT_EINVAL;

@@ -1340,6 +1340,34 @@ struct HashRowsF {
     }
 };
 
+// symbol census of the packed BWT (rows [0, n): codes 0..3, '#'/'$' rows count as 3): out4[c] += rows with code c
+__global__ __launch_bounds__(DEBWT_BLOCK) void k_bwt_census(const u64 *__restrict__ bwt, u64 n, u64 *__restrict__ out4) {
+    __shared__ u64 red[4][DEBWT_WAVES];
+    const u64 nw = (n + 31) >> 5;
+    u64 c1 = 0, c2 = 0, c3 = 0, rows = 0;
+    for (u64 w = (u64)blockIdx.x * DEBWT_BLOCK + threadIdx.x; w < nw; w += (u64)gridDim.x * DEBWT_BLOCK) {
+        u64 v = bwt[w];
+        const u32 lim = (n - (w << 5)) < 32 ? (u32)(n - (w << 5)) : 32u;
+        const u64 valid = lim == 32 ? 0x5555555555555555ull : (0x5555555555555555ull << (2 * (32 - lim)));
+        const u64 lo = v & valid, hi = (v >> 1) & valid;          // row r of the word sits at bits 2*(31-r)
+        c3 += (u64)__popcll(hi & lo); c2 += (u64)__popcll(hi & ~lo); c1 += (u64)__popcll(~hi & lo);
+        rows += lim;
+    }
+    u64 v[4] = {rows - c1 - c2 - c3, c1, c2, c3};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[q] += __shfl_xor(v[q], d, 64);
+        if (lane_id() == 0) red[q][threadIdx.x >> 6] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        u64 t = 0;
+        for (int w = 0; w < DEBWT_WAVES; w++) t += red[threadIdx.x][w];
+        atomicAdd(&out4[threadIdx.x], t);
+    }
+}
+
 // counts of equal adjacent keys -> (kmer left-aligned, count) pairs for debwt_kmer_count_sorted
 struct KmerInfoF {
     const u64 *sk; u64 M; int k; u64 *kmers; u32 *first;

@@ -65,10 +65,13 @@ def _mutate(codes, rate, key):
     return codes
 
 
-def base_genome(length, seed=SEED_P, repeat_coverage=0.25):
-    """Uniform genome with repeat families written over it."""
+def base_genome(length, seed=SEED_P, repeat_coverage=0.25, lowcx_fraction=0.0, alu_copies=0, alu_divergence=0.12):
+    """Uniform genome with repeat families written over it.  Distribution R adds what real genomes put into the
+    large blue blocks: one short interspersed family with very many diverged copies (Alu-like), satellite arrays
+    (tandem copies of a 5..171-base unit, 1 % divergence, lowcx_fraction of the genome) and homopolymer /
+    microsatellite tracts (one per 150 / lowcx_fraction bases)."""
     g = uniform_codes(length, seed).copy()
-    if length < 2000 or repeat_coverage <= 0:
+    if length < 2000:
         return g
     covered, target, f = 0, int(repeat_coverage * length), 0
     while covered < target:
@@ -84,6 +87,34 @@ def base_genome(length, seed=SEED_P, repeat_coverage=0.25):
             g[p:p + clen] = cp
             covered += clen
         f += 1
+    if alu_copies:
+        cons = uniform_codes(300, _mix(seed, 0xA1, 0) & 0x7FFFFFFFFFFF)
+        for c in range(alu_copies):
+            p = _mix(seed, 0xA1, 1, c) % (length - 300)
+            g[p:p + 300] = _mutate(cons.copy(), alu_divergence, _mix(seed, 0xA1, 2, c))
+    if lowcx_fraction > 0:
+        cap = max(64, length // 8)
+        covered, target, t = 0, int(lowcx_fraction * length), 0
+        while covered < target:                              # satellite arrays
+            ulen = 5 + _mix(seed, 0x5A7, t, 1) % 167
+            alen = min(1000 + _mix(seed, 0x5A7, t, 2) % 99000, cap)
+            unit = uniform_codes(ulen, _mix(seed, 0x5A7, t, 3) & 0x7FFFFFFFFFFF)
+            arr = np.tile(unit, (alen + ulen - 1) // ulen)[:alen].copy()
+            p = _mix(seed, 0x5A7, t, 4) % (length - alen)
+            g[p:p + alen] = _mutate(arr, 0.01, _mix(seed, 0x5A7, t, 5))
+            covered += alen
+            t += 1
+        for t in range(int(length * lowcx_fraction / 150)):  # homopolymer and microsatellite tracts (exact repeats)
+            kind = _mix(seed, 0x7AC, t, 0) % 3
+            if kind < 2:
+                ulen, tlen = 1, 20 + _mix(seed, 0x7AC, t, 1) % 181
+                unit = np.array([(0, 3, 0, 3, 1, 2)[_mix(seed, 0x7AC, t, 2) % 6]], dtype=np.uint8)
+            else:
+                ulen, tlen = 2 + _mix(seed, 0x7AC, t, 1) % 5, 30 + _mix(seed, 0x7AC, t, 2) % 471
+                unit = uniform_codes(ulen, _mix(seed, 0x7AC, t, 3) & 0x7FFFFFFFFFFF)
+            tlen = min(tlen, cap)
+            p = _mix(seed, 0x7AC, t, 4) % (length - tlen)
+            g[p:p + tlen] = np.tile(unit, (tlen + ulen - 1) // ulen)[:tlen]
     return g
 
 
@@ -111,6 +142,40 @@ def chromosomes(total, records, seed=SEED_P, repeat_coverage=0.25):
         c = int(max(c, a + 33))
         out.append(g[a:c])
         a = c
+    return out
+
+
+def chromosome_lengths(total, records):
+    """Record lengths of one genome of `total` bases cut into `records` chromosome-like pieces (sizes shrink
+    geometrically like a karyotype), every record > 32 bases."""
+    w = np.array([0.93 ** i for i in range(records)])
+    cuts = np.floor(np.cumsum(w / w.sum()) * total).astype(np.int64)
+    cuts[-1] = total
+    out, a = [], 0
+    for c in cuts:
+        c = int(max(c, a + 33))
+        out.append(c - a)
+        a = c
+    return out
+
+
+def pan_chromosomes(genome_len, genomes, chroms, seed=SEED_P, snp_rate=1e-3, repeat_coverage=0.25, lowcx_fraction=0.0,
+                    alu_copies=0, alu_divergence=0.12):
+    """Distribution P at chromosome granularity ("10 genomes of 24 chromosome-like records"):
+    `genomes` copies of one base genome, each with independent SNPs, each cut into the same `chroms` records.
+    genomes == 1 gives chromosomes(), chroms == 1 gives pan_genome().  The native generator
+    (csrc/synth_host.cpp, debwt_synth_*) produces the same text without materialising it in numpy."""
+    g = base_genome(genome_len, seed, repeat_coverage, lowcx_fraction, alu_copies, alu_divergence)
+    lens = chromosome_lengths(genome_len, chroms)
+    out = []
+    for j in range(genomes):
+        gj = g.copy() if genomes > 1 else g
+        if genomes > 1:
+            _mutate(gj, snp_rate, _mix(seed, 0xC0FFEE, j))
+        a = 0
+        for ln in lens:
+            out.append(gj[a:a + ln])
+            a += ln
     return out
 
 

@@ -135,10 +135,22 @@ int debwt_build(debwt_ctx *ctx);
 /* Copies the result to host memory: bwt ceil(n/32) words, hash_rows nrec-1 rows ascending,
  * dollar_row 1 row -- the contents of OUT, OUT.#, OUT.$ (src/insertCase3.c:115-131). */
 int debwt_fetch_bwt(debwt_ctx *ctx, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row);
+/* Only the row lists (OUT.#, OUT.$) -- for callers that keep the BWT words in HBM. */
+int debwt_fetch_rows(debwt_ctx *ctx, uint64_t *hash_rows, uint64_t *dollar_row);
 /* Device address of the packed BWT words of the last run (for callers that keep it in HBM). */
 int debwt_bwt_device_ptr(debwt_ctx *ctx, const uint64_t **d_words);
 
+/* Symbol census of the result in HBM: counts[c] = rows of the packed BWT that hold code c ('#' and '$' rows are
+ * stored as 3, src/insertCase3.c:86-97) -- a BWT is a permutation of its text, so the census must equal the text's. */
+int debwt_bwt_census(debwt_ctx *ctx, uint64_t counts[4]);
+
 int debwt_get_stats(const debwt_ctx *ctx, debwt_stats *out);
+
+/* Page-locked host memory for the text handed to debwt_load_text and the buffers debwt_fetch_bwt fills: the copies
+ * then run at link rate and asynchronously (the reference keeps both in ordinary heap memory, src/collect#$.c:61,
+ * src/insertCase3.c:115-119; pageable buffers work here too, only slower). */
+int debwt_pinned_alloc(size_t bytes, void **out);
+void debwt_pinned_free(void *p);
 
 /* ---- one build over several GPUs: k-mer-prefix shards ----------------------------------
  * The reference has no distributed path; these entry points extend the stage sequence above for the case

@@ -20,7 +20,22 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <time.h>
 #include "debwt_oracle.h"
+
+/* wall-clock per stage -> OUT.timing ("stage seconds" lines); insertCase3 exits the process itself
+ * (src/insertCase3.c:137), so the last stage is closed by an atexit handler */
+static char g_timing_path[2048];
+static double g_t_last;
+static const char *g_stage_open;
+static double wall(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+static void stage_done(const char *name) {
+    double t = wall();
+    FILE *f = fopen(g_timing_path, "a");
+    if (f) { fprintf(f, "%s %.6f\n", name, t - g_t_last); fclose(f); }
+    g_t_last = t;
+}
+static void close_last_stage(void) { if (g_stage_open) stage_done(g_stage_open); }
 
 /* reference globals (tentative definitions in its headers; linked with -fcommon) */
 extern uint64_t trans[256];
@@ -82,6 +97,9 @@ int main(int argc, char **argv) {
     trans['#'] = 4; trans['$'] = 5;
     KMER_LENGTH_PlusOne = k; KMER_LENGTH = k - 1;
 
+    snprintf(g_timing_path, sizeof g_timing_path, "%s.timing", obj);
+    remove(g_timing_path);
+    g_t_last = wall();
     /* the Jellyfish dump, from the restated counter */
     uint64_t *reclen, nrec;
     char *seq = read_fasta(source, &reclen, &nrec);
@@ -107,11 +125,13 @@ int main(int argc, char **argv) {
     }
     fclose(fo);
     free(kmers); free(counts); free(sym); free(seq); free(reclen);
+    stage_done("kmer_dump_standin");
 
     /* src/main.c:79-83 */
     void *arg[3];
     arg[0] = (void *)bin; arg[1] = (void *)threads; arg[2] = (void *)source;
     if (mySort((void **)arg) != 0) { fprintf(stderr, "mySort failed\n"); return 1; }
+    stage_done("mySort");
     char dst[2048];
     snprintf(path, sizeof path, "%s/kmerInfo", bin);
     snprintf(dst, sizeof dst, "%s.kmerInfo", obj);
@@ -119,8 +139,11 @@ int main(int argc, char **argv) {
     /* src/main.c:88-103 (the two run concurrently there; they share nothing) */
     collect((void *)arg);
     getKmer((void *)bin);
+    stage_done("collect_getKmer");
     if (generateBlocks(bin) != 1) return 1;          /* src/main.c:109 */
+    stage_done("generateBlocks");
     if (generateSP((void **)arg) != 1) return 1;     /* src/main.c:122 */
+    stage_done("generateSP");
     snprintf(dst, sizeof dst, "%s.counters", obj);
     FILE *fc = fopen(dst, "w");
     fprintf(fc, "BWTLEN %lu\ncountRead %lu\ncase3num %lu\nblueBoundNum %lu\nredCapacity %lu\n"
@@ -129,7 +152,11 @@ int main(int argc, char **argv) {
             (unsigned long)blueBoundNum, (unsigned long)redCapacity, (unsigned long)blueCapacity,
             (unsigned long)spCodeLen, (unsigned long)specialBranchNum, (unsigned long)D);
     fclose(fc);
+    g_t_last = wall();                               /* the counters file above is this driver's, not a stage */
     if (sortBlue((void **)arg) != 1) return 1;       /* src/main.c:136 */
+    stage_done("sortBlue");
+    g_stage_open = "insertCase3";
+    atexit(close_last_stage);
     insertCase3(obj, bin);                           /* src/main.c:149; exit(0) inside */
     return 1;
 }
