@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--port-sample", type=int, default=100_000_000, help="bases of record 0 given to the oracle port")
     ap.add_argument("--tune", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # gloo: ranks may share one GPU (tests)
+    ap.add_argument("--force-sharded", action="store_true", help=argparse.SUPPRESS)   # the N>1 code path at N = 1 (tests)
     ap.add_argument("--mode", choices=["exchange", "scan", "replicas"], default="exchange",
                     help="N>1: 'exchange' (default) = ONE collection built by N k-mer-prefix shards with the key and "
                          "blue-entry all_to_all exchanges; 'scan' = the same shards, every GPU scanning the whole text "
@@ -136,10 +137,10 @@ def main():
     if args.backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    D.init(backend=args.backend, device_id=torch.device("cuda", local_rank))
+    D.init(backend=args.backend, device_id=torch.device("cuda", local_rank), force=args.force_sharded)
     tdev = "cuda" if args.backend == "nccl" else "cpu"
     device = torch.device("cuda", local_rank)
-    sharded = world > 1 and args.mode != "replicas"
+    sharded = (world > 1 and args.mode != "replicas") or args.force_sharded
 
     # ---- the collection: formula-defined, generated natively into page-locked host memory --------------------------
     t0 = time.perf_counter()

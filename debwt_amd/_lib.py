@@ -42,7 +42,8 @@ SYMBOLS = [
     "debwt_fetch_array", "debwt_kmer_count_sorted", "debwt_radix_sort_u64", "debwt_verify_inverse",
     "debwt_shard_begin", "debwt_shard_histogram", "debwt_shard_set_range", "debwt_shard_classify_local",
     "debwt_shard_facts_export", "debwt_shard_classify_global", "debwt_shard_info", "debwt_shard_fetch",
-    "debwt_shard_partition_keys", "debwt_shard_import_keys", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
+    "debwt_shard_partition_keys", "debwt_shard_plan", "debwt_shard_ranges", "debwt_shard_sort_begin",
+    "debwt_shard_sort_range", "debwt_shard_sort_end", "debwt_concat_rows", "debwt_shard_export", "debwt_census_words", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
     "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_pinned_alloc", "debwt_pinned_free",
 ]
 
@@ -117,8 +118,22 @@ def lib():
     u8p, u32p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32)
     L.debwt_shard_partition_keys.restype = ctypes.c_int
     L.debwt_shard_partition_keys.argtypes = [vp, u8p, vp, ctypes.c_uint64, u64p]
-    L.debwt_shard_import_keys.restype = ctypes.c_int
-    L.debwt_shard_import_keys.argtypes = [vp, vp, ctypes.c_uint64]
+    L.debwt_shard_plan.restype = ctypes.c_int
+    L.debwt_shard_plan.argtypes = [vp, u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, u32p]
+    L.debwt_shard_ranges.restype = ctypes.c_int
+    L.debwt_shard_ranges.argtypes = [vp, u32p, u64p, ctypes.c_uint32]
+    L.debwt_shard_sort_begin.restype = ctypes.c_int
+    L.debwt_shard_sort_begin.argtypes = [vp]
+    L.debwt_shard_sort_range.restype = ctypes.c_int
+    L.debwt_shard_sort_range.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint64]
+    L.debwt_shard_sort_end.restype = ctypes.c_int
+    L.debwt_shard_sort_end.argtypes = [vp]
+    L.debwt_shard_export.restype = ctypes.c_int
+    L.debwt_shard_export.argtypes = [vp, vp, ctypes.c_uint64]
+    L.debwt_census_words.restype = ctypes.c_int
+    L.debwt_census_words.argtypes = [vp, vp, ctypes.c_uint64, u64p]
+    L.debwt_concat_rows.restype = ctypes.c_int
+    L.debwt_concat_rows.argtypes = [vp, vp, ctypes.c_uint32, u64p, u64p, u64p, ctypes.c_uint64, vp]
     L.debwt_shard_sp_flags.restype = ctypes.c_int
     L.debwt_shard_sp_flags.argtypes = [vp, u64p, u64p]
     L.debwt_shard_sp_emit.restype = ctypes.c_int

@@ -81,7 +81,17 @@ struct debwt_ctx {
     u64 s0 = 0, s1 = 0;         // special suffixes [s0, s1) fall into this shard's node range
     bool facts_ready = false;
     u64 n_hash_local = 0;
-    bool keys_imported = false; // sharded exchange mode: this shard's keys arrived by alltoallv (keysA)
+    bool exchange = false;      // sharded exchange mode: the keys of every range arrive by alltoallv in a caller buffer
+    bool shard_planned = false; // `ranges` were cut by debwt_shard_plan from the global census
+    u64 *sort_a = nullptr, *sort_b = nullptr;   // the two key buffers of the range being sorted
+    u64 Dsum = 0;               // distinct keys over the ranges sorted so far
+    bool shared_hist = false;   // the first-pass histograms of all ranges came from one scan of the text
+    u64 Qtotal = 0;             // multi-in blocks of the whole text (all shards)
+    u64 S_rank = 0, B_rank = 0; // SP symbols / multi-in positions of this shard's text slice (all its sub-slices)
+    struct SubSlice { u64 g0, g1, S, B; };
+    std::vector<SubSlice> sub;  // the slice in pieces of < 2^32 positions
+    std::thread special_thread; // host special-region module, runs beside the key sort of the first range
+    bool special_running = false;
     u64 g0 = 0, g1 = 0;         // text slice of this shard for the SP stage, in 32-position groups
     u64 S_local = 0, B_slice = 0, sp_off = 0;
     int hbits = 10, pbits = 13;
@@ -258,6 +268,7 @@ extern "C" int debwt_create(const debwt_config *cfg, debwt_ctx **out) {
 
 extern "C" void debwt_destroy(debwt_ctx *c) {
     if (!c) return;
+    if (c->special_running) { c->special_thread.join(); c->special_running = false; }
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->text, &c->sepbits, &c->sep, &c->keysA, &c->keysB, &c->rs_counts, &c->cp_counts, &c->dk,
@@ -289,11 +300,12 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     if (n <= nrec * (uint64_t)K) return DEBWT_EINVAL;
     uint64_t M = n - nrec * (uint64_t)K;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->stage = ST_EMPTY;                                  // a failed (re-)load leaves an unusable context, not a stale one
     c->h_text = packed;
     c->h_sep.assign(sep, sep + nrec);
     c->n = n; c->nrec = nrec; c->M = M; c->Mfull = M; c->Mctx = M; c->NS = nrec * (uint64_t)K;
     c->shard_rank = 0; c->shard_world = 1; c->key_lo = c->key_hi = 0; c->Mbase = 0; c->qbase = 0;
-    c->keys_imported = false;
+    c->exchange = false; c->shard_planned = false;
     c->ranges.clear(); c->plan_valid = false;
     size_t tw = (size_t)((n + 63) >> 5) + 2, bw = (size_t)(n >> 6) + 3;
     ENSURE(c, c->text, tw * 8);
@@ -388,52 +400,27 @@ extern "C" int debwt_load_ascii(debwt_ctx *c, const char *seq, const uint64_t *r
 // ---------------------------------------------------------------------------------------------------
 // stage 1: keys, sort, RLE                                                            (a-1, a-2, a-3)
 
-// Cuts the key space into ranges of at most range_cap node instances at 12-mer prefix bins (the census the
-// reference balances its sort threads on, src/mySort.c:98-110).  A sharded or key-importing context has exactly
-// the range it was given.
-static int plan_ranges(debwt_ctx *c) {
-    c->local_done = false;
-    if (c->plan_valid && c->ranges.size() > 1 && c->shard_world == 1 && !c->keys_imported) {
-        // the census of this text was taken by an earlier build: same cuts
-        for (auto &r : c->ranges) { r.Q = r.qbase = r.B = r.Bbase = r.s0 = r.s1 = 0; }
-        c->Mctx = c->Mfull;
-        return DEBWT_OK;
-    }
+// Largest number of node instances one key range may hold: what the free HBM allows at `per_key` bytes of range
+// workspace (key buffers, distinct keys, first instances, classification bytes; in exchange mode also the caller's
+// send buffer) next to `later` bytes the later stages hold, and always below 2^32 (per-range indices are 32-bit).
+static int default_range_cap(debwt_ctx *c, u64 per_key, u64 later, u64 *cap) {
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+    const u64 held = c->keysA.cap + c->keysB.cap + c->dk.cap + c->dstart.cap + c->pflag.cap + c->mchar.cap +
+                     c->spsym.cap + c->momask.cap + c->mimask.cap + c->blue.cap + c->mi_list.cap;   // reused by this build
+    const u64 avail = free_b + held;
+    u64 rc = avail > later + (per_key << 28) ? (avail - later) / per_key : (1ull << 28);
+    *cap = std::min<u64>(rc, 0xFFFFFFF0ull - (1ull << 20));
+    return DEBWT_OK;
+}
+
+// Cuts the prefix bins [bin_lo, bin_hi) of the census `hist` into key ranges of at most `cap` node instances each
+// (near-equal ranges; the reference balances its sort threads on the same census, src/mySort.c:98-110).
+static int cut_ranges(debwt_ctx *c, const u64 *hist, u32 bin_lo, u32 bin_hi, u64 cap, u64 Mshard) {
     c->ranges.clear();
-    debwt_ctx::KeyRange r{};
-    u64 range_cap = c->range_cap;
-    if (!range_cap) {
-        // as many keys per range as HBM allows: ~30 bytes per key of range workspace (two key buffers, distinct keys,
-        // first instances, classification bytes) next to what the later stages hold for the whole text
-        // (~4 bytes per position: row symbols, SP code, flag masks, blue entries, BWT)
-        size_t free_b = 0, total_b = 0;
-        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-        const u64 held = c->keysA.cap + c->keysB.cap + c->dk.cap + c->dstart.cap + c->pflag.cap + c->mchar.cap +
-                         c->spsym.cap + c->momask.cap + c->mimask.cap + c->blue.cap + c->mi_list.cap;   // reused by this build
-        const u64 avail = free_b + held;
-        const u64 later = 4 * c->n + (8ull << 30);
-        range_cap = avail > later + (30ull << 28) ? (avail - later) / 30 : (1ull << 28);
-        range_cap = std::min<u64>(range_cap, 0xFFFFFFF0ull - (1ull << 20));
-        if (range_cap >= c->Mfull && c->Mfull < 0xFFFFFFF0ull) range_cap = c->Mfull;
-    }
-    if (c->shard_world > 1 || c->keys_imported || c->Mfull <= range_cap) {
-        if (c->M >= 0xFFFFFFF0ull) { c->err = "a key range must hold fewer than 2^32 node instances"; return DEBWT_ERANGE; }
-        r.key_lo = c->key_lo; r.key_hi = c->key_hi; r.M = c->M;
-        c->ranges.push_back(r);
-        c->Mctx = c->M;
-        return DEBWT_OK;
-    }
-    ENSURE(c, c->shard_hist, SHARD_BINS * 8);
-    HIPCHK(c, hipMemsetAsync(c->shard_hist.p, 0, SHARD_BINS * 8, c->stream));
-    k_prefix_hist<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), 0, c->n, c->K,
-                                                        c->shard_hist.as<u64>());
-    std::vector<u64> hist(SHARD_BINS);
-    HIPCHK(c, hipMemcpyAsync(hist.data(), c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
-    int rc = sync_check(c);
-    if (rc) return rc;
-    const u64 cap = std::min<u64>(range_cap, 0xFFFFFFF0ull - 1);
-    const u64 P = (c->Mfull + cap - 1) / cap;
-    const u64 per = (c->Mfull + P - 1) / P;
+    cap = std::min<u64>(cap, 0xFFFFFFF0ull - 1);
+    const u64 P = std::max<u64>(1, (Mshard + cap - 1) / cap);
+    const u64 per = (Mshard + P - 1) / P;
     const u64 limit = std::min(cap, per + per / 16);            // near-equal ranges, never above the cap
     const int kb = 2 * c->cfg.k;
     auto push = [&](u32 lo, u32 hi, u64 m, u64 base) {
@@ -444,16 +431,53 @@ static int plan_ranges(debwt_ctx *c) {
         c->ranges.push_back(q);
     };
     u64 acc = 0, base = 0, total = 0;
-    u32 lo = 0;
-    for (u32 b = 0; b < SHARD_BINS; b++) {
+    u32 lo = bin_lo;
+    for (u32 b = bin_lo; b < bin_hi; b++) {
         // a bin above the cap becomes a range of its own (the cap is a target; 2^32 instances is the hard limit)
         if (hist[b] >= 0xFFFFFFF0ull - (1ull << 20)) { c->err = "one 12-mer prefix bin holds 2^32 node instances or more"; return DEBWT_ERANGE; }
         if (acc && acc + hist[b] > limit) { push(lo, b, acc, base); base += acc; acc = 0; lo = b; }
         acc += hist[b]; total += hist[b];
     }
-    push(lo, SHARD_BINS, acc, base);
-    if (total != c->Mfull) { c->err = "prefix census differs from the number of node instances"; return DEBWT_EINTERNAL; }
-    c->Mctx = c->Mfull;
+    push(lo, bin_hi, acc, base);
+    if (total != Mshard) { c->err = "prefix census differs from the number of node instances"; return DEBWT_EINTERNAL; }
+    return DEBWT_OK;
+}
+
+// The key ranges of this build.  One GPU: the whole key space, cut by the census of the text when it exceeds the range
+// cap.  A shard: the ranges debwt_shard_plan cut, or the one range debwt_shard_set_range gave.
+static int plan_ranges(debwt_ctx *c) {
+    c->local_done = false;
+    if (c->shard_world == 1 && !c->shard_planned) { c->key_lo = c->key_hi = 0; c->Mctx = c->Mfull; c->Mbase = 0; c->exchange = false; }
+    if (c->shard_planned || (c->plan_valid && c->ranges.size() > 1 && c->shard_world == 1)) {
+        // cut by debwt_shard_plan / by the census an earlier build of this text took: same cuts
+        for (auto &r : c->ranges) { r.Q = r.qbase = r.B = r.Bbase = r.s0 = r.s1 = 0; }
+        return DEBWT_OK;
+    }
+    c->ranges.clear();
+    u64 range_cap = c->range_cap;
+    if (!range_cap) {
+        // ~30 bytes per key of range workspace next to what the later stages hold for the whole text
+        // (~4 bytes per position: row symbols, SP code, flag masks, blue entries, BWT)
+        int rc = default_range_cap(c, 30, 4 * c->n + (8ull << 30), &range_cap);
+        if (rc) return rc;
+        if (range_cap >= c->Mfull && c->Mfull < 0xFFFFFFF0ull) range_cap = c->Mfull;
+    }
+    if (c->shard_world > 1 || c->Mfull <= range_cap) {
+        if (c->Mctx >= 0xFFFFFFF0ull) { c->err = "a key range must hold fewer than 2^32 node instances"; return DEBWT_ERANGE; }
+        debwt_ctx::KeyRange r{};
+        r.key_lo = c->key_lo; r.key_hi = c->key_hi; r.M = c->Mctx;
+        c->ranges.push_back(r);
+        return DEBWT_OK;
+    }
+    ENSURE(c, c->shard_hist, SHARD_BINS * 8);
+    HIPCHK(c, hipMemsetAsync(c->shard_hist.p, 0, SHARD_BINS * 8, c->stream));
+    k_prefix_hist<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), 0, c->n, c->K,
+                                                        c->shard_hist.as<u64>());
+    std::vector<u64> hist(SHARD_BINS);
+    HIPCHK(c, hipMemcpyAsync(hist.data(), c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
+    int rc = sync_check(c);
+    if (rc) return rc;
+    if ((rc = cut_ranges(c, hist.data(), 0, SHARD_BINS, range_cap, c->Mfull))) return rc;
     c->plan_valid = true;
     return DEBWT_OK;
 }
@@ -461,16 +485,18 @@ static int plan_ranges(debwt_ctx *c) {
 static int classify_local(debwt_ctx *c);
 static int append_range(debwt_ctx *c, debwt_ctx::KeyRange &r);
 
-extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
-    if (!c) return DEBWT_EINVAL;
-    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
+static void join_special(debwt_ctx *c) {
+    if (c->special_running) { c->special_thread.join(); c->special_running = false; }
+}
+
+// plans the ranges, sizes the range workspace, starts the host special-region module
+static int sort_begin(debwt_ctx *c) {
     const u64 n = c->n;
     int rc = plan_ranges(c);
     if (rc) return rc;
     u64 maxM = 0;
     for (auto &r : c->ranges) maxM = std::max(maxM, r.M);
-    ENSURE(c, c->keysA, maxM * 8 + 64);
+    if (!c->exchange) ENSURE(c, c->keysA, maxM * 8 + 64);          // exchange mode: the received keys are buffer A
     ENSURE(c, c->keysB, maxM * 8 + 64);
     ENSURE(c, c->rs_skew, (maxM / 2048 + 2) * 4);
     ENSURE(c, c->rs_rle, radix_rle_ws_bytes(maxM));
@@ -478,15 +504,22 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
     ENSURE(c, c->dstart, maxM * 4 + 64);
     ENSURE(c, c->pflag, maxM + 64);                      // classification byte per distinct key of a range
     ENSURE(c, c->mchar, c->Mctx + 64);
-    c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0;
+    c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0; c->Dsum = 0;
     const size_t P = c->ranges.size();
-    u64 Dsum = 0;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     // the keys (node << 2 | pred) are read off the text inside the first radix pass: no unsorted key array
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    // several ranges: the chunk histograms of every range's first pass from ONE scan of the text
-    const bool shared_hist = P > 1 && P <= RS_MAX_RANGES && !c->keys_imported && c->shard_world == 1;
-    if (shared_hist) {
+    // host special-region module beside the GPU's key sort (src/collect#$.c:118-157,348-602)
+    join_special(c);
+    c->special_running = true;
+    c->special_thread = std::thread([c, n]() {
+        auto t0 = std::chrono::steady_clock::now();
+        build_special_tables(c->h_text, n, c->h_sep.data(), c->nrec, c->K, &c->special);
+        c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    });
+    // several ranges read off the text: the chunk histograms of every range's first pass from ONE scan of the text
+    c->shared_hist = P > 1 && P <= RS_MAX_RANGES && !c->exchange;
+    if (c->shared_hist) {
         const int kb = 2 * c->cfg.k;
         std::vector<u8> rob(SHARD_BINS, 0xFF);
         int shifts[RS_MAX_RANGES];
@@ -499,75 +532,97 @@ extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
         ENSURE(c, c->dest_tab, SHARD_BINS);
         ENSURE(c, c->range_hist, P * radix_text_hist_stride() * sizeof(u32));
         HIPCHK(c, hipMemcpyAsync(c->dest_tab.p, rob.data(), SHARD_BINS, hipMemcpyHostToDevice, c->stream));
-        TextKeySrc all{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, 0, 0, 0, nullptr};
+        TextKeySrc all{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, 0, 0, 0, nullptr, nullptr, 0};
         hipError_t e = radix_text_hist_ranges(c->stream, all, c->dest_tab.as<u8>(), kb, shifts, (int)P, c->range_hist.as<u32>());
         if (e != hipSuccess) { c->err = std::string("range histograms: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
         HIPCHK(c, hipStreamSynchronize(c->stream));          // rob is host memory
     }
-    for (size_t i = 0; i < P; i++) {
-        debwt_ctx::KeyRange &r = c->ranges[i];
-        c->key_lo = r.key_lo; c->key_hi = r.key_hi; c->M = r.M;
-        TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, c->key_lo, c->key_hi, 0,
-                      shared_hist ? c->range_hist.as<u32>() + i * radix_text_hist_stride() : nullptr};
-        // exchange mode of a sharded build: the shard's keys are already in keysA (alltoallv), sort them from there
-        // the bucket finish of the sort counts the distinct keys of its tiles and the encoding follows tile by tile
-        // (tune bit 8 = 256: separate count and emit passes over the sorted keys instead)
-        RleSink sink{c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase, c->rs_rle.p, &c->h_scalars[0], false};
-        rc = sort_keys(c, c->keysA.as<u64>(), c->keysB.as<u64>(), r.M, 2 * c->cfg.k, &c->sk, i == 0,
-                       c->keys_imported ? nullptr : &ts, true, (c->cfg.reserved & 256) ? nullptr : &sink);
-        if (rc) return rc;
-        if (P == 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-        if (!sink.done) {
-            RleF f{c->sk, c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase};
-            if ((rc = cp_count(c, f, r.M, cp_area(c, 0), 0))) return rc;
-            if ((rc = cp_emit(c, f, r.M, cp_area(c, 0)))) return rc;
-        }
-        if (i == 0) {
-            // host special-region module while the GPU sorts (src/collect#$.c:118-157,348-602)
-            auto t0 = std::chrono::steady_clock::now();
-            build_special_tables(c->h_text, n, c->h_sep.data(), c->nrec, c->K, &c->special);
-            c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            const SpecialTables &sp = c->special;
-            ENSURE(c, c->branch, sp.branch.size() * 8 + 64);
-            HIPCHK(c, hipMemcpyAsync(c->head_keys.p, sp.head_keys.data(), c->nrec * 8, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->spkey.p, sp.key.data(), c->NS * 8, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->spchr.p, sp.chr.data(), c->NS, hipMemcpyHostToDevice, c->stream));
-            if (!sp.branch.empty())
-                HIPCHK(c, hipMemcpyAsync(c->branch.p, sp.branch.data(), sp.branch.size() * 8, hipMemcpyHostToDevice, c->stream));
-        }
-        // special suffixes whose key lies in this range, and their rows among the context's instances
-        {
-            const std::vector<uint64_t> &key = c->special.key;          // ascending (suffix order implies key order)
-            u64 s0 = 0, s1 = c->NS;
-            if (c->shard_world > 1 || P > 1) {
-                s0 = std::lower_bound(key.begin(), key.end(), r.key_lo >> 2) - key.begin();
-                s1 = r.key_hi ? (u64)(std::lower_bound(key.begin(), key.end(), r.key_hi >> 2) - key.begin()) : c->NS;
-            }
-            r.s0 = s0; r.s1 = s1;
-        }
-        if ((rc = sync_check(c))) return rc;
-        c->D = c->h_scalars[0];
-        Dsum += c->D;
-        if (r.s1 > r.s0)
-            k_special_rows<<<grid_for(r.s1 - r.s0, 256), 256, 0, c->stream>>>(
-                c->dk.as<u64>(), c->dstart.as<u32>(), c->D, r.M, c->spkey.as<u64>() + r.s0, r.s1 - r.s0,
-                r.Mbase + (r.s0 - c->ranges[0].s0), c->sprow.as<u64>() + r.s0);
-        if (P > 1) {
-            // the range's keys are gone after this iteration: classify them now
-            if ((rc = classify_local(c))) return rc;
-            if ((rc = append_range(c, r))) return rc;
-        }
+    return DEBWT_OK;
+}
+
+// sorts, run-length encodes and (unless it is the only range of a text-fed build) classifies range i.
+// imported: the range's keys in a caller-owned DEVICE buffer (exchange mode: it serves as key buffer A and must stay
+// valid until the next range or debwt_shard_sort_end), else the keys are read off the text.
+static int sort_range(debwt_ctx *c, size_t i, u64 *imported) {
+    const u64 n = c->n;
+    const size_t P = c->ranges.size();
+    debwt_ctx::KeyRange &r = c->ranges[i];
+    int rc;
+    c->M = r.M;
+    c->sort_a = imported ? imported : c->keysA.as<u64>();
+    c->sort_b = c->keysB.as<u64>();
+    TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), n, c->K, r.key_lo, r.key_hi, 0,
+                  c->shared_hist ? c->range_hist.as<u32>() + i * radix_text_hist_stride() : nullptr, nullptr, 0};
+    // the bucket finish of the sort counts the distinct keys of its tiles and the encoding follows tile by tile
+    // (tune bit 8 = 256: separate count and emit passes over the sorted keys instead)
+    RleSink sink{c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase, c->rs_rle.p, &c->h_scalars[0], false};
+    if (imported && r.M < 2) c->sk = c->sort_a;
+    else if ((rc = sort_keys(c, c->sort_a, c->sort_b, r.M, 2 * c->cfg.k, &c->sk, i == 0, imported ? nullptr : &ts, true,
+                             (c->cfg.reserved & 256) ? nullptr : &sink))) return rc;
+    if (P == 1 && !c->exchange) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (!sink.done) {
+        RleF f{c->sk, c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase};
+        if ((rc = cp_count(c, f, r.M, cp_area(c, 0), 0))) return rc;
+        if ((rc = cp_emit(c, f, r.M, cp_area(c, 0)))) return rc;
     }
+    if (i == 0) {
+        join_special(c);
+        const SpecialTables &sp = c->special;
+        ENSURE(c, c->branch, sp.branch.size() * 8 + 64);
+        HIPCHK(c, hipMemcpyAsync(c->head_keys.p, sp.head_keys.data(), c->nrec * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->spkey.p, sp.key.data(), c->NS * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->spchr.p, sp.chr.data(), c->NS, hipMemcpyHostToDevice, c->stream));
+        if (!sp.branch.empty())
+            HIPCHK(c, hipMemcpyAsync(c->branch.p, sp.branch.data(), sp.branch.size() * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    // special suffixes whose key lies in this range, and their rows among the context's instances
+    {
+        const std::vector<uint64_t> &key = c->special.key;          // ascending (suffix order implies key order)
+        u64 s0 = 0, s1 = c->NS;
+        if (c->shard_world > 1 || P > 1) {
+            s0 = std::lower_bound(key.begin(), key.end(), r.key_lo >> 2) - key.begin();
+            s1 = r.key_hi ? (u64)(std::lower_bound(key.begin(), key.end(), r.key_hi >> 2) - key.begin()) : c->NS;
+        }
+        r.s0 = s0; r.s1 = s1;
+    }
+    if ((rc = sync_check(c))) return rc;
+    c->D = c->h_scalars[0];
+    c->Dsum += c->D;
+    if (r.s1 > r.s0)
+        k_special_rows<<<grid_for(r.s1 - r.s0, 256), 256, 0, c->stream>>>(
+            c->dk.as<u64>(), c->dstart.as<u32>(), c->D, r.M, c->spkey.as<u64>() + r.s0, r.s1 - r.s0,
+            r.Mbase + (r.s0 - c->ranges[0].s0), c->sprow.as<u64>() + r.s0);
+    if (P > 1 || c->exchange) {
+        // the range's keys are gone after this call: classify them now
+        if ((rc = classify_local(c))) return rc;
+        if ((rc = append_range(c, r))) return rc;
+    }
+    return DEBWT_OK;
+}
+
+static int sort_end(debwt_ctx *c) {
     c->s0 = c->ranges.front().s0; c->s1 = c->ranges.back().s1;
-    if (P > 1) {
+    if (c->ranges.size() > 1 || c->exchange) {
         c->local_done = true;
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
         HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     }
-    c->st.distinct_keys = Dsum;
+    c->st.distinct_keys = c->Dsum;
     c->st.special_branch_num = c->special.branch.size();
     c->stage = ST_SORTED;
     return DEBWT_OK;
+}
+
+extern "C" int debwt_kmer_sort_rle(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    if (c->exchange) { c->err = "exchange-mode shard: use debwt_shard_sort_begin/_range/_end"; return DEBWT_ESTATE; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = sort_begin(c);
+    for (size_t i = 0; !rc && i < c->ranges.size(); i++) rc = sort_range(c, i, nullptr);
+    join_special(c);
+    if (rc) return rc;
+    return sort_end(c);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -587,7 +642,7 @@ static int classify_local(debwt_ctx *c) {
         u32 nchunks; u64 chunk;
         plan_chunks(D, &nchunks, &chunk);
         u32 *ca = cp_area(c, 1), *cb = cp_area(c, 2);
-        u32 *wl = (c->sk == c->keysA.as<u64>() ? c->keysB : c->keysA).as<u32>();   // the sort's scratch buffer: >= 8 M bytes
+        u32 *wl = reinterpret_cast<u32 *>(c->sk == c->sort_a ? c->sort_b : c->sort_a);   // the sort's scratch buffer: >= 8 M bytes
         u32 *wl_count = cp_area(c, 7);
         if (D) {
             k_classify_flags<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ff, chunk, ca, cb, wl, wl_count);
@@ -699,6 +754,7 @@ static int classify_global(debwt_ctx *c, const u64 *d_facts, u64 nfacts, u64 qba
     }
     c->st.red_capacity = R; c->st.blue_capacity = c->B; c->st.blue_bound_num = Q; c->st.case3num = 2 * Q;
     c->st.blue_large_blocks = c->nlarge;
+    c->Qtotal = c->h_scalars[6];
     c->stage = ST_CLASSIFIED;
     return DEBWT_OK;
 }
@@ -710,6 +766,7 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc;
     if (!c->local_done) {
+        c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0;      // a repeated call starts over
         if ((rc = classify_local(c))) return rc;
         if ((rc = append_range(c, c->ranges[0]))) return rc;
     }
@@ -1153,10 +1210,17 @@ extern "C" int debwt_bwt_device_ptr(debwt_ctx *c, const uint64_t **d_words) {
 // shard r sorts and classifies the keys of its prefix range, owns their contiguous BWT rows and their blocks.
 // Host orchestration and the collectives live in debwt_amd/sharded.py.
 
+static void shard_slice(const debwt_ctx *c, u64 *p0, u64 *p1) {
+    // slices are cut at multiples of 32 positions so that the SP stage can work on whole text words
+    u64 per = ((c->n / c->shard_world) >> 5) << 5;
+    *p0 = per * c->shard_rank;
+    *p1 = c->shard_rank + 1 == c->shard_world ? c->n : per * (c->shard_rank + 1);
+}
+
 extern "C" int debwt_shard_begin(debwt_ctx *c, int rank, int world) {
-    if (!c || world < 1 || rank < 0 || rank >= world) return DEBWT_EINVAL;
+    if (!c || world < 1 || world > 255 || rank < 0 || rank >= world) return DEBWT_EINVAL;   // owner tables hold bytes, 0xFF = none
     if (c->stage < ST_LOADED) return DEBWT_ESTATE;
-    c->shard_rank = rank; c->shard_world = world; c->keys_imported = false;
+    c->shard_rank = rank; c->shard_world = world; c->exchange = false; c->shard_planned = false;
     c->key_lo = c->key_hi = 0; c->M = c->Mctx = c->Mfull; c->Mbase = 0; c->qbase = 0; c->s0 = 0; c->s1 = c->NS;
     c->ranges.clear(); c->plan_valid = false;
     c->stage = ST_LOADED;
@@ -1169,9 +1233,9 @@ extern "C" int debwt_shard_histogram(debwt_ctx *c, uint64_t *hist4096) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     ENSURE(c, c->shard_hist, SHARD_BINS * 8);
     HIPCHK(c, hipMemsetAsync(c->shard_hist.p, 0, SHARD_BINS * 8, c->stream));
-    // this shard counts the positions [n*r/w, n*(r+1)/w): the census itself is data-parallel over the text
-    u64 p0 = c->n / c->shard_world * c->shard_rank;
-    u64 p1 = c->shard_rank + 1 == c->shard_world ? c->n : c->n / c->shard_world * (c->shard_rank + 1);
+    // this shard counts the positions of its text slice: the census itself is data-parallel over the text
+    u64 p0, p1;
+    shard_slice(c, &p0, &p1);
     k_prefix_hist<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), p0, p1, c->K,
                                                         c->shard_hist.as<u64>());
     HIPCHK(c, hipMemcpyAsync(hist4096, c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1186,19 +1250,90 @@ extern "C" int debwt_shard_set_range(debwt_ctx *c, uint32_t bin_lo, uint32_t bin
     c->key_lo = (u64)bin_lo << (kb - 12);
     c->key_hi = bin_hi == SHARD_BINS ? 0ull : ((u64)bin_hi << (kb - 12));   // 0: no upper bound (last shard)
     c->M = c->Mctx = m_keys; c->Mbase = m_base;
+    c->shard_planned = false; c->exchange = false; c->ranges.clear();
     c->stage = ST_LOADED;
     return DEBWT_OK;
+}
+
+extern "C" int debwt_shard_plan(debwt_ctx *c, const uint64_t *hist4096, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_base,
+                                int exchange, uint32_t *nranges) {
+    if (!c || !hist4096 || !nranges || bin_lo > bin_hi || bin_hi > SHARD_BINS) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int kb = 2 * c->cfg.k;
+    u64 m = 0;
+    for (u32 b = bin_lo; b < bin_hi; b++) m += hist4096[b];
+    if (m > c->Mfull) return DEBWT_EINVAL;
+    c->key_lo = (u64)bin_lo << (kb - 12);
+    c->key_hi = bin_hi == SHARD_BINS ? 0ull : ((u64)bin_hi << (kb - 12));
+    c->M = c->Mctx = m; c->Mbase = m_base;
+    u64 cap = c->range_cap;
+    if (!cap) {
+        // range workspace per key: 30 bytes, plus the caller's send buffer in exchange mode (the receive buffer is
+        // key buffer A); the later stages hold ~4 bytes per position of the shard's share and n/2 for the whole text
+        // (2-bit text, flag masks)
+        int rc = default_range_cap(c, exchange ? 40 : 30, 4 * (c->n / (u64)c->shard_world) + c->n / 2 + (8ull << 30), &cap);
+        if (rc) return rc;
+    }
+    int rc = cut_ranges(c, reinterpret_cast<const u64 *>(hist4096), bin_lo, bin_hi, cap, m);
+    if (rc) return rc;
+    c->shard_planned = true; c->exchange = exchange != 0; c->plan_valid = false;
+    c->stage = ST_LOADED;
+    *nranges = (u32)c->ranges.size();
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_shard_ranges(debwt_ctx *c, uint32_t *bin_bounds, uint64_t *m_keys, uint32_t capacity) {
+    if (!c || !bin_bounds || !m_keys) return DEBWT_EINVAL;
+    if (!c->shard_planned || c->ranges.size() > capacity) return DEBWT_ESTATE;
+    const int kb = 2 * c->cfg.k;
+    for (size_t i = 0; i < c->ranges.size(); i++) {
+        bin_bounds[i] = (u32)(c->ranges[i].key_lo >> (kb - 12));
+        bin_bounds[i + 1] = c->ranges[i].key_hi ? (u32)(c->ranges[i].key_hi >> (kb - 12)) : SHARD_BINS;
+        m_keys[i] = c->ranges[i].M;
+    }
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_shard_sort_begin(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED || !c->shard_planned || !c->exchange) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->stage = ST_LOADED;
+    int rc = sort_begin(c);
+    if (rc) join_special(c);
+    return rc;
+}
+
+extern "C" int debwt_shard_sort_range(debwt_ctx *c, uint32_t range, uint64_t *d_keys, uint64_t count) {
+    if (!c || (!d_keys && count)) return DEBWT_EINVAL;
+    if (c->stage != ST_LOADED || !c->exchange || range >= c->ranges.size()) return DEBWT_ESTATE;
+    if (count != c->ranges[range].M) { c->err = "received keys differ from the census of the range"; return DEBWT_EINTERNAL; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = sort_range(c, range, (u64 *)d_keys);
+    if (rc) join_special(c);
+    return rc;
+}
+
+extern "C" int debwt_shard_sort_end(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage != ST_LOADED || !c->exchange) return DEBWT_ESTATE;
+    join_special(c);
+    return sort_end(c);
 }
 
 extern "C" int debwt_shard_classify_local(debwt_ctx *c, uint64_t *nfacts, uint64_t *nblocks, uint64_t *blue_rows) {
     if (!c) return DEBWT_EINVAL;
     if (c->stage < ST_SORTED) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->ranges.size() != 1) return DEBWT_ESTATE;
-    int rc = classify_local(c);
-    if (rc) return rc;
-    if ((rc = append_range(c, c->ranges[0]))) return rc;
-    if (nfacts) *nfacts = c->Rmo + c->Q;
+    if (!c->local_done) {                                  // one text-fed range: its keys are still there
+        if (c->ranges.size() != 1) return DEBWT_ESTATE;
+        c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0;
+        int rc = classify_local(c);
+        if (rc) return rc;
+        if ((rc = append_range(c, c->ranges[0]))) return rc;
+    }
+    if (nfacts) *nfacts = c->nfacts_acc;
     if (nblocks) *nblocks = c->Q;
     if (blue_rows) *blue_rows = c->B;
     return DEBWT_OK;
@@ -1206,10 +1341,10 @@ extern "C" int debwt_shard_classify_local(debwt_ctx *c, uint64_t *nfacts, uint64
 
 extern "C" int debwt_shard_facts_export(debwt_ctx *c, uint64_t *d_dst, uint64_t capacity) {
     if (!c || !d_dst) return DEBWT_EINVAL;
-    if (!c->facts_ready || capacity < c->Rmo + c->Q) return DEBWT_ESTATE;
+    if (!c->facts_ready || capacity < c->nfacts_acc) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->Rmo + c->Q)
-        HIPCHK(c, hipMemcpyAsync(d_dst, c->facts.p, (c->Rmo + c->Q) * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (c->nfacts_acc)
+        HIPCHK(c, hipMemcpyAsync(d_dst, c->facts_acc.p, c->nfacts_acc * 8, hipMemcpyDeviceToDevice, c->stream));
     return sync_check(c);
 }
 
@@ -1223,43 +1358,36 @@ extern "C" int debwt_shard_classify_global(debwt_ctx *c, const uint64_t *d_facts
 
 // ---- exchange mode: keys and blue entries travel by alltoallv, every shard scans only its text slice ----------
 
-static void shard_slice(const debwt_ctx *c, u64 *p0, u64 *p1) {
-    // slices are cut at multiples of 32 positions so that the SP stage can work on whole text words
-    u64 per = ((c->n / c->shard_world) >> 5) << 5;
-    *p0 = per * c->shard_rank;
-    *p1 = c->shard_rank + 1 == c->shard_world ? c->n : per * (c->shard_rank + 1);
-}
-
 extern "C" int debwt_shard_partition_keys(debwt_ctx *c, const uint8_t *shard_of_bin, uint64_t *d_out, uint64_t capacity,
                                           uint64_t *offs) {
-    // keys of this shard's text slice, grouped by destination shard (bucket exchange)
+    // keys of this shard's text slice, grouped by destination shard (bucket exchange); bins whose
+    // entry is 0xFF are not part of this exchange round and yield nothing
     if (!c || !shard_of_bin || !d_out || !offs) return DEBWT_EINVAL;
     if (c->stage < ST_LOADED) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     u64 p0, p1;
     shard_slice(c, &p0, &p1);
-    if (capacity < p1 - p0) return DEBWT_EINVAL;
+    bool sparse = false;
+    for (u32 b = 0; b < SHARD_BINS; b++) {
+        if (shard_of_bin[b] == 0xFF) sparse = true;
+        else if (shard_of_bin[b] >= c->shard_world) return DEBWT_EINVAL;
+    }
+    if (capacity >= 0xFFFFFFF0ull) capacity = 0xFFFFFFF0ull - 1;     // a pass addresses its output with 32 bits
     ENSURE(c, c->dest_tab, SHARD_BINS);
     HIPCHK(c, hipMemcpyAsync(c->dest_tab.p, shard_of_bin, SHARD_BINS, hipMemcpyHostToDevice, c->stream));
-    TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, 0, 0, p0};
+    const int tshift = 2 * c->cfg.k - 12;
+    TextKeySrc ts{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, 0, 0, p0, nullptr,
+                  sparse ? c->dest_tab.as<u8>() : nullptr, tshift};
     RsDigit dg{};
-    dg.mode = 1; dg.tab = c->dest_tab.as<u8>(); dg.tshift = 2 * c->cfg.k - 12;
+    dg.mode = 1; dg.tab = c->dest_tab.as<u8>(); dg.tshift = tshift;
     hipError_t e = radix_partition_by_shard(c->stream, nullptr, &ts, p1 - p0, (u64 *)d_out, dg, (u32)c->shard_world,
-                                            radix_ws(c), (u64 *)offs);
+                                            radix_ws(c), (u64 *)offs, sparse);
     if (e != hipSuccess) { c->err = hipGetErrorString(e); return DEBWT_EDEVICE; }
+    if (offs[c->shard_world] > capacity) { c->err = "partition output exceeds the caller's buffer"; return DEBWT_EINTERNAL; }
     return DEBWT_OK;
 }
 
-extern "C" int debwt_shard_import_keys(debwt_ctx *c, const uint64_t *d_keys, uint64_t count) {
-    if (!c || (!d_keys && count)) return DEBWT_EINVAL;
-    if (c->stage < ST_LOADED || count != c->M) return DEBWT_ESTATE;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
-    ENSURE(c, c->keysA, count * 8 + 64);
-    if (count) HIPCHK(c, hipMemcpyAsync(c->keysA.p, d_keys, count * 8, hipMemcpyDeviceToDevice, c->stream));
-    c->keys_imported = true;
-    return sync_check(c);
-}
-
+// flags of the slice, in pieces of < 2^32 positions; totals of the slice
 extern "C" int debwt_shard_sp_flags(debwt_ctx *c, uint64_t *sp_symbols, uint64_t *mi_positions) {
     if (!c) return DEBWT_EINVAL;
     if (c->stage < ST_CLASSIFIED) return DEBWT_ESTATE;
@@ -1268,21 +1396,58 @@ extern "C" int debwt_shard_sp_flags(debwt_ctx *c, uint64_t *sp_symbols, uint64_t
     shard_slice(c, &p0, &p1);
     int rc = sp_prepare(c);
     if (rc) return rc;
-    if ((rc = sp_flags(c, p0 >> 5, (p1 + 31) >> 5))) return rc;
-    if (sp_symbols) *sp_symbols = c->S_local;
-    if (mi_positions) *mi_positions = c->B_slice;
+    c->sub.clear();
+    c->S_rank = c->B_rank = 0;
+    const u64 G0 = p0 >> 5, G1 = (p1 + 31) >> 5;
+    for (u64 g0 = G0; g0 < G1 || c->sub.empty(); g0 += SP_SLICE_GROUPS) {
+        const u64 g1 = std::min(G1, g0 + SP_SLICE_GROUPS);
+        if ((rc = sp_flags(c, g0, g1))) return rc;
+        c->sub.push_back(debwt_ctx::SubSlice{g0, g1, c->S_local, c->B_slice});
+        c->S_rank += c->S_local; c->B_rank += c->B_slice;
+    }
+    if (sp_symbols) *sp_symbols = c->S_rank;
+    if (mi_positions) *mi_positions = c->B_rank;
     return DEBWT_OK;
 }
 
+// bits of a routed blue entry: block id << qshift | SP index << 3 | pred
+static int routed_qshift(const debwt_ctx *c) {
+    int qbits = 1;
+    while ((1ull << qbits) < c->Qtotal) qbits++;
+    return 64 - qbits;
+}
+
 extern "C" int debwt_shard_sp_emit(debwt_ctx *c, uint64_t sp_offset, uint8_t *d_dst, uint64_t capacity) {
-    // SP symbols of the slice at global offset sp_offset; a copy of them goes to the DEVICE buffer d_dst
+    // SP symbols of the slice at global offset sp_offset (a copy of them goes to the DEVICE buffer d_dst) and its
+    // multi-in positions as routed blue entries (kept in the context for debwt_shard_blue_route)
     if (!c || !d_dst) return DEBWT_EINVAL;
-    if (c->stage < ST_CLASSIFIED || capacity < c->S_local) return DEBWT_ESTATE;
+    if (c->stage < ST_CLASSIFIED || c->sub.empty() || capacity < c->S_rank) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    int rc = sp_emit(c, sp_offset);
-    if (rc) return rc;
-    if (c->S_local)
-        HIPCHK(c, hipMemcpyAsync(d_dst, c->spsym.as<u8>() + sp_offset, c->S_local, hipMemcpyDeviceToDevice, c->stream));
+    const int qshift = routed_qshift(c);
+    if (sp_offset + c->S_rank >= (1ull << (qshift - 3))) {
+        c->err = "a routed blue entry cannot hold block id and SP index in 61 bits";
+        return DEBWT_ERANGE;
+    }
+    ENSURE(c, c->facts_tmp, c->B_rank * 8 + 64);
+    u64 *routed = c->facts_tmp.as<u64>();
+    u64 off = sp_offset, bseen = 0;
+    int rc;
+    for (const auto &sl : c->sub) {
+        // the scan of the piece's flag counts again (the compaction areas hold one piece at a time)
+        c->g0 = sl.g0; c->g1 = sl.g1;
+        SpCountF fc{c->momask.as<u32>() + sl.g0, c->mimask.as<u32>() + sl.g0};
+        if ((rc = cp_count2(c, fc, sl.g1 - sl.g0, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
+        c->S_local = sl.S; c->B_slice = sl.B;
+        if ((rc = sp_emit(c, off))) return rc;
+        if (sl.B)
+            k_blue_route_q<<<grid_for(sl.B, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+                c->mi_list.as<ulonglong2>(), sl.B, c->htab.as<HSlot>(), c->hbits, qshift, routed + bseen);
+        off += sl.S; bseen += sl.B;
+        if ((rc = sync_check(c))) return rc;
+    }
+    c->sp_off = sp_offset;
+    if (c->S_rank)
+        HIPCHK(c, hipMemcpyAsync(d_dst, c->spsym.as<u8>() + sp_offset, c->S_rank, hipMemcpyDeviceToDevice, c->stream));
     return sync_check(c);
 }
 
@@ -1300,26 +1465,20 @@ extern "C" int debwt_shard_sp_import(debwt_ctx *c, const uint8_t *d_src, uint64_
 
 extern "C" int debwt_shard_blue_route(debwt_ctx *c, const uint32_t *first_block_of_shard, uint64_t *d_out,
                                       uint64_t capacity, uint64_t *offs) {
-    // blue entries of this shard's text slice, grouped by the shard that owns their block
+    // the routed blue entries of this shard's text slice, grouped by the shard that owns their block
     if (!c || !first_block_of_shard || !d_out || !offs) return DEBWT_EINVAL;
-    if (c->stage < ST_CLASSIFIED || capacity < c->B_slice) return DEBWT_ESTATE;
-    if (first_block_of_shard[c->shard_world] >= (1u << 28) || c->sp_off + c->S_local >= (1ull << 33)) {
-        c->err = "routed blue entries hold 28-bit block ids and 33-bit SP indices";
-        return DEBWT_ERANGE;
-    }
+    if (c->stage < ST_CLASSIFIED || capacity < c->B_rank) return DEBWT_ESTATE;
+    if (c->B_rank >= 0xFFFFFFF0ull) { c->err = "a text slice holds 2^32 multi-in positions or more"; return DEBWT_ERANGE; }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const u32 w = (u32)c->shard_world;
     ENSURE(c, c->qbounds, (w + 1) * 4);
     HIPCHK(c, hipMemcpyAsync(c->qbounds.p, first_block_of_shard, (w + 1) * 4, hipMemcpyHostToDevice, c->stream));
     for (u32 i = 0; i <= w; i++) offs[i] = 0;
-    if (!c->B_slice) return sync_check(c);
-    ENSURE(c, c->facts_tmp, c->B_slice * 8 + 64);
-    u64 *tmp = c->facts_tmp.as<u64>();
-    k_blue_route<<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-        c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, tmp);
+    if (!c->B_rank) return sync_check(c);
     RsDigit dg{};
-    dg.mode = 2; dg.bounds = c->qbounds.as<u32>(); dg.nb = w;
-    hipError_t e = radix_partition_by_shard(c->stream, tmp, nullptr, c->B_slice, (u64 *)d_out, dg, w, radix_ws(c), (u64 *)offs);
+    dg.mode = 2; dg.bounds = c->qbounds.as<u32>(); dg.nb = w; dg.tshift = routed_qshift(c);
+    hipError_t e = radix_partition_by_shard(c->stream, c->facts_tmp.as<u64>(), nullptr, c->B_rank, (u64 *)d_out, dg, w,
+                                            radix_ws(c), (u64 *)offs);
     if (e != hipSuccess) { c->err = hipGetErrorString(e); return DEBWT_EDEVICE; }
     return DEBWT_OK;
 }
@@ -1333,10 +1492,35 @@ extern "C" int debwt_shard_blue_place(debwt_ctx *c, const uint64_t *d_entries, u
     if (c->Q) HIPCHK(c, hipMemsetAsync(c->qcursor.p, 0, c->Q * 4, c->stream));
     if (count)
         k_blue_place<<<grid_for(count, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>((const u64 *)d_entries, count,
-                                                                                 (u32)c->qbase, (u32)c->Q,
+                                                                                 (u32)c->qbase, (u32)c->Q, routed_qshift(c),
                                                                                  c->qcursor.as<u32>(), c->blk_start.as<u64>(),
                                                                                  c->blue.as<u64>());
     return sync_check(c);
+}
+
+// Final concatenation: the shards' packed row ranges, each packed from its own first row, are
+// shift-merged into the BWT words of the whole text (the reference joins its per-thread SP segments the same way,
+// src/generateSP.c:379-405).  d_parts: DEVICE words of all parts; part i starts at word part_word_off[i] (one spare
+// readable word behind each part), holds rows [row_base[i], row_base[i] + rows[i]); d_out: ceil(n/32) DEVICE words.
+extern "C" int debwt_concat_rows(debwt_ctx *c, const uint64_t *d_parts, uint32_t nparts, const uint64_t *part_word_off,
+                                 const uint64_t *row_base, const uint64_t *rows, uint64_t n, uint64_t *d_out) {
+    if (!c || !d_parts || !nparts || !part_word_off || !row_base || !rows || !d_out) return DEBWT_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<ConcatPart> pp;
+    u64 next = 0;
+    for (u32 i = 0; i < nparts; i++) {
+        if (!rows[i]) continue;
+        if (row_base[i] != next) { c->err = "shard row ranges do not tile the BWT"; return DEBWT_EINVAL; }
+        pp.push_back(ConcatPart{part_word_off[i], row_base[i], rows[i]});
+        next += rows[i];
+    }
+    if (next != n) { c->err = "shard rows do not add up to n"; return DEBWT_EINVAL; }
+    ENSURE(c, c->qbounds, pp.size() * sizeof(ConcatPart) + 64);
+    HIPCHK(c, hipMemcpyAsync(c->qbounds.p, pp.data(), pp.size() * sizeof(ConcatPart), hipMemcpyHostToDevice, c->stream));
+    const u64 nw = (n + 31) >> 5;
+    k_concat_rows<<<grid_for(nw, 256), 256, 0, c->stream>>>((const u64 *)d_parts, c->qbounds.as<ConcatPart>(), (u32)pp.size(), n,
+                                                            (u64 *)d_out);
+    return sync_check(c);                                   // pp is host memory
 }
 
 extern "C" int debwt_shard_info(debwt_ctx *c, uint64_t *row_base, uint64_t *rows, uint64_t *hash_rows) {
@@ -1351,11 +1535,11 @@ extern "C" int debwt_shard_info(debwt_ctx *c, uint64_t *row_base, uint64_t *rows
 extern "C" int debwt_shard_fetch(debwt_ctx *c, uint64_t *words, uint64_t *hash_rows, uint64_t *dollar_row) {
     // words: ceil(rows/32), row j of the shard at bit 2*(31-(j&31)) of word j>>5; hash_rows / dollar_row are
     // GLOBAL rows (dollar_row = ~0 when the '$' row is not in this shard)
-    if (!c || !words || !dollar_row) return DEBWT_EINVAL;
+    if (!c || !dollar_row) return DEBWT_EINVAL;             // words == NULL: only the row lists
     if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const u64 rows = shard_rows(c), base = c->Mbase + c->s0;
-    HIPCHK(c, hipMemcpyAsync(words, c->bwt.p, (size_t)((rows + 31) >> 5) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (words) HIPCHK(c, hipMemcpyAsync(words, c->bwt.p, (size_t)((rows + 31) >> 5) * 8, hipMemcpyDeviceToHost, c->stream));
     if (c->n_hash_local && hash_rows)
         HIPCHK(c, hipMemcpyAsync(hash_rows, c->hash_rows.p, c->n_hash_local * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(dollar_row, c->dollar.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1372,6 +1556,29 @@ extern "C" int debwt_pinned_alloc(size_t bytes, void **out) {
     return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? DEBWT_OK : DEBWT_ENOMEM;
 }
 extern "C" void debwt_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int debwt_shard_export(debwt_ctx *c, uint64_t *d_words, uint64_t capacity) {
+    // the shard's packed rows to a DEVICE buffer (for the gather of the final concat); the words behind the last
+    // row up to `capacity` are zeroed
+    if (!c || !d_words) return DEBWT_EINVAL;
+    if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
+    const u64 nw = (shard_rows(c) + 31) >> 5;
+    if (capacity < nw) return DEBWT_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (nw) HIPCHK(c, hipMemcpyAsync(d_words, c->bwt.p, nw * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (capacity > nw) HIPCHK(c, hipMemsetAsync(d_words + nw, 0, (capacity - nw) * 8, c->stream));
+    return sync_check(c);
+}
+
+extern "C" int debwt_census_words(debwt_ctx *c, const uint64_t *d_words, uint64_t n, uint64_t counts[4]) {
+    if (!c || !d_words || !counts) return DEBWT_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    u64 *d4 = c->dollar.as<u64>() + 1;
+    HIPCHK(c, hipMemsetAsync(d4, 0, 32, c->stream));
+    k_bwt_census<<<2048, DEBWT_BLOCK, 0, c->stream>>>((const u64 *)d_words, n, d4);
+    HIPCHK(c, hipMemcpyAsync(counts, d4, 32, hipMemcpyDeviceToHost, c->stream));
+    return sync_check(c);
+}
 
 extern "C" int debwt_get_stats(const debwt_ctx *c, debwt_stats *out) {
     if (!c || !out) return DEBWT_EINVAL;

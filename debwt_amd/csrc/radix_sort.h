@@ -31,6 +31,8 @@ struct TextKeySrc {
     u64 pos0;             // item i of a pass is text position pos0 + i
     const u32 *pre_counts;  // optional: the chunk histograms of the first pass, digit-major as rs_hist writes them
                             // (radix_text_hist_ranges computed them for all key ranges in one scan of the text)
+    const u8 *bin_tab;      // optional: 4096 bytes, a key whose prefix bin (key >> bin_shift) maps to 0xFF is not
+    int bin_shift;          // produced (exchange rounds: only the keys of this round's ranges leave the slice)
 };
 
 // One scan of the text for the first-pass chunk histograms of up to RS_MAX_RANGES key ranges at once: range r holds
@@ -48,13 +50,16 @@ struct RsDigit {
     int shift; u32 mask;          // mode 0
     int mode;
     const u8 *tab; int tshift;    // mode 1: tab[key >> tshift]
-    const u32 *bounds; u32 nb;    // mode 2: owner of block id key >> 36
+    const u32 *bounds; u32 nb;    // mode 2: owner of block id key >> tshift
 };
 
 size_t radix_workspace_bytes(u64 max_keys);
 size_t radix_over_bytes(u64 max_keys);
+// sparse: only a fraction of the text positions yields a key (bin_tab filter): collect the keys of several position
+// tiles before ranking (rs_scatter_sparse_kernel)
 hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const TextKeySrc *text, u64 count, u64 *dst,
-                                    const RsDigit &dg, u32 nshards, const RadixWorkspace &ws, u64 *offs_host);
+                                    const RsDigit &dg, u32 nshards, const RadixWorkspace &ws, u64 *offs_host,
+                                    bool sparse = false);
 
 // Sorts `n` keys ascending on their low `key_bits` bits.  a: input; b: scratch of n words.
 // Returns the buffer (a or b) that holds the result.  All work is enqueued on `stream`.

@@ -33,7 +33,7 @@ __device__ __forceinline__ u32 rs_digit(const RsDigit &g, u64 k) {
         return __builtin_amdgcn_alignbit(up ? 0u : hi, up ? hi : lo, (u32)g.shift & 31u) & g.mask;
     }
     if (g.mode == 1) return g.tab[(k >> g.tshift) & 4095u];   // masked: lanes without a key carry ~0
-    u32 q = (u32)(k >> 36), lo = 0, hi = g.nb;
+    u32 q = (u32)(k >> g.tshift), lo = 0, hi = g.nb;
     while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (g.bounds[mid] <= q) lo = mid; else hi = mid; }
     return lo;
 }
@@ -55,6 +55,7 @@ __device__ __forceinline__ bool rs_load_key(const u64 *__restrict__ in, const Te
         u32 pred = idx ? text_symbol(ts.text, idx - 1) : 3u;              // 'T' stands at separators
         u64 k = (node << 2) | pred;
         if (k < ts.key_lo || (ts.key_hi && k >= ts.key_hi)) return false;  // not this shard's prefix range
+        if (ts.bin_tab && ts.bin_tab[(k >> ts.bin_shift) & 4095u] == 0xFFu) return false;
         *key = k;
         return true;
     }
@@ -110,6 +111,7 @@ __device__ __forceinline__ u32 rs_staged_keys(const TextKeySrc &ts, const TextSt
         const u64 win = (A << (2 * j)) | (B >> (64 - 2 * j));
         const u64 k = ((win >> nsh) << 2) | ((A >> (64 - 2 * j)) & 3ull);
         if (k < ts.key_lo || (ts.key_hi && k >= ts.key_hi)) continue;   // not this shard's prefix range
+        if (ts.bin_tab && ts.bin_tab[(k >> ts.bin_shift) & 4095u] == 0xFFu) continue;   // not this exchange round's
         key[r] = k;
         vmask |= 1u << r;
     }
@@ -457,11 +459,11 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
 // phases are latency-bound with two workgroups per CU.  So the keys of consecutive position tiles are collected (in the
 // upper half of skeys, which the peer masks do not use) until the next tile would not fit, and ranked and flushed
 // together; a position tile that alone holds more than half a tile of keys is ranked as it is.
-template <int HI>
+template <int HI, int AUX = 0>
 __global__ __launch_bounds__(SC_NT) __attribute__((amdgpu_waves_per_eu(RS_WAVES_EU, RS_WAVES_EU)))
 void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 chunk, RsDigit dg,
                               const u32 *__restrict__ offsets, const u32 *__restrict__ digit_base, u32 nchunks) {
-    constexpr int DG = HI ? 2 : 1;
+    constexpr int DG = AUX ? 0 : (HI ? 2 : 1);
     constexpr u32 CAP = RS_TILE / 2;
     __shared__ ScShared sh;
     __shared__ u64 stext[RS_STEXT], ssep[RS_SSEP];
@@ -1264,7 +1266,7 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
 // One bucketing pass by destination shard: `count` source items (text positions [text->pos0, +count) when `text`
 // is given, else the keys in `src`) -> `dst` grouped by shard; offs_host[0..nshards] receives the group offsets.
 hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const TextKeySrc *text, u64 count, u64 *dst,
-                                    const RsDigit &dg, u32 nshards, const RadixWorkspace &ws, u64 *offs_host) {
+                                    const RsDigit &dg, u32 nshards, const RadixWorkspace &ws, u64 *offs_host, bool sparse) {
     TextKeySrc none{};
     u32 nchunks; u64 chunk;
     rs_plan(count, &nchunks, &chunk);
@@ -1277,7 +1279,8 @@ hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const Te
     }
     rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
     rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
-    if (text) rs_scatter_kernel<1, 1, 0><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    if (text && sparse) rs_scatter_sparse_kernel<0, 1><<<nchunks, SC_NT, 0, stream>>>(*text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    else if (text) rs_scatter_kernel<1, 1, 0><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
     else rs_scatter_kernel<0, 1, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
     u32 tot[RS_RADIX];
     hipError_t e = hipMemcpyAsync(tot, digit_tot, sizeof tot, hipMemcpyDeviceToHost, stream);

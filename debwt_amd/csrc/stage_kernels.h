@@ -676,23 +676,11 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const ulonglong2 *__r
     }
 }
 
-// sharded build: a multi-in position of this shard's text slice -> (global block id << 36 | spIndex << 3 | pred),
-// to be sent to the shard that owns the block (28 + 33 + 3 bits: Q < 2^28 blocks, S < 2^33 SP symbols, checked by
-// the host); and the owner's placement of the entries it received
-__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route(const ulonglong2 *__restrict__ mi_list, u64 B,
-                                                             const HSlot *__restrict__ htab, int hbits,
-                                                             u64 *__restrict__ out) {
-    u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    ulonglong2 it = mi_list[b];
-    u32 fl;
-    u32 h = red_lookup(htab, hbits, it.x, &fl);
-    u64 q = h == 0xFFFFFFFFu ? 0xFFFFFFFull : (u64)htab[h].q;
-    out[b] = (q << 36) | ((it.y >> 4) << 3) | (it.y & 7ull);
-}
 // Atomic-free blue fill: a multi-in position -> (block id << qshift | spIndex << 3 | pred); sorting these words by
 // their block bits puts every entry into its block (the blocks' blue slots are the exclusive scan of their sizes in
-// block order), k_blue_strip turns them into blue entries (pred | spIndex << 4).
+// block order), k_blue_strip turns them into blue entries (pred | spIndex << 4).  A sharded build routes the same
+// words (global block ids) to the shard that owns the block, where k_blue_place puts them into the block through a
+// cursor per owned block.
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route_q(const ulonglong2 *__restrict__ mi_list, u64 B,
                                                                const HSlot *__restrict__ htab, int hbits, int qshift,
                                                                u64 *__restrict__ out) {
@@ -711,16 +699,16 @@ __global__ void k_blue_strip(const u64 *__restrict__ src, u64 *__restrict__ dst,
     dst[i] = (e & 7ull) | (((e & ((1ull << qshift) - 1ull)) >> 3) << 4);
 }
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_place(const u64 *__restrict__ ent, u64 count, u32 qbase,
-                                                             u32 Qlocal, u32 *__restrict__ qcursor,
+                                                             u32 Qlocal, int qshift, u32 *__restrict__ qcursor,
                                                              const u64 *__restrict__ blk_start,
                                                              u64 *__restrict__ blue) {
     u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= count) return;
     u64 e = ent[b];
-    u32 q = (u32)(e >> 36) - qbase;
+    u32 q = (u32)(e >> qshift) - qbase;
     if (q >= Qlocal) return;                                                // misrouted entry: never index outside
     u32 slot = atomicAdd(&qcursor[q], 1u);
-    blue[blk_start[q] + slot] = (e & 7ull) | (((e >> 3) & 0x1FFFFFFFFull) << 4);   // pred | spIndex << 4
+    blue[blk_start[q] + slot] = (e & 7ull) | (((e & ((1ull << qshift) - 1ull)) >> 3) << 4);   // pred | spIndex << 4
 }
 
 // SP symbols -> 3 bits per symbol in one MSB-first bit stream (symbol s at stream bits [3s, 3s+3)); a window
@@ -1339,6 +1327,33 @@ struct HashRowsF {
         while (m) { u32 t = __ffs(m) - 1; m &= m - 1; hash_rows[off++] = (w << 5) + t; }
     }
 };
+
+// final concatenation of a sharded build: output word w = rows [32w, 32w + 32), taken from the parts that cover them
+struct ConcatPart { u64 word_off, row_base, rows; };
+__global__ void k_concat_rows(const u64 *__restrict__ parts, const ConcatPart *__restrict__ pp, u32 nparts, u64 n,
+                              u64 *__restrict__ out) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= ((n + 31) >> 5)) return;
+    u64 R = w << 5;
+    const u64 Rend = R + 32 < n ? R + 32 : n;
+    u32 lo = 0, hi = nparts;                                  // last part that starts at or before row R
+    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (pp[mid].row_base <= R) lo = mid; else hi = mid; }
+    u64 word = 0;
+    for (u32 p = lo; p < nparts && R < Rend; p++) {
+        const ConcatPart P = pp[p];
+        const u64 pe = P.row_base + P.rows;
+        if (pe <= R) continue;
+        const u64 l = R - P.row_base;                         // first local row wanted
+        const u32 cnt = (u32)((pe < Rend ? pe : Rend) - R), sh = (u32)(l & 31) << 1;
+        const u64 *pw = parts + P.word_off + (l >> 5);
+        u64 v = pw[0] << sh;
+        if (sh) v |= pw[1] >> (64 - sh);                      // 32 rows from local row l on, first on top
+        if (cnt < 32) v &= ~(~0ull >> (2 * cnt));
+        word |= v >> (2 * (u32)(R & 31));
+        R += cnt;
+    }
+    out[w] = word;
+}
 
 // symbol census of the packed BWT (rows [0, n): codes 0..3, '#'/'$' rows count as 3): out4[c] += rows with code c
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_bwt_census(const u64 *__restrict__ bwt, u64 n, u64 *__restrict__ out4) {

@@ -1,9 +1,11 @@
 """Host-side orchestration of the multi-GPU runs: one process per GPU, torch.distributed for rendezvous and
 the two small reductions of the timing protocol (backend "nccl" = RCCL on the GPU box, "gloo" in CPU tests).
 
-Round-1 partitioning: the collections are independent objects, rank r builds the BWT of
-collection r with no data-path collective ("weak" scaling).  The sharded single-BWT variant (prefix ranges of
-one key space) plugs in here later; nothing in this module touches device memory.
+This module holds the launch and timing protocol only (rendezvous, barrier-bracketed max-over-ranks timing, the
+whole-job sum); the data path of a multi-GPU build -- ONE collection as k-mer-prefix shards with the key and
+blue-entry all_to_all exchanges -- is debwt_amd/sharded.py.  `collection_seed` / `assign_collections`
+serve the alternative of independent collections per GPU (bench.py --mode replicas).  Nothing here touches device
+memory.
 """
 import os
 import time
@@ -15,10 +17,10 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend=None, device_id=None):
-    """Join the process group when WORLD_SIZE > 1.  Returns (rank, local_rank, world)."""
+def init(backend=None, device_id=None, force=False):
+    """Join the process group when WORLD_SIZE > 1 (force: also a group of one).  Returns (rank, local_rank, world)."""
     rank, local_rank, world = env_world()
-    if world > 1:
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

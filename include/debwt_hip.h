@@ -155,17 +155,45 @@ void debwt_pinned_free(void *p);
 /* ---- one build over several GPUs: k-mer-prefix shards ----------------------------------
  * The reference has no distributed path; these entry points extend the stage sequence above for the case
  * that one text is built by `world` contexts (one per GPU, each holding the whole 2-bit text).  Shard r sorts
- * and classifies the keys of one prefix range, owns the BWT rows and the multi-in blocks of those nodes.
- * Order per shard:  load -> shard_begin -> shard_histogram -> [all-reduce] -> shard_set_range ->
- * kmer_sort_rle -> shard_classify_local -> shard_facts_export -> [all-gather of the fact lists] ->
- * shard_classify_global -> sp_generate -> blue_sort -> bwt_assemble -> shard_fetch -> [concatenate by row].
- * The collectives (bracketed) are the caller's (debwt_amd/sharded.py uses torch.distributed: RCCL or gloo). */
-int debwt_shard_begin(debwt_ctx *ctx, int rank, int world);
+ * and classifies the keys of one prefix range -- in several key ranges one after the other when they do not
+ * fit HBM at once -- and owns the BWT rows and the multi-in blocks of those nodes.
+ * The collectives (bracketed) are the caller's (debwt_amd/sharded.py uses torch.distributed: RCCL or gloo).
+ *
+ * Exchange mode (the default; per-GPU work is O(n / world): every shard scans only its 1/world slice of the text):
+ *   load -> shard_begin -> shard_histogram -> [all-gather of the slice censuses] -> shard_plan -> shard_ranges ->
+ *   [all-gather of the range cuts] -> shard_sort_begin ->
+ *   per exchange round t:  shard_partition_keys (keys of the slice that fall into round t's ranges, grouped by owner)
+ *                          -> [alltoallv of 8-byte keys: the k-mer bucket exchange] -> shard_sort_range(t) ->
+ *   shard_sort_end -> shard_classify_local -> shard_facts_export -> [all-gather of the fact lists] ->
+ *   shard_classify_global -> shard_sp_flags -> [all-gather of the slice SP lengths] -> shard_sp_emit ->
+ *   [all-gather of the slice SP symbols] -> shard_sp_import -> shard_blue_route -> [alltoallv of 8-byte blue entries]
+ *   -> shard_blue_place -> blue_sort -> bwt_assemble -> shard_info -> [gather of the packed row ranges] -> concat_rows.
+ * Scan mode (no bulk exchange; every shard reads the whole text and keeps the keys of its ranges):
+ *   ... shard_plan(exchange = 0) or shard_set_range -> kmer_sort_rle -> shard_classify_local -> ... ->
+ *   shard_classify_global -> sp_generate -> blue_sort -> bwt_assemble. */
+int debwt_shard_begin(debwt_ctx *ctx, int rank, int world);           /* world <= 255 */
 /* counts of this shard's slice of text positions by the top 12 bits of their key: 4096 words (host) */
 int debwt_shard_histogram(debwt_ctx *ctx, uint64_t *hist4096);
-/* this shard takes the keys whose top 12 bits lie in [bin_lo, bin_hi): m_keys of them (from the all-reduced
- * histogram), m_base keys in the shards before it */
+/* this shard takes the keys whose top 12 bits lie in [bin_lo, bin_hi) as ONE key range: m_keys of them (from the
+ * summed histogram), m_base keys in the shards before it */
 int debwt_shard_set_range(debwt_ctx *ctx, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_keys, uint64_t m_base);
+/* the same from the summed census hist4096 (host), cut into as many key ranges as the free HBM (or debwt_set_range_cap)
+ * asks for: the reference's segCount balancing (src/mySort.c:104-110) applied twice, over GPUs and over rounds.
+ * exchange != 0: the keys of every range will arrive through debwt_shard_sort_range. */
+int debwt_shard_plan(debwt_ctx *ctx, const uint64_t *hist4096, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_base,
+                     int exchange, uint32_t *nranges);
+/* the cuts of debwt_shard_plan: range i = bins [bin_bounds[i], bin_bounds[i+1]) with m_keys[i] keys */
+int debwt_shard_ranges(debwt_ctx *ctx, uint32_t *bin_bounds, uint64_t *m_keys, uint32_t capacity);
+/* exchange mode: shard_of_bin: 4096 bytes (host), owner of each 12-bit prefix bin in this round, 0xFF = the bin is
+ * not exchanged in this round; d_out: DEVICE buffer of `capacity` words; offs: world+1 host words,
+ * group i = d_out[offs[i] .. offs[i+1]). */
+int debwt_shard_partition_keys(debwt_ctx *ctx, const uint8_t *shard_of_bin, uint64_t *d_out, uint64_t capacity,
+                               uint64_t *offs);
+int debwt_shard_sort_begin(debwt_ctx *ctx);
+/* d_keys: the `count` keys of range `range` in a DEVICE buffer the caller owns; it is used as sort workspace and must
+ * stay untouched until the next shard_sort_range / shard_sort_end */
+int debwt_shard_sort_range(debwt_ctx *ctx, uint32_t range, uint64_t *d_keys, uint64_t count);
+int debwt_shard_sort_end(debwt_ctx *ctx);
 int debwt_shard_classify_local(debwt_ctx *ctx, uint64_t *nfacts, uint64_t *nblocks, uint64_t *blue_rows);
 /* copies the shard's nfacts fact words (node<<2 | 1 multi-out, | 2 multi-in) to a DEVICE buffer */
 int debwt_shard_facts_export(debwt_ctx *ctx, uint64_t *d_dst, uint64_t capacity);
@@ -173,16 +201,6 @@ int debwt_shard_facts_export(debwt_ctx *ctx, uint64_t *d_dst, uint64_t capacity)
  * this one; blue_total: sum of blue_rows over all shards */
 int debwt_shard_classify_global(debwt_ctx *ctx, const uint64_t *d_facts, uint64_t nfacts, uint64_t qbase,
                                 uint64_t blue_total);
-/* Exchange mode (scales with the GPU count: every shard scans only its 1/world slice of the text):
- *   shard_partition_keys -> [alltoallv of 8-byte keys, the k-mer bucket exchange] -> shard_import_keys ->
- *   kmer_sort_rle -> classify_local/_global as above -> shard_sp_flags -> [all-gather of the slice SP lengths]
- *   -> shard_sp_emit -> [all-gather of the slice SP symbols] -> shard_sp_import -> shard_blue_route ->
- *   [alltoallv of 8-byte blue entries] -> shard_blue_place -> blue_sort -> bwt_assemble.
- * shard_of_bin: 4096 bytes (host), shard owning each 12-bit prefix bin; d_out: DEVICE buffer of `capacity`
- * words; offs: world+1 host words, group i = d_out[offs[i] .. offs[i+1]). */
-int debwt_shard_partition_keys(debwt_ctx *ctx, const uint8_t *shard_of_bin, uint64_t *d_out, uint64_t capacity,
-                               uint64_t *offs);
-int debwt_shard_import_keys(debwt_ctx *ctx, const uint64_t *d_keys, uint64_t count);
 int debwt_shard_sp_flags(debwt_ctx *ctx, uint64_t *sp_symbols, uint64_t *mi_positions);
 int debwt_shard_sp_emit(debwt_ctx *ctx, uint64_t sp_offset, uint8_t *d_dst, uint64_t capacity);
 int debwt_shard_sp_import(debwt_ctx *ctx, const uint8_t *d_src, uint64_t sp_total);
@@ -190,12 +208,22 @@ int debwt_shard_sp_import(debwt_ctx *ctx, const uint8_t *d_src, uint64_t sp_tota
 int debwt_shard_blue_route(debwt_ctx *ctx, const uint32_t *first_block_of_shard, uint64_t *d_out, uint64_t capacity,
                            uint64_t *offs);
 int debwt_shard_blue_place(debwt_ctx *ctx, const uint64_t *d_entries, uint64_t count);
+/* Final concat on one GPU: d_parts holds the shards' packed row ranges (part i from word part_word_off[i], one spare
+ * word behind each, rows [row_base[i], row_base[i] + rows[i])); the ranges are not 32-row aligned and are
+ * shift-merged into d_out (ceil(n/32) DEVICE words), as src/generateSP.c:379-405 joins SP segments. */
+int debwt_concat_rows(debwt_ctx *ctx, const uint64_t *d_parts, uint32_t nparts, const uint64_t *part_word_off,
+                      const uint64_t *row_base, const uint64_t *rows, uint64_t n, uint64_t *d_out);
 
 /* first global row of the shard, its row count, and (after assemble) its number of '#' rows */
 int debwt_shard_info(debwt_ctx *ctx, uint64_t *row_base, uint64_t *rows, uint64_t *hash_rows);
-/* shard result to host: ceil(rows/32) words packed from the shard's first row; GLOBAL '#' rows; the GLOBAL '$'
- * row or ~0 when it is not in this shard */
+/* shard result to host: ceil(rows/32) words packed from the shard's first row (words may be NULL: row lists only);
+ * GLOBAL '#' rows; the GLOBAL '$' row or ~0 when it is not in this shard */
 int debwt_shard_fetch(debwt_ctx *ctx, uint64_t *words, uint64_t *hash_rows, uint64_t *dollar_row);
+
+/* the shard's packed rows into a DEVICE buffer of `capacity` words (zero-filled behind the last row) */
+int debwt_shard_export(debwt_ctx *ctx, uint64_t *d_words, uint64_t capacity);
+/* debwt_bwt_census over any packed rows in HBM (n rows at d_words) */
+int debwt_census_words(debwt_ctx *ctx, const uint64_t *d_words, uint64_t n, uint64_t counts[4]);
 
 /* ---- intermediates, for stage-by-stage parity ---------------------------------- */
 typedef enum {

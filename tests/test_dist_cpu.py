@@ -60,3 +60,85 @@ def test_single_process_defaults():
     dt = D.timed_steps(lambda: calls.append(1), steps=3, warmup=2)
     assert len(calls) == 5 and dt >= 0
     assert D.sum_over_ranks(7) == 7.0
+
+
+# ---- the host logic of the sharded build (debwt_amd/sharded.py) over gloo on CPU tensors: round planning from the
+# slice censuses, the variable all_to_all of the key rounds and the variable all_gather of facts / SP symbols.  The
+# "keys" are plain integers whose top 12 bits are their prefix bin; the device work is not part of this test.
+SHARD_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch
+    import torch.distributed as dist
+    from debwt_amd import dist as D, sharded as SH
+    rank, local_rank, world = D.init(backend="gloo")
+    rng = np.random.default_rng(100 + rank)
+    keys = rng.integers(0, 1 << 20, size=5000 + 700 * rank, dtype=np.int64)        # my slice; bin = key >> 8
+    keys[:300] = (77 << 8) | (keys[:300] & 255)                                    # a heavy bin
+    hist = np.bincount(keys >> 8, minlength=4096).astype(np.int64)
+    hists = SH._all_gather_small(hist)
+    assert hists.shape == (world, 4096) and (hists[rank] == hist).all()
+    total = hists.sum(axis=0)
+    bins, cum = SH.plan_splitters(total, world)
+    # every shard cuts its bins into key ranges of at most `cap` keys (the job of debwt_shard_plan)
+    cap = int(total.sum()) // (world * 3) + 1
+    def cut(lo, hi):
+        b, acc, out = lo, 0, [lo]
+        for x in range(lo, hi):
+            if acc and acc + total[x] > cap:
+                out.append(x); acc = 0
+            acc += int(total[x])
+        return out + [hi]
+    cuts = [np.array(cut(bins[s], bins[s + 1])) for s in range(world)]
+    rounds = max(len(c) - 1 for c in cuts)
+    ws = SH.Workspace(type("Ctx", (), {"n": 0})(), torch.device("cpu"))
+    got_all = []
+    for t in range(rounds):
+        tab, send, recv = SH.plan_round(hists, cuts, t, rank)
+        dest = tab[keys >> 8]
+        order = np.argsort(dest, kind="stable")
+        part = keys[order][: int((dest != 0xFF).sum())]                             # grouped by owner, 0xFF last
+        assert [int((dest == s).sum()) for s in range(world)] == send
+        xa = torch.from_numpy(part.copy())
+        xb = torch.empty(max(sum(recv), 1), dtype=torch.int64)
+        n = SH._all_to_all(xb, xa, recv, send)
+        got = xb[:n].numpy()
+        if t + 1 < len(cuts[rank]):
+            lo, hi = cuts[rank][t], cuts[rank][t + 1]
+            assert n == int(total[lo:hi].sum()) and ((got >> 8) >= lo).all() and ((got >> 8) < hi).all()
+        else:
+            assert n == 0
+        got_all.append(got.copy())
+    mine = np.concatenate(got_all) if got_all else np.zeros(0, np.int64)
+    assert len(mine) == int(total[bins[rank]:bins[rank + 1]].sum())
+    # variable all_gather (facts, SP symbols)
+    part = torch.arange(10 + 5 * rank, dtype=torch.int64) + 1000 * rank
+    counts = [int(x) for x in SH._all_gather_small([part.numel()])[:, 0]]
+    cat, tot = SH._all_gather_var(ws, "t", part, part.numel(), counts)
+    want = np.concatenate([np.arange(10 + 5 * r) + 1000 * r for r in range(world)])
+    assert tot == len(want) and (cat[:tot].numpy() == want).all()
+    sp = torch.full((7 * (rank + 1),), rank, dtype=torch.uint8)
+    counts = [int(x) for x in SH._all_gather_small([sp.numel()])[:, 0]]
+    cat, tot = SH._all_gather_var(ws, "sp", sp, sp.numel(), counts)
+    assert tot == sum(counts) and (cat[:tot].numpy() == np.concatenate([np.full(7 * (r + 1), r) for r in range(world)])).all()
+    open(os.path.join(sys.argv[1], f"shard{rank}.json"), "w").write(json.dumps(
+        {"rank": rank, "rounds": rounds, "keys": int(len(mine)), "sum": int(mine.sum()), "sent": int(len(keys)), "sent_sum": int(keys.sum())}))
+    D.finalize()
+""") % ROOT
+
+
+def test_sharded_host_logic_over_gloo(tmp_path):
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER)
+    for world, port, p2p_max in ((2, "29535", None), (3, "29536", "4096")):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        if p2p_max:
+            env["DEBWT_P2P_MAX_BYTES"] = p2p_max           # every collective cut into many calls (RCCL's 1 GiB limit)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(tmp_path)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res = [json.load(open(tmp_path / f"shard{i}.json")) for i in range(world)]
+        assert res[0]["rounds"] >= 3                                               # several exchange rounds
+        assert sum(x["keys"] for x in res) == sum(x["sent"] for x in res)           # every key reached exactly one owner
+        assert sum(x["sum"] for x in res) == sum(x["sent_sum"] for x in res)

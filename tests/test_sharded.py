@@ -53,7 +53,7 @@ WORKER = textwrap.dedent("""
     from debwt_amd import dist as D
     rank, local_rank, world = D.init(backend="gloo")
     torch.cuda.set_device(0)                              # every rank on the one GPU of the test box
-    case, k, out, mode = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    case, k, out, mode, cap = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
     if case == "pan":
         recs = synth.pan_genome(300_000, 3)
     elif case == "many":
@@ -63,9 +63,12 @@ WORKER = textwrap.dedent("""
     n = sum(len(r) for r in recs) + len(recs)
     d = api.DeBWT(k=k, device=0)
     d.load_records(recs)
+    if cap:
+        d.set_range_cap(cap)                              # several key ranges (exchange rounds) per shard
+    ws = sharded.Workspace(d, torch.device("cuda", 0), mode=mode)
     for it in range(2):                                   # a context is reusable in sharded mode too
-        base, rows, nh = sharded.build_sharded(d, mode=mode)
-    res = sharded.gather_bwt(d, n)
+        info = sharded.build_sharded(d, ws)
+    res = sharded.gather_bwt(d, n, ws)
     if rank == 0:
         w, h, dr = res
         np.savez(out, w=w, h=h, d=np.array([dr], dtype=np.uint64))
@@ -76,16 +79,19 @@ WORKER = textwrap.dedent("""
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["scan", "exchange"])
-@pytest.mark.parametrize("world,case,k", [(2, "pan", 32), (3, "pan", 20), (2, "many", 32), (4, "chrom", 32)])
-def test_sharded_build_equals_oracle(tmp_path, oracle, world, case, k, mode):
+@pytest.mark.parametrize("world,case,k,cap", [(2, "pan", 32, 0), (3, "pan", 20, 0), (2, "many", 32, 0), (4, "chrom", 32, 0),
+                                              (2, "pan", 32, 100_000), (3, "chrom", 24, 150_000), (4, "many", 32, 8192)])
+def test_sharded_build_equals_oracle(tmp_path, oracle, world, case, k, mode, cap):
     from debwt_amd import synth
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / "res.npz")
-    port = str(29540 + world + (10 if mode == "exchange" else 0))
+    port = str(29540 + world + (10 if mode == "exchange" else 0) + (20 if cap else 0))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    if cap:
+        env["DEBWT_P2P_MAX_BYTES"] = "65536"               # collectives in many calls, as above RCCL's 1 GiB message limit
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", port, str(script), case, str(k), out, mode]
+           "--master-addr", "127.0.0.1", "--master-port", port, str(script), case, str(k), out, mode, str(cap)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     recs = {"pan": lambda: synth.pan_genome(300_000, 3), "many": lambda: synth.pan_genome(20_000, 9, seed=5),
