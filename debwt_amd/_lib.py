@@ -119,7 +119,8 @@ def lib():
     L.debwt_shard_partition_keys.restype = ctypes.c_int
     L.debwt_shard_partition_keys.argtypes = [vp, u8p, vp, ctypes.c_uint64, u64p]
     L.debwt_shard_plan.restype = ctypes.c_int
-    L.debwt_shard_plan.argtypes = [vp, u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, u32p]
+    L.debwt_shard_plan.argtypes = [vp, u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int,
+                                   ctypes.c_uint64, u32p]
     L.debwt_shard_ranges.restype = ctypes.c_int
     L.debwt_shard_ranges.argtypes = [vp, u32p, u64p, ctypes.c_uint32]
     L.debwt_shard_sort_begin.restype = ctypes.c_int

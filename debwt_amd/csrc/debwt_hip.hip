@@ -224,6 +224,18 @@ int sort_keys(debwt_ctx *c, u64 *a, u64 *b, u64 count, int key_bits, u64 **resul
 
 // ---------------------------------------------------------------------------------------------------
 
+// every device buffer of a context (all grow on demand and are reused by the next build)
+static std::vector<DevBuf *> all_buffers(debwt_ctx *c) {
+    return {&c->text, &c->sepbits, &c->sep, &c->keysA, &c->keysB, &c->rs_counts, &c->cp_counts, &c->dk,
+            &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q,
+            &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
+            &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
+            &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew,
+            &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
+            &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0,
+            &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf};
+}
+
 extern "C" const char *debwt_strerror(int code) {
     switch (code) {
         case DEBWT_OK: return "ok";
@@ -271,13 +283,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
     if (c->special_running) { c->special_thread.join(); c->special_running = false; }
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->text, &c->sepbits, &c->sep, &c->keysA, &c->keysB, &c->rs_counts, &c->cp_counts, &c->dk,
-                     &c->dstart, &c->mchar, &c->head_keys, &c->facts, &c->facts_tmp, &c->red, &c->red_q,
-                     &c->mi_j0, &c->mi_freq, &c->bstart, &c->cursor, &c->blue, &c->spkey, &c->sprow, &c->spchr,
-                     &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
-                     &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew, &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
-                     &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0, &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf};
-    for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : all_buffers(c)) if (b->p) (void)hipFree(b->p);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_over) (void)hipHostFree(c->h_over);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -403,12 +409,12 @@ extern "C" int debwt_load_ascii(debwt_ctx *c, const char *seq, const uint64_t *r
 // Largest number of node instances one key range may hold: what the free HBM allows at `per_key` bytes of range
 // workspace (key buffers, distinct keys, first instances, classification bytes; in exchange mode also the caller's
 // send buffer) next to `later` bytes the later stages hold, and always below 2^32 (per-range indices are 32-bit).
-static int default_range_cap(debwt_ctx *c, u64 per_key, u64 later, u64 *cap) {
+static int default_range_cap(debwt_ctx *c, u64 per_key, u64 later, u64 caller_held, u64 *cap) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-    const u64 held = c->keysA.cap + c->keysB.cap + c->dk.cap + c->dstart.cap + c->pflag.cap + c->mchar.cap +
-                     c->spsym.cap + c->momask.cap + c->mimask.cap + c->blue.cap + c->mi_list.cap;   // reused by this build
-    const u64 avail = free_b + held;
+    u64 held = caller_held;                                  // what this build reuses: the context's own buffers and the
+    for (DevBuf *b : all_buffers(c)) held += b->cap;         // caller's exchange buffers -- the plan of a repeated build
+    const u64 avail = (free_b + held) / 100 * 94;            // equals the first; 6 %: allocator granularity, RCCL, runtime
     u64 rc = avail > later + (per_key << 28) ? (avail - later) / per_key : (1ull << 28);
     *cap = std::min<u64>(rc, 0xFFFFFFF0ull - (1ull << 20));
     return DEBWT_OK;
@@ -458,7 +464,7 @@ static int plan_ranges(debwt_ctx *c) {
     if (!range_cap) {
         // ~30 bytes per key of range workspace next to what the later stages hold for the whole text
         // (~4 bytes per position: row symbols, SP code, flag masks, blue entries, BWT)
-        int rc = default_range_cap(c, 30, 4 * c->n + (8ull << 30), &range_cap);
+        int rc = default_range_cap(c, 30, 4 * c->n + (8ull << 30), 0, &range_cap);
         if (rc) return rc;
         if (range_cap >= c->Mfull && c->Mfull < 0xFFFFFFF0ull) range_cap = c->Mfull;
     }
@@ -1256,7 +1262,7 @@ extern "C" int debwt_shard_set_range(debwt_ctx *c, uint32_t bin_lo, uint32_t bin
 }
 
 extern "C" int debwt_shard_plan(debwt_ctx *c, const uint64_t *hist4096, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_base,
-                                int exchange, uint32_t *nranges) {
+                                int exchange, uint64_t caller_held_bytes, uint32_t *nranges) {
     if (!c || !hist4096 || !nranges || bin_lo > bin_hi || bin_hi > SHARD_BINS) return DEBWT_EINVAL;
     if (c->stage < ST_LOADED) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -1270,9 +1276,11 @@ extern "C" int debwt_shard_plan(debwt_ctx *c, const uint64_t *hist4096, uint32_t
     u64 cap = c->range_cap;
     if (!cap) {
         // range workspace per key: 30 bytes, plus the caller's send buffer in exchange mode (the receive buffer is
-        // key buffer A); the later stages hold ~4 bytes per position of the shard's share and n/2 for the whole text
-        // (2-bit text, flag masks)
-        int rc = default_range_cap(c, exchange ? 40 : 30, 4 * (c->n / (u64)c->shard_world) + c->n / 2 + (8ull << 30), &cap);
+        // key buffer A); the later stages hold ~3.5 bytes per position of the shard's share (row symbols, blue
+        // entries and their routed form, BWT) and ~1.25 bytes per position of the whole text (2-bit text, flag
+        // masks, SP code and its gather buffers, node table, the concatenated BWT on the gathering rank)
+        int rc = default_range_cap(c, exchange ? 40 : 30,
+                                   c->n / (u64)c->shard_world / 2 * 7 + c->n / 4 * 5 + (8ull << 30), caller_held_bytes, &cap);
         if (rc) return rc;
     }
     int rc = cut_ranges(c, reinterpret_cast<const u64 *>(hist4096), bin_lo, bin_hi, cap, m);

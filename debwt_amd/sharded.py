@@ -194,6 +194,9 @@ class Workspace:
         self.built = False          # build_sharded ran (on every rank: the final concat is a collective)
         self.n = d.n
 
+    def held_bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.buf.values())
+
     def get(self, name, numel, dtype):
         t = self.buf.get(name)
         if t is None or t.numel() < numel or t.dtype != dtype:
@@ -258,7 +261,7 @@ def build_sharded(d, ws=None, mode=None, device=None):
     bins, cum = plan_splitters(total, world)
     nr = ctypes.c_uint32()
     _chk(d, L.debwt_shard_plan(d._h, np.ascontiguousarray(total).ctypes.data_as(u64p), bins[rank], bins[rank + 1],
-                               int(cum[bins[rank]]), 1 if exchange else 0, ctypes.byref(nr)))
+                               int(cum[bins[rank]]), 1 if exchange else 0, ws.held_bytes(), ctypes.byref(nr)))
     bounds = np.zeros(MAX_RANGES + 1, dtype=np.uint32)
     mkeys = np.zeros(MAX_RANGES, dtype=np.uint64)
     _chk(d, L.debwt_shard_ranges(d._h, bounds.ctypes.data_as(u32p), mkeys.ctypes.data_as(u64p), MAX_RANGES))
@@ -368,7 +371,9 @@ def _concat_on_rank0(d, ws, dst=0):
     rb, rows, nh = _shard_rows(d)
     allr = _all_gather_small([rb, rows, nh])
     maxw = int(max((int(r) + 31) // 32 for r in allr[:, 1])) + 1               # one spare word behind every part
-    mine = ws.get("part", maxw, torch.int64)
+    # after the exchanges the key buffers are free: the shard's rows leave from xb, the parts arrive in xa
+    xa, xb = ws.buf.get("xa"), ws.buf.get("xb")
+    mine = xb if xb is not None and xb.numel() >= maxw else ws.get("part", maxw, torch.int64)
     _chk(d, L.debwt_shard_export(d._h, ctypes.c_void_p(mine.data_ptr()), maxw))
     torch.cuda.synchronize(ws.device)
     # '#' rows and the '$' row: short lists, global row numbers
@@ -379,7 +384,8 @@ def _concat_on_rank0(d, ws, dst=0):
     lists = _all_gather_small([int(dr[0]) if dr[0] != 0xFFFFFFFFFFFFFFFF else -1] + hr[:nh].astype(np.int64).tolist()
                               + [0] * (maxh - 1 - nh))
     # gather of the packed row ranges as an all_to_all whose only receiver is `dst` (RCCL's gather is send/recv too)
-    parts = ws.get("parts", maxw * world if rank == dst else 1, torch.int64)
+    need = maxw * world if rank == dst else 1
+    parts = xa if xa is not None and xa.numel() >= need else ws.get("parts", need, torch.int64)
     send = [maxw if i == dst else 0 for i in range(world)]
     recv = [maxw] * world if rank == dst else [0] * world
     _all_to_all(parts, mine, recv, send)

@@ -179,9 +179,10 @@ int debwt_shard_histogram(debwt_ctx *ctx, uint64_t *hist4096);
 int debwt_shard_set_range(debwt_ctx *ctx, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_keys, uint64_t m_base);
 /* the same from the summed census hist4096 (host), cut into as many key ranges as the free HBM (or debwt_set_range_cap)
  * asks for: the reference's segCount balancing (src/mySort.c:104-110) applied twice, over GPUs and over rounds.
- * exchange != 0: the keys of every range will arrive through debwt_shard_sort_range. */
+ * exchange != 0: the keys of every range will arrive through debwt_shard_sort_range.  caller_held_bytes: device
+ * memory the caller already holds for the exchanges of this build (counted as available: it is reused). */
 int debwt_shard_plan(debwt_ctx *ctx, const uint64_t *hist4096, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_base,
-                     int exchange, uint32_t *nranges);
+                     int exchange, uint64_t caller_held_bytes, uint32_t *nranges);
 /* the cuts of debwt_shard_plan: range i = bins [bin_bounds[i], bin_bounds[i+1]) with m_keys[i] keys */
 int debwt_shard_ranges(debwt_ctx *ctx, uint32_t *bin_bounds, uint64_t *m_keys, uint32_t capacity);
 /* exchange mode: shard_of_bin: 4096 bytes (host), owner of each 12-bit prefix bin in this round, 0xFF = the bin is
