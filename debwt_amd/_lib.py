@@ -34,6 +34,15 @@ class DebwtStats(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class DebwtVerifyReport(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_uint64) for n in ("segments", "steps", "mismatches", "broken_links", "search_failures",
+                                                "search_steps")] +
+                [(n, ctypes.c_float) for n in ("ms_index", "ms_search", "ms_walk")] + [("ok", ctypes.c_int)])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 # every symbol include/debwt_hip.h declares
 SYMBOLS = [
     "debwt_create", "debwt_destroy", "debwt_strerror", "debwt_last_error", "debwt_load_text",
@@ -44,7 +53,7 @@ SYMBOLS = [
     "debwt_shard_facts_export", "debwt_shard_classify_global", "debwt_shard_info", "debwt_shard_fetch",
     "debwt_shard_partition_keys", "debwt_shard_plan", "debwt_shard_ranges", "debwt_shard_sort_begin",
     "debwt_shard_sort_range", "debwt_shard_sort_end", "debwt_concat_rows", "debwt_shard_export", "debwt_census_words", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
-    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_pinned_alloc", "debwt_pinned_free",
+    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_verify_device", "debwt_pinned_alloc", "debwt_pinned_free",
 ]
 
 
@@ -163,6 +172,8 @@ def lib():
     L.debwt_load_fasta_opts.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64]
     L.debwt_special_digest.restype = ctypes.c_int
     L.debwt_special_digest.argtypes = [u64p, ctypes.c_uint64, u64p, ctypes.c_uint64, ctypes.c_int, u64p]
+    L.debwt_verify_device.restype = ctypes.c_int
+    L.debwt_verify_device.argtypes = [vp, vp, u64p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(DebwtVerifyReport)]
     L.debwt_fetch_rows.restype = ctypes.c_int
     L.debwt_fetch_rows.argtypes = [vp, u64p, u64p]
     L.debwt_bwt_census.restype = ctypes.c_int

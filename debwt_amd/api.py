@@ -157,6 +157,20 @@ class DeBWT:
         self._chk(self._L.debwt_bwt_census(self._h, _p64(c)))
         return c
 
+    def verify_device(self, d_words=None, hash_rows=None, dollar_row=0, segments=0):
+        """Inverse BWT on the device against the loaded text (debwt_verify_device).  Default: the context's own result;
+        otherwise d_words = device address of packed rows, hash_rows / dollar_row their row lists."""
+        rep = _lib.DebwtVerifyReport()
+        hp = None
+        if d_words is not None and hash_rows is not None and len(hash_rows):
+            hash_rows = np.ascontiguousarray(hash_rows, dtype=np.uint64)
+            hp = _p64(hash_rows)
+        self._chk(self._L.debwt_verify_device(self._h, ctypes.c_void_p(d_words) if d_words else None, hp, int(dollar_row),
+                                              int(segments), ctypes.byref(rep)))
+        r = rep.as_dict()
+        return {"inverse_bwt_ok": bool(r["ok"]), "inverse_bwt": {k: (round(v, 2) if isinstance(v, float) else v)
+                                                                  for k, v in r.items() if k != "ok"}}
+
     def stats(self):
         st = _lib.DebwtStats()
         self._chk(self._L.debwt_get_stats(self._h, ctypes.byref(st)))

@@ -21,6 +21,7 @@
 #include "special_host.h"
 #include "fasta_host.h"
 #include "stage_kernels.h"
+#include "verify_kernels.h"
 
 namespace {
 
@@ -70,6 +71,7 @@ struct debwt_ctx {
     u64 nfacts_acc = 0;         // facts accumulated over the ranges
     bool local_done = false;    // classify_local already ran per range (multi-range build)
     bool plan_valid = false;    // `ranges` holds the cuts of the loaded text (several ranges)
+    DevBuf vidx, vtmp;          // debwt_verify_device: rank structure (when no free key buffer holds it), small arrays
     DevBuf ls_buf, blk_j0, blk_freq, blk_start, facts_acc, large_tmp, blue_tmp, sub_start, sub_j0, sub_freq, sub_depth, range_hist;
     // k-mer-prefix shard of a multi-GPU build (world == 1: the whole key space)
     int shard_rank = 0, shard_world = 1;
@@ -233,7 +235,7 @@ static std::vector<DevBuf *> all_buffers(debwt_ctx *c) {
             &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew,
             &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
             &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0,
-            &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf};
+            &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf, &c->vidx, &c->vtmp};
 }
 
 extern "C" const char *debwt_strerror(int code) {
@@ -1739,6 +1741,104 @@ extern "C" int debwt_special_digest(const uint64_t *packed, uint64_t n, const ui
     for (uint64_t v : t.head_keys) d[3] = mix(d[3], v);
     for (uint64_t v : t.tail_facts) d[3] = mix(d[3], v);
     for (int i = 0; i < 4; i++) digest[i] = d[i];
+    return DEBWT_OK;
+}
+
+// Inverse BWT on the device (verify_kernels.h): rank structure over the packed rows, backward search for the segment
+// boundaries, one LF walk per segment against the text in HBM.
+extern "C" int debwt_verify_device(debwt_ctx *c, const uint64_t *d_words, const uint64_t *hash_rows, uint64_t dollar_row,
+                                   uint64_t segments, debwt_verify_report *rep) {
+    if (!c || !rep) return DEBWT_EINVAL;
+    memset(rep, 0, sizeof *rep);
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const u64 n = c->n, nrec = c->nrec;
+    std::vector<u64> hr;
+    if (!d_words) {                                           // the context's own result
+        if (c->stage < ST_ASSEMBLED || c->shard_world > 1) return DEBWT_ESTATE;
+        d_words = c->bwt.as<uint64_t>();
+        hr.resize(nrec);
+        if (nrec > 1) HIPCHK(c, hipMemcpy(hr.data(), c->hash_rows.p, (nrec - 1) * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&dollar_row, c->dollar.p, 8, hipMemcpyDeviceToHost));
+        hr.resize(nrec - 1);
+    } else {
+        if (nrec > 1 && !hash_rows) return DEBWT_EINVAL;
+        hr.assign(hash_rows, hash_rows + (nrec - 1));
+    }
+    if (dollar_row >= n) { c->err = "'$' row outside the BWT"; return DEBWT_EINVAL; }
+    for (size_t i = 0; i < hr.size(); i++)
+        if (hr[i] >= n || (i && hr[i] <= hr[i - 1])) { c->err = "'#' rows are not ascending rows of the BWT"; return DEBWT_EINVAL; }
+    std::vector<u64> sr(hr);
+    sr.insert(std::upper_bound(sr.begin(), sr.end(), dollar_row), dollar_row);
+    // rank structure
+    const u64 nlines = n / VB_ROWS + 1, nchunks = (nlines + VB_CHUNK - 1) / VB_CHUNK;
+    const size_t idx_bytes = (size_t)nlines * VB_LINE * 8;
+    u64 *idx;
+    if (c->keysB.cap >= idx_bytes) idx = c->keysB.as<u64>();              // free between builds
+    else if (c->keysA.cap >= idx_bytes) idx = c->keysA.as<u64>();
+    else { ENSURE(c, c->vidx, idx_bytes); idx = c->vidx.as<u64>(); }
+    if (!segments) segments = std::min<u64>(std::max<u64>(n / 16384, 1), 1ull << 20);
+    const u64 gap = std::max<u64>(n / segments, 2);
+    const u64 nbound = n > 2 ? (n - 2) / gap : 0;                          // (j + 1) * gap < n - 1
+    const u32 maxm = (u32)std::min<u64>(std::max<u64>(gap / 2, 1), 1u << 16);
+    // small arrays: [csum 5 x nchunks][totals 8][counters 8][hash nrec][srows nrec + 1][bounds 2 x (nbound + 2)]
+    const size_t small_words = (size_t)nchunks * 5 + 16 + 2 * nrec + 2 + 2 * (nbound + 2) + 8;
+    ENSURE(c, c->vtmp, small_words * 8);
+    u64 *csum = c->vtmp.as<u64>(), *totals = csum + nchunks * 5, *counters = totals + 8, *d_hash = counters + 8,
+        *d_srows = d_hash + nrec, *d_bounds = d_srows + nrec + 1;
+    HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, c->stream));
+    if (!hr.empty()) HIPCHK(c, hipMemcpyAsync(d_hash, hr.data(), hr.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_srows, sr.data(), sr.size() * 8, hipMemcpyHostToDevice, c->stream));
+    hipEvent_t ev[4];
+    for (auto &e : ev) HIPCHK(c, hipEventCreate(&e));
+    auto drop_events = [&]() { for (auto &e : ev) (void)hipEventDestroy(e); };
+    HIPCHK(c, hipEventRecord(ev[0], c->stream));
+    const u64 *bw = reinterpret_cast<const u64 *>(d_words);
+    k_vidx_count<<<(u32)nchunks, VB_CHUNK, 0, c->stream>>>(bw, n, nlines, d_srows, sr.size(), csum);
+    k_vidx_scan<<<1, 1024, 0, c->stream>>>(csum, nchunks, totals);
+    k_vidx_write<<<(u32)nchunks, VB_CHUNK, 0, c->stream>>>(bw, n, nlines, d_srows, sr.size(), csum, idx);
+    u64 tot[5];
+    HIPCHK(c, hipMemcpyAsync(tot, totals, 40, hipMemcpyDeviceToHost, c->stream));
+    int rc = sync_check(c);
+    if (rc) { drop_events(); return rc; }
+    if (tot[4] != nrec || tot[0] + tot[1] + tot[2] + tot[3] != n) { drop_events(); c->err = "rank structure: row census is inconsistent"; return DEBWT_EINTERNAL; }
+    VIndex V{};
+    V.idx = idx; V.hash = d_hash; V.srows = d_srows; V.nhash = hr.size(); V.nsep = sr.size(); V.n = n;
+    V.C[0] = 0; V.C[1] = tot[0]; V.C[2] = tot[0] + tot[1]; V.C[3] = V.C[2] + tot[2];
+    V.C[4] = V.C[3] + (tot[3] - nrec); V.C[5] = n - 1;
+    V.dollar_row = dollar_row;
+    HIPCHK(c, hipEventRecord(ev[1], c->stream));
+    // segment boundaries by backward search
+    std::vector<u64> found(2 * nbound), bounds;
+    if (nbound) {
+        k_vsearch<<<grid_for(nbound, 256), 256, 0, c->stream>>>(V, c->text.as<u64>(), c->sepbits.as<u64>(), nbound, gap, maxm,
+                                                               d_bounds, counters);
+        HIPCHK(c, hipMemcpyAsync(found.data(), d_bounds, nbound * 16, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(ev[2], c->stream));
+    if ((rc = sync_check(c))) { drop_events(); return rc; }
+    bounds.push_back(0); bounds.push_back(dollar_row);
+    u64 last = 0;
+    for (u64 j = 0; j < nbound; j++)
+        if (found[2 * j] != ~0ull && found[2 * j] > last && found[2 * j] < n - 1) {
+            bounds.push_back(found[2 * j]); bounds.push_back(found[2 * j + 1]);
+            last = found[2 * j];
+        }
+    bounds.push_back(n - 1); bounds.push_back(n - 1);                      // the suffix "$" is the last row
+    const u64 nseg = bounds.size() / 2 - 1;
+    HIPCHK(c, hipMemcpyAsync(d_bounds, bounds.data(), bounds.size() * 8, hipMemcpyHostToDevice, c->stream));
+    k_vwalk<<<grid_for(nseg, 256), 256, 0, c->stream>>>(V, c->text.as<u64>(), c->sepbits.as<u64>(), d_bounds, nseg, counters);
+    HIPCHK(c, hipEventRecord(ev[3], c->stream));
+    u64 ctr[8];
+    HIPCHK(c, hipMemcpyAsync(ctr, counters, 64, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = sync_check(c))) { drop_events(); return rc; }                 // bounds is host memory
+    (void)hipEventElapsedTime(&rep->ms_index, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&rep->ms_search, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&rep->ms_walk, ev[2], ev[3]);
+    drop_events();
+    rep->segments = nseg; rep->steps = ctr[4]; rep->mismatches = ctr[0]; rep->broken_links = ctr[1];
+    rep->search_failures = ctr[2]; rep->search_steps = ctr[3];
+    rep->ok = (ctr[0] == 0 && ctr[1] == 0 && ctr[2] == 0 && ctr[4] == n - 1) ? 1 : 0;
     return DEBWT_OK;
 }
 

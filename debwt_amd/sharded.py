@@ -425,6 +425,9 @@ def check_result(d, ws, census, n, nrec):
     _chk(d, L.debwt_census_words(d._h, ctypes.c_void_p(out.data_ptr()), n, got.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
     want = census.astype(np.int64).copy()
     want[3] += nrec
-    return {"census_equals_text": bool((got.astype(np.int64) == want).all()),
-            "hash_rows_ascending": bool((np.diff(hrows.astype(np.int64)) > 0).all()) if nrec > 2 else True,
-            "hash_rows": int(len(hrows)), "dollar_row": int(dollar)}
+    res = {"census_equals_text": bool((got.astype(np.int64) == want).all()),
+           "hash_rows_ascending": bool((np.diff(hrows.astype(np.int64)) > 0).all()) if nrec > 2 else True,
+           "hash_rows": int(len(hrows)), "dollar_row": int(dollar)}
+    # the inverse BWT of the concatenated rows against the text this rank holds (one LF walk per text segment)
+    res.update(d.verify_device(out.data_ptr(), hrows, dollar))
+    return res

@@ -267,6 +267,22 @@ int debwt_special_digest(const uint64_t *packed, uint64_t n, const uint64_t *sep
 int debwt_verify_inverse(const uint64_t *bwt, uint64_t n, const uint64_t *hash_rows, uint64_t nrec,
                          uint64_t dollar_row, uint8_t *sym_out);
 
+/* The same check on the device, for results that never leave HBM and for sizes where one chain of n dependent LF steps
+ * (the reference's walk, src/LFsearch.c:49-166, ~0.2 us per step on a host core) takes hours: a sampled rank structure
+ * over the packed rows (the reference's occ tables, src/insertCase3.c:141-194, as one 128-byte line per 384 rows), the
+ * rows of ~`segments` text positions found by backward search of the text in the BWT, and one LF walk per segment, each
+ * compared symbol by symbol with the loaded text and required to end on the row the previous segment starts from --
+ * together one chain over all n rows.  d_words: DEVICE packed rows (NULL: the context's own result, with its row
+ * lists); hash_rows / dollar_row: OUT.# / OUT.$ (host).  segments 0 = default.  ok = 1: the inverse BWT of the rows is
+ * the loaded text. */
+typedef struct {
+    uint64_t segments, steps, mismatches, broken_links, search_failures, search_steps;
+    float ms_index, ms_search, ms_walk;
+    int ok;
+} debwt_verify_report;
+int debwt_verify_device(debwt_ctx *ctx, const uint64_t *d_words, const uint64_t *hash_rows, uint64_t dollar_row,
+                        uint64_t segments, debwt_verify_report *report);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,8 +13,12 @@
  *
  * usage: ref_driver WORKDIR INPUT.fa OUT K THREADS
  *   writes OUT, OUT.#, OUT.$ (src/insertCase3.c:115-131), OUT.kmerInfo (copy of the sorted edge
- *   file of src/mySort.c:193-195) and OUT.counters (the globals printed at
- *   src/generateSP.c:28-31).
+ *   file of src/mySort.c:193-195), OUT.counters (the globals printed at src/generateSP.c:28-31),
+ *   and the intermediates the stages hand to each other, copied out of WORKDIR between the stage
+ *   calls before the next stage consumes and removes them: OUT.kmerdump (the k-mer dump mySort
+ *   parses), OUT.redSeq / OUT.redPoint / OUT.blueBound / OUT.case3bound (generateBlocks,
+ *   src/INandOut.c:347-366,396-417), OUT.spCode / OUT.blueTable / OUT.spSpecialIndex (generateSP,
+ *   src/generateSP.c:626-672) and OUT.timing.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -42,6 +46,7 @@ extern uint64_t trans[256];
 extern int KMER_LENGTH_PlusOne, KMER_LENGTH;
 extern uint64_t case3num, blueBoundNum, redCapacity, blueCapacity, spCodeLen, specialBranchNum, BWTLEN,
     countRead;
+extern uint64_t *spCode, *blueTable;     /* src/sortBlue.h:1,5: filled by generateSP */
 /* reference stage entry points, src/main.h:1-8 */
 void *collect(void *arg_collect);
 int generateBlocks(char *bin);
@@ -110,7 +115,7 @@ int main(int argc, char **argv) {
     if (!n) { fprintf(stderr, "invalid input\n"); return 2; }
     uint64_t *kmers = malloc(n * 8), *counts = malloc(n * 8);
     uint64_t D = orc_kmer_count(sym, n, k, kmers, counts);
-    char path[2048];
+    char path[2048], dst[2048];
     snprintf(path, sizeof path, "%s/out", bin);
     FILE *fo = fopen(path, "w");
     if (!fo) { perror(path); return 2; }
@@ -124,6 +129,8 @@ int main(int argc, char **argv) {
         fprintf(fo, "%s\t%lu\n", s, (unsigned long)counts[i]);
     }
     fclose(fo);
+    snprintf(dst, sizeof dst, "%s.kmerdump", obj);
+    copy_file(path, dst);
     free(kmers); free(counts); free(sym); free(seq); free(reclen);
     stage_done("kmer_dump_standin");
 
@@ -132,7 +139,6 @@ int main(int argc, char **argv) {
     arg[0] = (void *)bin; arg[1] = (void *)threads; arg[2] = (void *)source;
     if (mySort((void **)arg) != 0) { fprintf(stderr, "mySort failed\n"); return 1; }
     stage_done("mySort");
-    char dst[2048];
     snprintf(path, sizeof path, "%s/kmerInfo", bin);
     snprintf(dst, sizeof dst, "%s.kmerInfo", obj);
     copy_file(path, dst);
@@ -142,8 +148,31 @@ int main(int argc, char **argv) {
     stage_done("collect_getKmer");
     if (generateBlocks(bin) != 1) return 1;          /* src/main.c:109 */
     stage_done("generateBlocks");
+    {
+        static const char *names[] = {"redSeq", "redPoint", "blueBound", "case3bound"};
+        for (int i = 0; i < 4; i++) {
+            snprintf(path, sizeof path, "%s/%s", bin, names[i]);
+            snprintf(dst, sizeof dst, "%s.%s", obj, names[i]);
+            copy_file(path, dst);
+        }
+        g_t_last = wall();
+    }
     if (generateSP((void **)arg) != 1) return 1;     /* src/main.c:122 */
     stage_done("generateSP");
+    {
+        /* spCode: 2 bits per SP symbol, 32 per word; the last 32 of spCodeLen are padding (src/generateSP.c:215-216) */
+        snprintf(dst, sizeof dst, "%s.spCode", obj);
+        FILE *f = fopen(dst, "wb");
+        fwrite(spCode, 8, (size_t)((spCodeLen - 32 + 31) / 32), f);
+        fclose(f);
+        snprintf(dst, sizeof dst, "%s.blueTable", obj);
+        f = fopen(dst, "wb");
+        fwrite(blueTable, 8, (size_t)blueCapacity, f);
+        fclose(f);
+        snprintf(path, sizeof path, "%s/spSpecialIndex", bin);
+        snprintf(dst, sizeof dst, "%s.spSpecialIndex", obj);
+        copy_file(path, dst);
+    }
     snprintf(dst, sizeof dst, "%s.counters", obj);
     FILE *fc = fopen(dst, "w");
     fprintf(fc, "BWTLEN %lu\ncountRead %lu\ncase3num %lu\nblueBoundNum %lu\nredCapacity %lu\n"

@@ -8,8 +8,13 @@ Run in the build container only (needs /root/reference):   python tests/golden/m
 Every case is data: an input (a small FASTA, or the parameters of a formula-defined input from
 debwt_amd.synth) and the reference's outputs for it -- OUT / OUT.# / OUT.$ bytes for small
 cases, their sha256 for all, the stage counters the reference prints
-(src/generateSP.c:28-31), and the sha256 of its sorted edge file kmerInfo
-(src/mySort.c:193-195).  All inputs stay inside the reference's valid domain (all
+(src/generateSP.c:28-31), the sha256 of its sorted edge file kmerInfo (src/mySort.c:193-195), and the
+sha256 of the intermediates its stages hand to each other (ref_driver copies them out between the
+stage calls): redSeq, redPoint, blueBound, case3bound (src/INandOut.c:347-366,396-417), the SP code
+as one byte per symbol, the blue table with every block's entries sorted (src/generateSP.c:626-672).
+The k-mer dump that stands in for Jellyfish's is checked HERE against naive counting (np.unique over the
+windows of every record): the golden kmerInfo is therefore the reference's mySort applied to counts that
+are right by definition, not merely to what the oracle's counter produced.  All inputs stay inside the reference's valid domain (all
 four bases present, SP code well over 32 symbols, records > 32 bases).
 """
 import hashlib
@@ -25,8 +30,10 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from debwt_amd import fasta, synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
+import refformat as RF  # noqa: E402
 
 SMALL = 40_000  # store output bytes below this many rows
 
@@ -79,8 +86,19 @@ def run_ref(driver, recs, k, lower=False):
         p = subprocess.run([driver, d, fa, out, str(k), "1"], capture_output=True, text=True)
         if p.returncode != 0:
             raise RuntimeError(f"reference failed ({p.returncode}):\n{p.stdout[-1500:]}\n{p.stderr[-1500:]}")
-        res = {ext: open(out + ext, "rb").read() for ext in ("", ".#", ".$", ".kmerInfo")}
+        res = {ext: open(out + ext, "rb").read() for ext in ("", ".#", ".$", ".kmerInfo", ".redSeq", ".redPoint",
+                                                              ".blueBound", ".case3bound", ".spCode", ".blueTable",
+                                                              ".spSpecialIndex")}
         ctr = {a: int(b) for a, b in (ln.split() for ln in open(out + ".counters"))}
+        # the stand-in for the Jellyfish dump against the definition of the counts
+        km, ct = RF.parse_kmer_dump(open(out + ".kmerdump").read(), k)
+        nk, nc = RF.naive_kmer_counts(recs, k)
+        assert np.array_equal(km, nk) and np.array_equal(ct, nc), "k-mer dump differs from naive counting"
+        info = np.frombuffer(res[".kmerInfo"], dtype=np.uint64).reshape(-1, 2)
+        assert np.array_equal(info[:, 0], nk) and np.array_equal(info[:, 1], nc), "mySort output differs from naive counting"
+        u64 = lambda b: np.frombuffer(b, dtype=np.uint64)  # noqa: E731
+        res["spSymbols"] = RF.sp_symbols(u64(res[".spCode"]), ctr["spCodeLen"] - 32, u64(res[".spSpecialIndex"])).tobytes()
+        res["blueBlocks"] = RF.blue_blocks_sorted(u64(res[".blueTable"]), u64(res[".blueBound"])).tobytes()
         return res, ctr
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -100,7 +118,10 @@ def main():
             res, ctr = run_ref(driver, recs, k, lower)
             entry = {"name": name, "k": k, "n": n, "records": len(recs), "source": source, "counters": ctr,
                      "sha256": {"bwt": sha(res[""]), "hash": sha(res[".#"]), "dollar": sha(res[".$"]),
-                                "kmerInfo": sha(res[".kmerInfo"])}}
+                                "kmerInfo": sha(res[".kmerInfo"]), "redSeq": sha(res[".redSeq"]),
+                                "redPoint": sha(res[".redPoint"]), "blueBound": sha(res[".blueBound"]),
+                                "case3bound": sha(res[".case3bound"]), "spSymbols": sha(res["spSymbols"]),
+                                "blueBlocks": sha(res["blueBlocks"])}}
             if n <= SMALL:
                 stem = os.path.join(HERE, f"{name}.k{k}")
                 open(stem + ".bwt", "wb").write(res[""])

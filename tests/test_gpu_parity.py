@@ -52,6 +52,30 @@ def test_hip_matches_reference_golden(api, entry):
     d.close()
 
 
+@pytest.mark.parametrize("entry", MANIFEST, ids=golden_id)
+def test_hip_intermediates_match_reference_files(api, entry):
+    """the arrays the stages hand to each other, fetched from the HIP build (debwt_fetch_array) and put
+    into the reference's formats, against the files the reference's own generateBlocks / generateSP wrote
+    (redSeq, redPoint, blueBound, case3bound: src/INandOut.c:347-366,396-417; spCode, blueTable:
+    src/generateSP.c:626-672) -- sha256 in the golden manifest, made by tests/golden/make_golden.py."""
+    import refformat as RF
+    d = api.DeBWT(k=entry["k"])
+    d.load_records(golden_records(entry))
+    d.kmer_sort_rle()
+    d.classify()
+    red = d.fetch_array(api.ARR_RED)
+    bb = d.fetch_array(api.ARR_BLUE_BOUND)
+    sha = entry["sha256"]
+    assert _sha(RF.red_seq(red, entry["k"])) == sha["redSeq"]
+    assert _sha(bb) == sha["blueBound"]
+    assert _sha(RF.red_point(red, bb)) == sha["redPoint"]
+    assert _sha(d.fetch_array(api.ARR_CASE3_BOUND)) == sha["case3bound"]
+    d.sp_generate()
+    assert _sha(d.fetch_array(api.ARR_SP_SYMBOLS)) == sha["spSymbols"]
+    assert _sha(RF.blue_blocks_sorted(d.fetch_array(api.ARR_BLUE), bb)) == sha["blueBlocks"]
+    d.close()
+
+
 @pytest.mark.parametrize("entry", [e for e in MANIFEST if e["n"] < 400000], ids=golden_id)
 def test_hip_kmer_count_matches_reference_kmerinfo(api, entry):
     d = api.DeBWT(k=entry["k"])

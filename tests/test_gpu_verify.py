@@ -1,0 +1,118 @@
+"""The device inverse-BWT verifier (debwt_verify_device: rank structure, backward search for segment starts, one LF walk
+per segment -- the job of the reference's dead LFsearch path, src/LFsearch.c:49-166) and the BASELINE.json
+configurations on one GPU: chr1-sized against the oracle, GRCh38-sized by its size-independent properties."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import golden_id, golden_manifest, golden_records
+
+pytestmark = pytest.mark.gpu
+MANIFEST = golden_manifest()
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from debwt_amd import api as A
+    return A
+
+
+@pytest.mark.parametrize("entry", [e for e in MANIFEST if e["k"] in (12, 32)], ids=golden_id)
+def test_verify_device_accepts_reference_golden(api, entry):
+    recs = golden_records(entry)
+    d = api.DeBWT(k=entry["k"])
+    d.load_records(recs)
+    d.build()
+    for segments in (0, 1, 7, 1000):
+        r = d.verify_device(segments=segments)
+        assert r["inverse_bwt_ok"], (segments, r)
+        assert r["inverse_bwt"]["steps"] == entry["n"] - 1
+    d.close()
+
+
+def test_verify_device_agrees_with_host_walk_and_rejects_corruption(api):
+    import torch
+    from debwt_amd import synth
+    recs = synth.pan_genome(150_000, 4)
+    n = sum(len(r) for r in recs) + len(recs)
+    d = api.DeBWT(k=32)
+    d.load_records(recs)
+    d.build()
+    words, hrows, drow = d.fetch()
+    rc, inv = api.verify_inverse(words, n, hrows, drow)                  # the host tool (one walk per record)
+    assert rc == 0
+    good = torch.from_numpy(words.view(np.int64)).cuda()
+    r = d.verify_device(good.data_ptr(), hrows, drow, segments=64)
+    assert r["inverse_bwt_ok"] and r["inverse_bwt"]["segments"] > 8, r   # several segments found by backward search
+    rng = np.random.default_rng(3)
+    # (a) two rows with different symbols swapped: the census survives, the walk does not
+    for trial in range(4):
+        bad = words.copy()
+        while True:
+            i, j = (int(x) for x in rng.integers(0, n, size=2))
+            si = int(bad[i >> 5] >> np.uint64(2 * (31 - (i & 31)))) & 3
+            sj = int(bad[j >> 5] >> np.uint64(2 * (31 - (j & 31)))) & 3
+            if si != sj and i not in hrows and j not in hrows and drow not in (i, j):
+                break
+        for pos, s in ((i, sj), (j, si)):
+            sh = np.uint64(2 * (31 - (pos & 31)))
+            bad[pos >> 5] = (bad[pos >> 5] & ~(np.uint64(3) << sh)) | (np.uint64(s) << sh)
+        t = torch.from_numpy(bad.view(np.int64)).cuda()
+        r = d.verify_device(t.data_ptr(), hrows, drow, segments=64)
+        assert not r["inverse_bwt_ok"], (trial, i, j, r)
+    # (b) a wrong '#' row, (c) a wrong '$' row
+    h2 = hrows.copy()
+    h2[1] = h2[1] + 1 if h2[1] + 1 < h2[2] else h2[1] - 1
+    assert not d.verify_device(good.data_ptr(), h2, drow, segments=64)["inverse_bwt_ok"]
+    assert not d.verify_device(good.data_ptr(), hrows, (drow + 5) % n, segments=64)["inverse_bwt_ok"]
+    d.close()
+
+
+def test_config1_chr1_250M_equals_oracle(api, oracle):
+    """BASELINE.json configs[1]: chr1-sized (250 Mbp, k = 32), the whole BWT against the CPU oracle."""
+    from debwt_amd import synth_native as SN
+    syn = SN.Synth.named("chr1_250M")
+    words, census = syn.words()
+    d = api.DeBWT(k=32)
+    d.load_packed(words, syn.n, syn.sep())
+    d.build()
+    w, h, dr = d.fetch()
+    st = d.stats()
+    assert d.verify_device()["inverse_bwt_ok"]
+    d.close()
+    ow, oh, od, ost = oracle.build_bwt(oracle.sym_from_codes([syn.codes(0)]), 32)
+    assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od
+    for a, b in (("red_capacity", "red_capacity"), ("blue_capacity", "blue_capacity"), ("blue_bound_num", "blue_bound_num"),
+                 ("sp_len", "sp_len"), ("case3num", "case3num")):
+        assert st[a] == ost[b]
+
+
+@pytest.mark.parametrize("workload", ["grch38_3.1G", "real_small"])
+def test_config2_properties(api, workload):
+    """BASELINE.json configs[2]: GRCh38-sized (3.1 Gbp in 24 records) on one GPU -- beyond what the oracle holds, so the
+    size-independent properties: the inverse BWT reproduces the text (device LF walks), the symbol census equals the
+    text's, the '#' rows ascend, and the result does not depend on k (k = 32 and k = 24 give the identical BWT).
+    real_small: the same checks on distribution R (Alu-like family, satellites, homopolymers)."""
+    from debwt_amd import synth_native as SN
+    syn = SN.Synth.named(workload)
+    words, census = syn.words()
+    sep = syn.sep()
+    digests = []
+    for k in (32, 24):
+        d = api.DeBWT(k=k)
+        d.load_packed(words, syn.n, sep)
+        d.build()
+        got = d.bwt_census().astype(np.int64)
+        want = census.astype(np.int64).copy()
+        want[3] += syn.nrec
+        assert (got == want).all()
+        r = d.verify_device()
+        assert r["inverse_bwt_ok"], r
+        w, h, dr = d.fetch()
+        assert len(h) == syn.nrec - 1 and (np.diff(h.astype(np.int64)) > 0).all()
+        digests.append((hashlib.sha256(w.tobytes()).hexdigest(), hashlib.sha256(h.tobytes()).hexdigest(), dr))
+        d.close()
+    assert digests[0] == digests[1]

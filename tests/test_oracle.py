@@ -54,6 +54,45 @@ def test_golden_equals_naive_definition(oracle, entry):
     assert np.array_equal(got, oracle.naive_bwt(sym))
 
 
+@pytest.mark.parametrize("entry", MANIFEST, ids=golden_id)
+def test_kmer_counts_equal_naive_definition(oracle, entry):
+    """a-1 by definition, independent of the oracle's counter: np.unique over the k-windows of every record.  The
+    reference's mySort output (the golden kmerInfo hash) and the oracle's counter must both equal it -- so the
+    golden kmerInfo is the reference applied to counts that are right by definition (the generator asserts the same
+    for the dump ref_driver feeds to mySort)."""
+    import refformat as RF
+    recs = golden_records(entry)
+    km, ct = RF.naive_kmer_counts(recs, entry["k"])
+    assert _sha(np.stack([km, ct], axis=1)) == entry["sha256"]["kmerInfo"]           # reference mySort == definition
+    okm, oct_ = oracle.kmer_count(oracle.sym_from_codes(recs), entry["k"])
+    assert np.array_equal(km, okm) and np.array_equal(ct, oct_)                      # oracle counter == definition
+    assert len(km) == entry["counters"]["distinctKmers"]
+
+
+@pytest.mark.parametrize("entry", MANIFEST, ids=golden_id)
+def test_oracle_intermediates_match_reference(oracle, entry):
+    """The oracle's red table and SP code against what the reference's generateBlocks / generateSP wrote
+    (redSeq, src/INandOut.c:396-404; spCode + spSpecialIndex, src/generateSP.c:626-660)."""
+    import refformat as RF
+    sym = oracle.sym_from_codes(golden_records(entry))
+    out = oracle.build_bwt(sym, entry["k"], want_intermediates=True)
+    sp, red = out[4], out[5]
+    assert _sha(RF.red_seq(red, entry["k"])) == entry["sha256"]["redSeq"]
+    assert _sha(sp) == entry["sha256"]["spSymbols"]
+
+
+def test_naive_kmer_counts_on_adversarial_inputs(oracle):
+    import refformat as RF
+    for seed in range(10):
+        rng = np.random.default_rng(7000 + seed)
+        recs = _random_collection(rng)
+        for k in (12, 21, 32):
+            km, ct = RF.naive_kmer_counts(recs, k)
+            okm, oct_ = oracle.kmer_count(oracle.sym_from_codes(recs), k)
+            assert np.array_equal(km, okm) and np.array_equal(ct, oct_)
+            assert int(ct.sum()) == sum(len(r) - k + 1 for r in recs)
+
+
 def _random_collection(rng):
     nrec = int(rng.integers(1, 6))
     base = rng.integers(0, 4, size=int(rng.integers(60, 300))).astype(np.uint8)
