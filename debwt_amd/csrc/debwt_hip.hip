@@ -944,34 +944,35 @@ static int bitonic_large(debwt_ctx *c, u64 b0, u32 m, u64 j0) {
 
 static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
     int rc;
-    std::vector<u32> lq(c->nlarge), fr(c->nlarge);
-    std::vector<u64> bs(c->nlarge), j0(c->nlarge);
-    HIPCHK(c, hipMemcpyAsync(lq.data(), c->large_q.p, c->nlarge * 4, hipMemcpyDeviceToHost, c->stream));
+    // descriptors of the large blocks: one gather, one copy
+    std::vector<u64> desc3(3 * c->nlarge);
+    ENSURE(c, c->large_k0, 3 * c->nlarge * 8);
+    k_large_gather<<<grid_for(c->nlarge, 256), 256, 0, c->stream>>>(c->large_q.as<u32>(), c->nlarge, c->blk_freq.as<u32>(),
+                                                                   c->blk_start.as<u64>(), c->blk_j0.as<u64>(), c->large_k0.as<u64>());
+    HIPCHK(c, hipMemcpyAsync(desc3.data(), c->large_k0.p, desc3.size() * 8, hipMemcpyDeviceToHost, c->stream));
     if ((rc = sync_check(c))) return rc;
-    for (u64 t = 0; t < c->nlarge; t++) {
-        HIPCHK(c, hipMemcpyAsync(&fr[t], c->blk_freq.as<u32>() + lq[t], 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&bs[t], c->blk_start.as<u64>() + lq[t], 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&j0[t], c->blk_j0.as<u64>() + lq[t], 8, hipMemcpyDeviceToHost, c->stream));
-    }
-    if ((rc = sync_check(c))) return rc;
-    u32 maxm = 0;
-    for (u64 t = 0; t < c->nlarge; t++) maxm = std::max(maxm, fr[t]);
-    c->st.blue_max_block = maxm;
     // rounds: every pending block is split in the same five launches (batches of at most LS_BATCH_ROWS rows of
-    // scratch), one synchronisation per batch; the ranges a batch reports as still too large are the next round's blocks
+    // scratch), one synchronisation per batch; the ranges a batch reports as still too large are the next round's
+    // blocks: a range of ties one pair of windows deeper, any other range on finer splitters.  A run of one symbol or a
+    // tandem repeat ties for as long as it lasts and sheds 42 SP symbols per round -- rounds are cheap (a few launches
+    // over the rows still pending), the bitonic network with its symbol-by-symbol comparator is only the last resort.
     constexpr u64 LS_BATCH_ROWS = 1ull << 28;
-    // ties that outlast this many pairs of windows (runs of one symbol, tandem repeats: the tie shrinks by a window
-    // per round) go to the network, whose comparator walks as far as it has to
-    constexpr u32 LS_MAX_DEPTH = 3;
     struct Work { u64 b0, j0; u32 m, depth; };
     std::vector<Work> work, next;
-    for (u64 t = 0; t < c->nlarge; t++) work.push_back(Work{bs[t], j0[t], fr[t], 0u});
+    u32 maxm = 0;
+    for (u64 t = 0; t < c->nlarge; t++) {
+        work.push_back(Work{desc3[3 * t], desc3[3 * t + 1], (u32)desc3[3 * t + 2], 0u});
+        maxm = std::max(maxm, (u32)desc3[3 * t + 2]);
+    }
+    c->st.blue_max_block = maxm;
     if (c->cfg.reserved & 1024) {                                  // bit 10: bitonic network only (tests)
         for (const Work &wk : work) if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc;
         return DEBWT_OK;
     }
     std::vector<u32> res;
+    std::vector<LsOver> over;
     std::vector<LsBlock> desc;
+    u32 round = 0;
     while (!work.empty()) {
         next.clear();
         for (size_t w0 = 0; w0 < work.size();) {
@@ -988,9 +989,11 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
                 wgs += (wk.m + 255u) / 256u;
             }
             const size_t nblk = desc.size();
-            // scratch: w, x, en (u64 per row), bin (u32 per row); per block: splitters, range words, results, descriptor
-            const size_t per_blk = LS_MAXBINS * 16 + LS_MAXR * 12 + LS_RES * 4 + sizeof(LsBlock);
-            ENSURE(c, c->ls_buf, rows * 28 + nblk * per_blk + 256);
+            const size_t over_cap = (size_t)(rows / BLUE_LDS_CAP) + 2;
+            // scratch: w, x, en (u64 per row), bin (u32 per row); per block: splitters, range words, result, descriptor;
+            // the batch's oversize ranges
+            const size_t per_blk = LS_MAXBINS * 16 + LS_MAXR * 12 + 4 + sizeof(LsBlock);
+            ENSURE(c, c->ls_buf, rows * 28 + nblk * per_blk + over_cap * sizeof(LsOver) + 512);
             u64 *p64 = c->ls_buf.as<u64>();
             LargeSplit ls{};
             ls.nblk = (u32)nblk;
@@ -998,48 +1001,44 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
             ls.spl_w = p64 + 3 * rows; ls.spl_x = ls.spl_w + nblk * LS_MAXBINS;
             LsBlock *dblk = reinterpret_cast<LsBlock *>(ls.spl_x + nblk * LS_MAXBINS);
             ls.blk = dblk;
-            ls.bin = reinterpret_cast<u32 *>(dblk + nblk);
+            ls.over = reinterpret_cast<LsOver *>(dblk + nblk);
+            ls.bin = reinterpret_cast<u32 *>(ls.over + over_cap);
             ls.cnt = ls.bin + rows; ls.start = ls.cnt + nblk * LS_MAXR; ls.cur = ls.start + nblk * LS_MAXR;
             ls.res = ls.cur + nblk * LS_MAXR;
+            ls.nover = ls.res + nblk;
             HIPCHK(c, hipMemcpyAsync(dblk, desc.data(), nblk * sizeof(LsBlock), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemsetAsync(ls.nover, 0, 4, c->stream));
             k_ls_windows<<<(u32)wgs, 256, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
             k_ls_splitters<<<(u32)nblk, 1024, 0, c->stream>>>(ls);
             k_ls_bin<<<(u32)wgs, 256, 0, c->stream>>>(ls);
             k_ls_plan<<<(u32)nblk, LS_MAXBINS, 0, c->stream>>>(ls, sub);
             k_ls_scatter<<<(u32)wgs, 256, 0, c->stream>>>(c->blue.as<u64>(), ls);
-            res.resize(nblk * LS_RES);
-            HIPCHK(c, hipMemcpyAsync(res.data(), ls.res, res.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            res.resize(nblk + 1);
+            HIPCHK(c, hipMemcpyAsync(res.data(), ls.res, (nblk + 1) * 4, hipMemcpyDeviceToHost, c->stream));
             if ((rc = sync_check(c))) return rc;                   // desc and res are host memory
-            for (size_t i = 0; i < nblk; i++) {
-                const Work &wk = work[w0 + i];
-                const u32 *r = res.data() + i * LS_RES;
-                if (r[0]) { if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc; continue; }   // queue full: nothing moved
-                // a range of ties that is most of the block: a run of one symbol or a tandem repeat -- the tie shrinks by
-                // one window per round; the whole block goes to the network as it is (the ranges already queued are
-                // ranges of the sorted block too, the LDS kernels find them in order)
-                bool low_complexity = false;
-                for (u32 o = 0; o < r[1]; o++) low_complexity |= r[4 + 3 * o] && (u64)r[3 + 3 * o] * 2 > wk.m;
-                if (low_complexity) { if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc; continue; }
-                for (u32 o = 0; o < r[1]; o++) {
-                    const u32 st = r[2 + 3 * o], cnt = r[3 + 3 * o], ties = r[4 + 3 * o];
-                    // a range of ties is split on the next pair of windows, any other on finer splitters (it cannot
-                    // hold every row: the splitters are rows)
-                    const u64 deeper = ((u64)wk.depth + 2) * (2 * SP_WIN);
-                    if (ties && wk.depth < LS_MAX_DEPTH && deeper < c->S + 2 * SP_WIN)
-                        next.push_back(Work{wk.b0 + st, wk.j0 + st, cnt, wk.depth + 1});
-                    else if (!ties && cnt < wk.m) next.push_back(Work{wk.b0 + st, wk.j0 + st, cnt, wk.depth});
-                    else if ((rc = bitonic_large(c, wk.b0 + st, cnt, wk.j0 + st))) return rc;
-                }
+            const u32 nover = res[nblk];
+            if (nover > over_cap) { c->err = "large-block split: more oversize ranges than rows allow"; return DEBWT_EINTERNAL; }
+            over.resize(nover);
+            if (nover) HIPCHK(c, hipMemcpy(over.data(), ls.over, nover * sizeof(LsOver), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nblk; i++)                       // sub-block table full: nothing of the block moved
+                if (res[i]) { const Work &wk = work[w0 + i]; if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc; }
+            for (const LsOver &o : over) {
+                const Work &wk = work[w0 + o.blk];
+                const u64 deeper = ((u64)wk.depth + 2) * (2 * SP_WIN);
+                if (o.ties && deeper < c->S + 2 * SP_WIN) next.push_back(Work{wk.b0 + o.st, wk.j0 + o.st, o.cnt, wk.depth + 1});
+                else if (!o.ties && o.cnt < wk.m) next.push_back(Work{wk.b0 + o.st, wk.j0 + o.st, o.cnt, wk.depth});
+                else if ((rc = bitonic_large(c, wk.b0 + o.st, o.cnt, wk.j0 + o.st))) return rc;
             }
             w0 = w1;
         }
         if (getenv("DEBWT_TRACE_LARGE")) {
             u32 dmax = 0; u64 rows = 0;
             for (const Work &wk : next) { dmax = std::max(dmax, wk.depth); rows += wk.m; }
-            fprintf(stderr, "large blocks: round of %zu blocks -> %zu ranges to split again (%llu rows, deepest %u)\n",
-                    work.size(), next.size(), (unsigned long long)rows, dmax);
+            fprintf(stderr, "large blocks: round %u of %zu blocks -> %zu ranges to split again (%llu rows, deepest %u)\n",
+                    round, work.size(), next.size(), (unsigned long long)rows, dmax);
         }
         work.swap(next);
+        round++;
     }
     return DEBWT_OK;
 }

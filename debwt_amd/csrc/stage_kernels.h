@@ -1066,33 +1066,41 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
 #define LS_SAMPLES 4096
 #define LS_MAXBINS 1024                // splitters + 1
 #define LS_MAXR (2 * LS_MAXBINS)       // ranges: below splitter 0, equal to it, between 0 and 1, equal to 1, ...
-#define LS_RES (2 + 3 * LS_MAXR)
 struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0, depth, pad; };   // row0: first scratch row; wg0: first 256-row
                                                                         // workgroup; depth: windows already equal
+struct LsOver { u32 blk, st, cnt, ties; };                              // a range above BLUE_LDS_CAP rows: block of the
+                                                                        // batch, first row, rows, 1 = rows tie with a splitter
 struct LargeSplit {
     const LsBlock *blk; u32 nblk;
     u64 *w, *x, *en;                  // per row: first two windows, entry (copy)
     u32 *bin;                         // per row: its range
     u64 *spl_w, *spl_x;               // per block: LS_MAXBINS splitters
     u32 *cnt, *start, *cur;           // per block: LS_MAXR ranges
-    u32 *res;                         // per block: LS_RES words -- [0] = 1: sub-block table full (nothing queued, nothing
-};                                    // moved); [1] = oversize ranges, then their (start, rows, ties) triples
+    u32 *res;                         // per block: 1 = sub-block table full (nothing queued, nothing moved)
+    LsOver *over; u32 *nover;         // oversize ranges of the batch (at most rows / BLUE_LDS_CAP of them), their number
+};
 // atomicAdd(&ctr[r], 1) for every active lane; returns what it returned.  When the whole wave names the same counter
 // (most rows of a low-complexity block share a range) one lane adds for all.  All lanes of the wave must call it;
 // lanes with !active take no part.
 __device__ __forceinline__ u32 ls_wave_add(u32 *__restrict__ ctr, u32 r, bool active) {
-    const u64 todo = __ballot(active);
-    if (!todo) return 0;
+    u64 todo = __ballot(active);
     const u32 lane = threadIdx.x & 63u;
-    const u32 leader = (u32)__builtin_ctzll(todo);
-    const u32 r0 = __shfl(r, (int)leader, 64);
-    if (__ballot(active && r == r0) == todo) {
+    u32 result = 0;
+    // the few counters most lanes name (rows of a low-complexity block crowd into a handful of ranges): one atomic per
+    // counter and wave; whoever is left after four of them adds for itself
+#pragma unroll 1
+    for (int it = 0; it < 4 && todo; it++) {
+        const u32 leader = (u32)__builtin_ctzll(todo);
+        const u32 r0 = __shfl(r, (int)leader, 64);
+        const u64 same = __ballot(active && r == r0) & todo;
         u32 base = 0;
-        if (lane == leader) base = atomicAdd(&ctr[r0], (u32)__popcll(todo));
+        if (lane == leader) base = atomicAdd(&ctr[r0], (u32)__popcll(same));
         base = __shfl(base, (int)leader, 64);
-        return base + (u32)__popcll(todo & ((1ull << lane) - 1ull));
+        if ((same >> lane) & 1ull) result = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
     }
-    return active ? atomicAdd(&ctr[r], 1u) : 0u;
+    if ((todo >> lane) & 1ull) result = atomicAdd(&ctr[r], 1u);
+    return result;
 }
 __device__ __forceinline__ u32 ls_block_of(const LargeSplit &ls, u32 wg) {
     u32 lo = 0, hi = ls.nblk;                                // last block whose first workgroup is <= wg
@@ -1162,15 +1170,14 @@ __global__ __launch_bounds__(256) void k_ls_bin(LargeSplit ls) {
 // one workgroup per block: range starts; ranges of <= BLUE_LDS_CAP rows become sub-blocks, larger ones are reported
 __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub sub) {
     __shared__ u32 part[LS_MAXBINS];
-    __shared__ u32 nsub, nover, base, full;
+    __shared__ u32 nsub, base, full;
     const LsBlock B = ls.blk[blockIdx.x];
-    u32 *res = ls.res + (size_t)blockIdx.x * LS_RES;
     const u32 tid = threadIdx.x;
     const u32 nr = 2 * B.nb;
     u32 c[2];
     for (int h = 0; h < 2; h++) c[h] = 2 * tid + h < nr ? ls.cnt[blockIdx.x * LS_MAXR + 2 * tid + h] : 0u;
     part[tid] = c[0] + c[1];
-    if (tid == 0) { nsub = 0; nover = 0; full = 0; }
+    if (tid == 0) { nsub = 0; full = 0; }
     __syncthreads();
     for (u32 d = 1; d < LS_MAXBINS; d <<= 1) {
         const u32 v = tid >= d ? part[tid - d] : 0u;
@@ -1184,33 +1191,41 @@ __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub s
     for (int h = 0; h < 2; h++) {
         if (2 * tid + h < nr) ls.start[blockIdx.x * LS_MAXR + 2 * tid + h] = st[h];
         if (c[h] >= 1 && c[h] <= BLUE_LDS_CAP) my[h] = atomicAdd(&nsub, 1u);
-        if (c[h] > BLUE_LDS_CAP) {
-            const u32 o = atomicAdd(&nover, 1u);
-            res[2 + 3 * o] = st[h]; res[3 + 3 * o] = c[h]; res[4 + 3 * o] = (u32)h;      // h = 1: a range of ties
-        }
     }
     __syncthreads();
     if (tid == 0) {
         base = atomicAdd(sub.count, nsub);
         full = (u64)base + nsub > (u64)sub.cap ? 1u : 0u;
-        res[0] = full; res[1] = nover;
+        ls.res[blockIdx.x] = full;
     }
     __syncthreads();
-    for (int h = 0; h < 2; h++)
+    for (int h = 0; h < 2; h++) {
         if (c[h] >= 1 && c[h] <= BLUE_LDS_CAP && !full) {
             const u32 e = base + my[h];
             sub.start[e] = B.b0 + st[h]; sub.freq[e] = c[h]; sub.j0[e] = B.j0 + st[h]; sub.depth[e] = B.depth;
         }
+        if (c[h] > BLUE_LDS_CAP && !full)                                   // h = 1: a range of ties
+            ls.over[atomicAdd(ls.nover, 1u)] = LsOver{blockIdx.x, st[h], c[h], (u32)h};
+    }
 }
 __global__ __launch_bounds__(256) void k_ls_scatter(u64 *__restrict__ blue, LargeSplit ls) {
     const u32 bi = ls_block_of(ls, blockIdx.x);
     const LsBlock B = ls.blk[bi];
     const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
-    if (ls.res[(size_t)bi * LS_RES]) return;                 // nothing was queued: the rows stay for the network
+    if (ls.res[bi]) return;                                  // nothing was queued: the rows stay for the network
     const bool valid = i < B.m;
     const u32 b = valid ? ls.bin[B.row0 + i] : 0u;
     const u32 slot = ls_wave_add(ls.cur + (size_t)bi * LS_MAXR, b, valid);
     if (valid) blue[B.b0 + ls.start[bi * LS_MAXR + b] + slot] = ls.en[B.row0 + i];
+}
+
+// descriptors of the large blocks (context-wide block ids in large_q) in one gather
+__global__ void k_large_gather(const u32 *__restrict__ large_q, u64 nlarge, const u32 *__restrict__ blk_freq,
+                               const u64 *__restrict__ blk_start, const u64 *__restrict__ blk_j0, u64 *__restrict__ out) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlarge) return;
+    const u32 q = large_q[t];
+    out[3 * t] = blk_start[q]; out[3 * t + 1] = blk_j0[q]; out[3 * t + 2] = blk_freq[q];
 }
 
 // large blocks: bitonic network in global memory, one launch per compare-exchange distance
