@@ -1011,6 +1011,8 @@ __global__ __launch_bounds__(256) void rs_tile_emit_kernel(const u64 *__restrict
     }
 }
 
+// One workgroup per unfit stretch, 8 consecutive keys per thread and step (16-byte loads).  A stretch that is one run of
+// equal keys (a homopolymer's k-mer: millions of instances) is recognised by its ends and has exactly one head.
 template <int EMIT>
 __global__ __launch_bounds__(256) void rs_unfit_rle_kernel(const u64 *__restrict__ keys, u64 n,
                                                            const u64 *__restrict__ bnd, u32 nwtiles,
@@ -1018,6 +1020,7 @@ __global__ __launch_bounds__(256) void rs_unfit_rle_kernel(const u64 *__restrict
                                                            u32 *__restrict__ tcnt, const u32 *__restrict__ tex,
                                                            const u32 *__restrict__ boff, u64 *__restrict__ dk,
                                                            u32 *__restrict__ dstart, u8 *__restrict__ mchar) {
+    constexpr u32 V = 8, STEP = 256 * V;
     __shared__ u32 wsum[4];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const u32 nu = *nunfit;
@@ -1025,22 +1028,52 @@ __global__ __launch_bounds__(256) void rs_unfit_rle_kernel(const u64 *__restrict
         const u32 t = unfit[i];
         const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
         u32 run = EMIT ? tex[t] + boff[t / RLT_BLOCK] : 0u;                 // distinct keys before the tile
-        for (u64 p = s; p < e; p += 256) {
-            const u64 j = p + tid;
-            const bool valid = j < e;
-            const u64 k = valid ? keys[j] : 0ull;
-            const bool head = valid && (j == s || keys[j - 1] != k);
-            const u64 bm = __ballot(head);
-            if (lane == 0) wsum[w] = (u32)__popcll(bm);
+        const u64 kfirst = keys[s];
+        const bool one_run = kfirst == keys[e - 1];                          // sorted: every key of the stretch is equal
+        if (one_run) {
+            if (!EMIT) { if (tid == 0) tcnt[t] = 1; continue; }
+            if (tid == 0) { dk[run] = kfirst; dstart[run] = (u32)s; }
+            const u8 sy = (u8)(kfirst & 3);
+            for (u64 j = s + tid; j < e; j += 256) mchar[j] = sy;
+            continue;
+        }
+        for (u64 p = s; p < e; p += STEP) {
+            const u64 j0 = p + (u64)tid * V;
+            u64 k[V + 1];
+            const bool whole = j0 + V <= e && ((j0 & 1ull) == 0);
+            if (whole) {
+#pragma unroll
+                for (u32 q = 0; q < V; q += 2) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + j0 + q);
+                    k[1 + q] = v.x; k[2 + q] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (u32 q = 0; q < V; q++) k[1 + q] = j0 + q < e ? keys[j0 + q] : 0ull;
+            }
+            k[0] = (j0 > s && j0 < e) ? keys[j0 - 1] : 0ull;
+            u32 heads = 0;
+#pragma unroll
+            for (u32 q = 0; q < V; q++) {
+                const u64 j = j0 + q;
+                if (j < e && (j == s || k[q] != k[1 + q])) heads |= 1u << q;
+            }
+            const u32 cnt = (u32)__popc(heads);
+            const u32 incl = wave_scan_incl(cnt);
+            if (lane == 63) wsum[w] = incl;
             __syncthreads();
-            u32 before = 0, tot = 0;
+            u32 before = incl - cnt, tot = 0;
 #pragma unroll
             for (u32 x = 0; x < 4; x++) { const u32 v = wsum[x]; before += x < w ? v : 0u; tot += v; }
-            if (EMIT && valid) {
-                mchar[j] = (u8)(k & 3);
-                if (head) {
-                    const u64 off = (u64)run + before + (u32)__popcll(bm & ((1ull << lane) - 1ull));
-                    dk[off] = k; dstart[off] = (u32)j;
+            if (EMIT && j0 < e) {
+                u64 off = (u64)run + before;
+#pragma unroll
+                for (u32 q = 0; q < V; q++) {
+                    const u64 j = j0 + q;
+                    if (j < e) {
+                        mchar[j] = (u8)(k[1 + q] & 3);
+                        if ((heads >> q) & 1u) { dk[off] = k[1 + q]; dstart[off] = (u32)j; off++; }
+                    }
                 }
             }
             run += tot;

@@ -1079,29 +1079,6 @@ struct LargeSplit {
     u32 *res;                         // per block: 1 = sub-block table full (nothing queued, nothing moved)
     LsOver *over; u32 *nover;         // oversize ranges of the batch (at most rows / BLUE_LDS_CAP of them), their number
 };
-// atomicAdd(&ctr[r], 1) for every active lane; returns what it returned.  When the whole wave names the same counter
-// (most rows of a low-complexity block share a range) one lane adds for all.  All lanes of the wave must call it;
-// lanes with !active take no part.
-__device__ __forceinline__ u32 ls_wave_add(u32 *__restrict__ ctr, u32 r, bool active) {
-    u64 todo = __ballot(active);
-    const u32 lane = threadIdx.x & 63u;
-    u32 result = 0;
-    // the few counters most lanes name (rows of a low-complexity block crowd into a handful of ranges): one atomic per
-    // counter and wave; whoever is left after four of them adds for itself
-#pragma unroll 1
-    for (int it = 0; it < 4 && todo; it++) {
-        const u32 leader = (u32)__builtin_ctzll(todo);
-        const u32 r0 = __shfl(r, (int)leader, 64);
-        const u64 same = __ballot(active && r == r0) & todo;
-        u32 base = 0;
-        if (lane == leader) base = atomicAdd(&ctr[r0], (u32)__popcll(same));
-        base = __shfl(base, (int)leader, 64);
-        if ((same >> lane) & 1ull) result = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    if ((todo >> lane) & 1ull) result = atomicAdd(&ctr[r], 1u);
-    return result;
-}
 __device__ __forceinline__ u32 ls_block_of(const LargeSplit &ls, u32 wg) {
     u32 lo = 0, hi = ls.nblk;                                // last block whose first workgroup is <= wg
     while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (ls.blk[mid].wg0 <= wg) lo = mid; else hi = mid; }
@@ -1146,13 +1123,18 @@ __global__ __launch_bounds__(1024) void k_ls_splitters(LargeSplit ls) {
         ls.spl_w[blockIdx.x * LS_MAXBINS + b] = sw[i]; ls.spl_x[blockIdx.x * LS_MAXBINS + b] = sx[i];
     }
 }
+// A workgroup takes 256 consecutive rows of one block.  The rows' ranges are counted in LDS first and the global range
+// counters receive one atomic per range and workgroup (issued by different threads, not one after the other): rows of a
+// low-complexity block crowd into a handful of ranges, and one device-scope atomic per row serialises on them.
 __global__ __launch_bounds__(256) void k_ls_bin(LargeSplit ls) {
+    __shared__ u32 h[LS_MAXR];
     const u32 bi = ls_block_of(ls, blockIdx.x);
     const LsBlock B = ls.blk[bi];
+    const u32 nr = 2 * B.nb;
+    for (u32 r = threadIdx.x; r < nr; r += 256) h[r] = 0;
+    __syncthreads();
     const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
-    const bool valid = i < B.m;
-    u32 r = 0;
-    if (valid) {
+    if (i < B.m) {
         const u64 w = ls.w[B.row0 + i], x = ls.x[B.row0 + i];
         const u64 *spw = ls.spl_w + (size_t)bi * LS_MAXBINS, *spx = ls.spl_x + (size_t)bi * LS_MAXBINS;
         u32 lo = 0, hi = B.nb - 1;                           // number of splitters below the row's windows
@@ -1162,10 +1144,13 @@ __global__ __launch_bounds__(256) void k_ls_bin(LargeSplit ls) {
             if (sw != w ? sw < w : sx < x) lo = mid + 1; else hi = mid;
         }
         const bool tie = lo + 1 < B.nb && spw[lo] == w && spx[lo] == x;
-        r = 2 * lo + (tie ? 1u : 0u);
+        const u32 r = 2 * lo + (tie ? 1u : 0u);
         ls.bin[B.row0 + i] = r;
+        atomicAdd(&h[r], 1u);
     }
-    (void)ls_wave_add(ls.cnt + (size_t)bi * LS_MAXR, r, valid);
+    __syncthreads();
+    for (u32 r = threadIdx.x; r < nr; r += 256)
+        if (h[r]) atomicAdd(&ls.cnt[(size_t)bi * LS_MAXR + r], h[r]);
 }
 // one workgroup per block: range starts; ranges of <= BLUE_LDS_CAP rows become sub-blocks, larger ones are reported
 __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub sub) {
@@ -1209,14 +1194,24 @@ __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub s
     }
 }
 __global__ __launch_bounds__(256) void k_ls_scatter(u64 *__restrict__ blue, LargeSplit ls) {
+    __shared__ u32 h[LS_MAXR];                               // rows of the workgroup per range, then their first slot
     const u32 bi = ls_block_of(ls, blockIdx.x);
     const LsBlock B = ls.blk[bi];
-    const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
     if (ls.res[bi]) return;                                  // nothing was queued: the rows stay for the network
+    const u32 nr = 2 * B.nb;
+    for (u32 r = threadIdx.x; r < nr; r += 256) h[r] = 0;
+    __syncthreads();
+    const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
     const bool valid = i < B.m;
     const u32 b = valid ? ls.bin[B.row0 + i] : 0u;
-    const u32 slot = ls_wave_add(ls.cur + (size_t)bi * LS_MAXR, b, valid);
-    if (valid) blue[B.b0 + ls.start[bi * LS_MAXR + b] + slot] = ls.en[B.row0 + i];
+    const u32 mine = valid ? atomicAdd(&h[b], 1u) : 0u;      // rank among the workgroup's rows of the range
+    __syncthreads();
+    for (u32 r = threadIdx.x; r < nr; r += 256) {
+        const u32 c = h[r];
+        if (c) h[r] = ls.start[bi * LS_MAXR + r] + atomicAdd(&ls.cur[(size_t)bi * LS_MAXR + r], c);
+    }
+    __syncthreads();
+    if (valid) blue[B.b0 + h[b] + mine] = ls.en[B.row0 + i];
 }
 
 // descriptors of the large blocks (context-wide block ids in large_q) in one gather

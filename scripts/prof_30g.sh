@@ -8,6 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o $TAG -- python3 $ROOT/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-check --h2h-reps 0 "$@" > $ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2> $ROOT/gpurun_out/${TAG}_under.err
 cd $ROOT
 F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
+find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete
 cp $F gpurun_out/${TAG}_kernel_stats.csv
 python - <<PY
 import csv
