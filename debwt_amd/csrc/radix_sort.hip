@@ -454,97 +454,110 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
     }
 }
 
-// First pass of a key RANGE (a build in key ranges, or a shard that scans the whole text): only a fraction of the
-// positions yields a key of the range, but a tile costs nearly the same whatever it holds -- its barrier-separated
-// phases are latency-bound with two workgroups per CU.  So the keys of consecutive position tiles are collected (in the
-// upper half of skeys, which the peer masks do not use) until the next tile would not fit, and ranked and flushed
-// together; a position tile that alone holds more than half a tile of keys is ranked as it is.
+// First pass of a key RANGE (a build in key ranges, a shard that scans the whole text, an exchange round): only a
+// fraction of the positions yields a key of the range, and what such a pass costs is finding them.  One lane takes one
+// text word = 32 consecutive positions straight from global memory (no staging, no barrier); the range test needs only
+// the first 12 bits of a window (ranges are cut at 12-bit prefix bins) and a separator test -- a handful of operations
+// per position with compile-time shifts -- and leaves a 32-bit mask of the positions that yield a key.  The keys of the
+// marked positions are computed and collected in the tile buffer (the whole of skeys: the rank state that aliases its
+// first half is cleared again before the ranking); a full tile, RS_TILE keys from however many positions it took, is
+// ranked and flushed like a tile of the array passes.  Any density works: what does not fit the tile stays in the masks
+// for the next round of the same words.
+// key_lo / key_hi must be multiples of a prefix bin (2^(key bits - 12)), as every caller cuts them.
 template <int HI, int AUX = 0>
 __global__ __launch_bounds__(SC_NT) __attribute__((amdgpu_waves_per_eu(RS_WAVES_EU, RS_WAVES_EU)))
 void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 chunk, RsDigit dg,
                               const u32 *__restrict__ offsets, const u32 *__restrict__ digit_base, u32 nchunks) {
     constexpr int DG = AUX ? 0 : (HI ? 2 : 1);
-    constexpr u32 CAP = RS_TILE / 2;
     __shared__ ScShared sh;
-    __shared__ u64 stext[RS_STEXT], ssep[RS_SSEP];
+    __shared__ u8 stab[AUX ? 4096 : 4];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     if (tid < RS_RADIX) {
         sh.run[tid] = offsets[(u64)tid * nchunks + blockIdx.x] + digit_base[tid];
         sh.cc[tid] = 0;
     }
+    if (AUX) for (u32 i = tid; i < 4096; i += SC_NT) stab[i] = ts.bin_tab ? ts.bin_tab[i] : 0;
     const u32 oalign = (u32)(reinterpret_cast<uintptr_t>(out) >> 3) & (SC_LINE - 1u);
-    const u64 beg = (u64)blockIdx.x * chunk;
+    const u64 beg = (u64)blockIdx.x * chunk;                  // a multiple of RS_TILE: word-aligned
     const u64 end = beg + chunk < n ? beg + chunk : n;
-    TextStage st{stext, ssep, 0, 0};
-    rs_clear_rank_state(sh);
+    const int K = ts.K, nsh = 64 - 2 * K, kb = 2 * K + 2;
+    const u64 kmask = (1ull << K) - 1ull;
+    const u32 lo12 = (u32)(ts.key_lo >> (kb - 12)), hi12 = ts.key_hi ? (u32)(ts.key_hi >> (kb - 12)) : 4096u;
+    const u32 span12 = hi12 - lo12;
     lds_barrier();
-    u64 *dense = sh.skeys + CAP;
-    u64 pos = beg;
-    u32 ndense = 0;                               // keys collected in dense[]
-    u64 pend[SC_ITEMS];                           // the position tile that did not fit (this thread's 8 positions)
-    u32 pend_mask = 0, pend_off = 0, pend_total = 0;
-    bool have_pend = false;
-    for (;;) {
-        while (!have_pend && pos < end) {
-            rs_stage_text(ts, ts.pos0 + pos, st);
-            pend_mask = rs_staged_keys<SC_ITEMS>(ts, st, pos + (u64)tid * SC_ITEMS, end, pend);
-            pos += RS_TILE;
-            const u32 mine = (u32)__popc(pend_mask);
-            const u32 incl = wave_scan_incl(mine);
+    const u64 nwords = beg < end ? (end - beg + 31) >> 5 : 0;
+    u32 ndense = 0;                                           // keys in the tile buffer (uniform)
+    for (u64 wbase = 0;; wbase += SC_NT) {
+        const bool more = wbase < nwords;                     // uniform; the round after the last word flushes the rest
+        const u64 idx0 = beg + ((wbase + tid) << 5);          // first item of this lane's word
+        u32 m = 0;
+        u64 w0 = 0, w1 = 0, wp = 0;
+        u64 g = 0;
+        if (more && idx0 < end) {
+            const u64 p = ts.pos0 + idx0;                      // text position, a multiple of 32
+            g = p >> 5;
+            w0 = ts.text[g]; w1 = ts.text[g + 1];
+            wp = g ? ts.text[g - 1] : 3ull;                    // the 'T' that stands at separators goes before the text
+            const u64 sb = sep_window(ts.sepbits, p);          // bit t: separator at p + t
+            const u32 lim = end - idx0 < 32 ? (u32)(end - idx0) : 32u;
+#pragma unroll
+            for (u32 t = 0; t < 32; t++) {
+                const u32 pre = t <= 26 ? (u32)(w0 >> (52 - 2 * t)) & 0xFFFu
+                                        : (u32)(((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) >> 52);
+                const bool in = AUX ? stab[pre] != 0xFFu : (pre - lo12) < span12;
+                const bool ok = in && ((sb >> t) & kmask) == 0ull;
+                m |= (ok ? 1u : 0u) << t;
+            }
+            if (lim < 32) m &= (1u << lim) - 1u;
+        }
+        for (;;) {
+            const u32 cnt = (u32)__popc(m);
+            const u32 incl = wave_scan_incl(cnt);
             if (lane == 63) sh.scan_tmp[w] = incl;
             lds_barrier();
-            pend_off = incl - mine; pend_total = 0;
+            u32 woff = incl - cnt, tot = 0;
 #pragma unroll
-            for (u32 i = 0; i < SC_WAVES; i++) { const u32 t = sh.scan_tmp[i]; if (i < w) pend_off += t; pend_total += t; }
-            lds_barrier();                                         // scan_tmp is free again
-            have_pend = true;
-            if (ndense + pend_total <= CAP) {
-                u32 o = ndense + pend_off;
-#pragma unroll
-                for (int r = 0; r < SC_ITEMS; r++)
-                    if ((pend_mask >> r) & 1u) dense[o++] = pend[r];
-                ndense += pend_total;
-                have_pend = false;
+            for (u32 i = 0; i < SC_WAVES; i++) { const u32 t = sh.scan_tmp[i]; if (i < w) woff += t; tot += t; }
+            const u32 room = RS_TILE - ndense;
+            u32 take = woff >= room ? 0u : (cnt < room - woff ? cnt : room - woff);
+            u32 o = ndense + woff;
+            while (take--) {
+                const u32 t = (u32)__ffs(m) - 1u;
+                m &= m - 1u;
+                const u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
+                const u64 pred = t ? (w0 >> (2 * (32 - t))) & 3ull : wp & 3ull;
+                sh.skeys[o++] = ((win >> nsh) << 2) | pred;
             }
-        }
-        if (ndense == 0 && !have_pend) break;
-        u64 key[SC_ITEMS];
-        int tot;
-        if (ndense == 0) {
-            // the pending position tile holds more than CAP keys: rank it where it is
-            tot = (int)rs_rank_tile<DG, 0>(pend, pend_mask, dg, sh, oalign);
-            have_pend = false;
-        } else {
-            lds_barrier();                                         // every append is visible
-            const u32 R = (ndense + SC_NT - 1) / SC_NT;           // rounds: wave w takes keys [(w*R)*64, (w*R + R)*64)
-            u32 vmask = 0;
+            const bool rest = tot > room;                      // uniform: keys left in the masks
+            ndense += rest ? room : tot;
+            lds_barrier();                                     // the appends are visible, scan_tmp is free
+            if (ndense == RS_TILE || (!more && ndense)) {
+                const u32 R = (ndense + SC_NT - 1) / SC_NT;    // rounds: wave w takes keys [(w*R)*64, (w*R + R)*64)
+                u64 key[SC_ITEMS];
+                u32 vmask = 0;
 #pragma unroll
-            for (int r = 0; r < SC_ITEMS; r++) {
-                const u32 idx = (w * R + (u32)r) * 64u + lane;
-                const bool have = (u32)r < R && idx < ndense;
-                key[r] = have ? dense[idx] : ~0ull;
-                vmask |= (have ? 1u : 0u) << r;
+                for (int r = 0; r < SC_ITEMS; r++) {
+                    const u32 idx = (w * R + (u32)r) * 64u + lane;
+                    const bool have = (u32)r < R && idx < ndense;
+                    key[r] = have ? sh.skeys[idx] : ~0ull;
+                    vmask |= (have ? 1u : 0u) << r;
+                }
+                lds_barrier();                                 // every wave holds its keys: skeys becomes rank state
+                rs_clear_rank_state(sh);
+                lds_barrier();
+                const int tile_tot = (int)rs_rank_tile<DG, 0>(key, vmask, dg, sh, oalign, R);
+                rs_flush_heads(sh, out);
+                u64 k[SC_ITEMS];
+#pragma unroll
+                for (int r = 0; r < SC_ITEMS; r++) k[r] = sh.skeys[tid + r * SC_NT];
+                lds_barrier();
+                rs_flush_body<DG>(sh, dg, out, k, tile_tot);
+                lds_barrier();
+                ndense = 0;
             }
-            lds_barrier();                                         // the staging step writes skeys
-            tot = (int)rs_rank_tile<DG, 0>(key, vmask, dg, sh, oalign, R);
-            ndense = 0;
+            if (!rest) break;
         }
-        rs_flush_heads(sh, out);
-        u64 k[SC_ITEMS];
-#pragma unroll
-        for (int r = 0; r < SC_ITEMS; r++) k[r] = sh.skeys[tid + r * SC_NT];
-        lds_barrier();
-        rs_flush_body<DG>(sh, dg, out, k, tot);
-        rs_clear_rank_state(sh);
-        lds_barrier();
-        if (have_pend && pend_total <= CAP) {                      // the tile that did not fit opens the next collection
-            u32 o = pend_off;
-#pragma unroll
-            for (int r = 0; r < SC_ITEMS; r++)
-                if ((pend_mask >> r) & 1u) dense[o++] = pend[r];
-            ndense = pend_total;
-            have_pend = false;
-        }
+        if (!more) break;
     }
 #pragma unroll
     for (u32 i = 0; i < RS_RADIX * SC_LINE / SC_NT; i++) {
