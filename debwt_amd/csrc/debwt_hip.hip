@@ -97,6 +97,7 @@ struct debwt_ctx {
     u64 g0 = 0, g1 = 0;         // text slice of this shard for the SP stage, in 32-position groups
     u64 S_local = 0, B_slice = 0, sp_off = 0;
     int hbits = 10, pbits = 13;
+    bool mzfilter = false;      // the prefilter is indexed by the nodes' minimizers (pbits = log2 of its 64-bit words)
     bool abs32 = true;          // fill cursors hold absolute blue slots
 
     hipEvent_t ev[8]{};         // stage boundaries
@@ -797,28 +798,44 @@ static int sp_prepare(debwt_ctx *c) {
     // node table: 2..4 slots per red node; prefilter: ~8 bits per red node (tuning knob: reserved = delta+8)
     int hbits = 10;
     while ((1ull << hbits) < 2 * c->R) hbits++;
-    // prefilter: 8 bits per red node; while the node table still fits the Infinity Cache (<= 256 MB) the bitmap is
-    // held at L2 size (2 MB, down to 2..4 bits per node): a probe that leaves L2 then costs more than the extra table
-    // lookups of a fuller bitmap (3 Gbp: SP stage 57.8 ms with 2 MB, 75.8 ms with 16 MB).  Beyond that a false positive
-    // is a random HBM access and the full 8 bits win again (30 Gbp: 0.93 s against 0.97 s).
-    // cfg.reserved & 15 = delta + 8 overrides (tuning).
-    int pb = (c->cfg.reserved & 15) ? hbits + (c->cfg.reserved & 15) - 8
+    // prefilter.  K >= 24: 64-bit words chosen by the node's minimizer, ~2 red nodes per word (stage_kernels.h,
+    // k_build_mzfilter) -- a lane that walks 32 consecutive positions fetches ~4 words instead of probing 32 times.
+    // Smaller K (or cfg.reserved bit 11: tests): one bit per hashed node, 8 bits per red node; while the node table
+    // still fits the Infinity Cache (<= 256 MB) the bitmap is held at L2 size (2 MB, down to 2..4 bits per node).
+    // cfg.reserved & 15 = delta + 8 overrides the size (tuning).
+    // The plain bitmap wins while it stays L2-sized (250 Mbp: SP stage 3.3 ms against 3.5 ms); cfg.reserved bit 12
+    // forces the minimizer filter for any size (tests).
+    c->mzfilter = c->K >= 24 && !(c->cfg.reserved & 2048) && (hbits >= 23 || (c->cfg.reserved & 4096));
+    int pb;
+    if (c->mzfilter) {
+        pb = 10;
+        while ((2ull << pb) < c->R) pb++;
+        if (c->cfg.reserved & 15) pb += (c->cfg.reserved & 15) - 8;
+        if (pb < 10) pb = 10;
+        if (pb > 30) pb = 30;
+    } else {
+        pb = (c->cfg.reserved & 15) ? hbits + (c->cfg.reserved & 15) - 8
                                      : (hbits <= 24 ? std::max(hbits, std::min(hbits + 3, 24)) : hbits + 3);
-    if (pb < 10) pb = 10;
+        if (pb < 10) pb = 10;
+    }
     if (pb > 31 || hbits > 31) { c->err = "red table too large for 32-bit slots"; return DEBWT_ERANGE; }
     c->hbits = hbits; c->pbits = pb;
     // absolute 32-bit fill cursors unless the context's blue slots need more bits (cfg.reserved bit 4 forces the
     // 64-bit form: tests)
     c->abs32 = c->B < 0xFFFFFFF0ull && !(c->cfg.reserved & 16);
-    size_t rb_bytes = ((size_t)1 << pb) / 8 + 64, ht_slots = (size_t)1 << hbits;
+    size_t rb_bytes = (c->mzfilter ? ((size_t)8 << pb) : ((size_t)1 << pb) / 8) + 64, ht_slots = (size_t)1 << hbits;
     ENSURE(c, c->rbits, rb_bytes);
     ENSURE(c, c->htab, ht_slots * sizeof(HSlot));
     HIPCHK(c, hipMemsetAsync(c->rbits.p, 0, rb_bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(c->htab.p, 0, ht_slots * sizeof(HSlot), c->stream));
-    if (c->R)
+    if (c->R) {
         k_build_hash<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->red_q.as<u32>(),
                                                                 c->blk_start.as<u64>(), c->abs32 ? 1 : 0, (u32)c->qbase,
-                                                                (u32)c->Q, hbits, c->htab.as<HSlot>(), pb, c->rbits.as<u32>());
+                                                                (u32)c->Q, hbits, c->htab.as<HSlot>(), c->mzfilter ? 0 : pb,
+                                                                c->rbits.as<u32>());
+        if (c->mzfilter)
+            k_build_mzfilter<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->K, pb, c->rbits.as<u64>());
+    }
     return DEBWT_OK;
 }
 
@@ -832,8 +849,12 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
     if (g1 - g0 > (1ull << 27) - 2) { c->err = "text slice of the SP stage exceeds 2^32 positions"; return DEBWT_ERANGE; }
     c->g0 = g0; c->g1 = g1;
     const u64 ng = g1 - g0;
-    if (ng)
-        k_sp_flags<<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+    if (ng && c->mzfilter)
+        k_sp_flags<1><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+            c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
+            c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1);
+    else if (ng)
+        k_sp_flags<0><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
             c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1);
     SpCountF fc{c->momask.as<u32>() + g0, c->mimask.as<u32>() + g0};

@@ -508,8 +508,35 @@ __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__re
         htab[h].cur = q < Qlocal ? (abs32 ? (u32)blk_start[q] : 0u) : HCURSOR_SKIP;
         htab[h].q = red_q[r];                                    // global block id (blue-entry exchange)
     }
-    u32 hb = red_hash2(node, pb);
-    atomicOr(&rbits[hb >> 5], 1u << (hb & 31));
+    if (pb) {                                                    // pb = 0: the minimizer filter is built by k_build_mzfilter
+        u32 hb = red_hash2(node, pb);
+        atomicOr(&rbits[hb >> 5], 1u << (hb & 31));
+    }
+}
+
+// Prefilter with locality.  A probe per text position into a bitmap the size of the Infinity Cache is what the SP stage
+// of a 30 Gbp build spends its time on: 3 * 10^10 random 64-byte sectors for one bit each.  Consecutive positions hold
+// nodes that overlap in all but one symbol, and so mostly share their MINIMIZER (the 16-mer of the node with the smallest
+// hash): the filter word of a node is chosen by its minimizer, the bit inside the word by the node itself.  A lane that
+// walks 32 consecutive positions then changes words only ~4 times and fetches 4 sectors instead of 32.  Nodes that share
+// a minimizer share the word (red nodes cluster around the same loci), the words are sized for ~2 red nodes each; a
+// minimizer that very many red nodes share (a homopolymer's) saturates its word and merely sends its positions to the
+// node table, as every position went before.  Used for K >= 24 (a node then has >= 9 candidate 16-mers).
+#define MZ_W 16
+__device__ __forceinline__ u32 mz_hash(u32 x) { x *= 0x9E3779B1u; x ^= x >> 15; return x * 0x85EBCA6Bu; }
+__device__ __forceinline__ u32 mz_word(u32 m, int fbits) { return (m * 0xC2B2AE3Du) >> (32 - fbits); }
+__device__ __forceinline__ u32 mz_bit(u64 node) { return (u32)((node * 0xC2B2AE3D27D4EB4Full) >> 58); }
+__global__ void k_build_mzfilter(const u64 *__restrict__ red, u64 R, int K, int fbits, u64 *__restrict__ fw) {
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const u64 node = red[r] >> 2, win = node << (64 - 2 * K);
+    const int nw = K - MZ_W + 1;
+    u32 m = 0xFFFFFFFFu;
+    for (int j = 0; j < nw; j++) {
+        const u32 h = mz_hash((u32)(win >> (32 - 2 * j)));
+        m = h < m ? h : m;
+    }
+    atomicOr(&fw[mz_word(m, fbits)], 1ull << mz_bit(node));
 }
 
 // returns the slot (or 0xFFFFFFFF) and the flags of `node`
@@ -539,6 +566,7 @@ __global__ void k_special_rows(const u64 *__restrict__ dk, const u32 *__restrict
 
 // pass 1: one lane = 32 consecutive positions = one text word (coalesced 8-byte loads); per position the
 // node is a shift of the 128-bit (w0,w1) pair; flags go out as two 32-bit masks per group
+template <int MZ>
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict__ text, const u64 *__restrict__ sepbits,
                                                            u64 n, int K, const HSlot *__restrict__ htab, int hbits,
                                                            const u32 *__restrict__ rbits, int pb,
@@ -554,8 +582,37 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
     u32 lim = (n - i0) < 32 ? (u32)(n - i0) : 32u;
     const u32 inrange = lim == 32 ? 0xFFFFFFFFu : ((1u << lim) - 1u);
     u32 mo = 0, mi = 0;
-    // phase 1 (no divergence): which positions hold a node that may be in the red table
+    // phase 1: which positions hold a node that may be in the red table
     u32 cand = 0, spec = 0;
+    if (MZ) {
+        // hashes of the 16-mers that start at symbols 0..46 of the word pair; minimizer of the node at t = the smallest
+        // among those of symbols t .. t + K - 16 (pb = filter words as a power of two, rbits = the words)
+        const u64 *fw = reinterpret_cast<const u64 *>(rbits);
+        const int nw = K - MZ_W + 1;
+        u32 H[47];
+#pragma unroll
+        for (int j = 0; j < 47; j++) {
+            u32 x;
+            if (j <= 16) x = (u32)(w0 >> (32 - 2 * j));
+            else if (j < 32) x = (u32)(w0 << (2 * j - 32)) | (u32)(w1 >> (96 - 2 * j));
+            else x = (u32)(w1 >> (96 - 2 * j));
+            H[j] = mz_hash(x);
+        }
+        u32 mprev = 0;
+        u64 fwv = 0;
+#pragma unroll
+        for (u32 t = 0; t < 32; t++) {
+            u32 m = H[t];
+#pragma unroll
+            for (int d = 1; d < 16; d++)
+                if (d < nw) m = H[t + d] < m ? H[t + d] : m;
+            if (t == 0 || m != mprev) fwv = fw[mz_word(m, pb)];
+            mprev = m;
+            const u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
+            cand |= (u32)((fwv >> mz_bit(win >> (64 - 2 * K))) & 1ull) << t;
+            spec |= (((sb >> t) & kmask) ? 1u : 0u) << t;
+        }
+    } else {
 #pragma unroll
     for (u32 t = 0; t < 32; t++) {
         u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
@@ -563,6 +620,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
         u32 bit = (rbits[hb >> 5] >> (hb & 31)) & 1u;
         cand |= bit << t;
         spec |= (((sb >> t) & kmask) ? 1u : 0u) << t;
+    }
     }
     cand &= inrange & ~spec;
     spec &= inrange;

@@ -28,7 +28,7 @@ for c in range(cases):
     else:
         recs = [rng.integers(0, 4, size=int(rng.integers(33, 3000))).astype(np.uint8) for _ in range(int(rng.integers(1, 40)))]
     k = int(rng.choice([12, 13, 16, 20, 24, 27, 31, 32]))
-    tune = int(rng.choice([0, 0, 32, 48, 128, 160, 256]))
+    tune = int(rng.choice([0, 0, 32, 48, 128, 160, 256, 4096, 4096 + 32, 4096 + 6]))
     cap = int(rng.choice([0, 0, 4096, 20000, 300000]))
     sym = O.sym_from_codes(recs)
     ow, oh, od, ost = O.build_bwt(sym, k)

@@ -426,6 +426,22 @@ def test_multi_range_with_large_blocks_and_many_records(api, oracle):
     d.close()
 
 
+@pytest.mark.parametrize("entry", [e for e in MANIFEST if e["k"] >= 24], ids=golden_id)
+def test_minimizer_prefilter_matches_reference_golden(api, entry):
+    """The SP stage's prefilter indexed by minimizers (the form large texts use; tune bit 12 forces it at any size), with
+    the filter at its default size and cut to 1/4 (saturated words send more positions to the node table)."""
+    for tune in (4096, 4096 + 6):
+        d = api.DeBWT(k=entry["k"], tune=tune)
+        d.load_records(golden_records(entry))
+        d.build()
+        words, hrows, drow = d.fetch()
+        st = d.stats()
+        assert _sha(words) == entry["sha256"]["bwt"] and _sha(hrows) == entry["sha256"]["hash"]
+        assert st["sp_len"] + 32 == entry["counters"]["spCodeLen"] and st["blue_capacity"] == entry["counters"]["blueCapacity"]
+        assert _sha(d.fetch_array(api.ARR_SP_SYMBOLS)) == entry["sha256"]["spSymbols"]
+        d.close()
+
+
 @pytest.mark.parametrize("tune", [0, 128])
 def test_pan_genome_deep_tie_groups(api, oracle, tune):
     """Ten near-identical genomes with repeat families: blocks of hundreds of rows whose tie groups (one locus in
