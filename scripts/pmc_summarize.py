@@ -25,6 +25,7 @@ def per_kernel(path, counter):
 
 def main():
     fetch_csv, write_csv, keys, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    workload = sys.argv[5] if len(sys.argv) > 5 else "chr1_250M"
     F, W = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     hist = next(k for k in F if k.startswith("rs_hist_kernel<0, 0"))
     known_kib = 8.0 * keys / 1024.0
@@ -32,7 +33,15 @@ def main():
     scat = next(k for k in F if k.startswith("rs_scatter_kernel<0, 0"))
     rd = F[scat]["mean_of_large_KiB"] * 1024.0 * factor
     wr = W[scat]["mean_of_large_KiB"] * 1024.0
+    table = {}
+    for name in sorted(set(F) | set(W)):
+        f, w = F.get(name, {}), W.get(name, {})
+        table[name] = {"launches": f.get("launches", w.get("launches")),
+                       "read_GB_per_large_launch": round(f.get("mean_of_large_KiB", 0) * 1024 * factor / 1e9, 4),
+                       "write_GB_per_large_launch": round(w.get("mean_of_large_KiB", 0) * 1024 / 1e9, 4)}
     res = {
+        "workload": workload,
+        "per_kernel_GB": table,
         "calibration": {"kernel": hist + " reads exactly 8 B x %d keys" % keys, "known_KiB": known_kib,
                         "FETCH_SIZE_KiB": F[hist]["mean_of_large_KiB"], "factor": factor},
         "rs_scatter_kernel": {"name": scat, "FETCH_SIZE_KiB": F[scat]["mean_of_large_KiB"],
