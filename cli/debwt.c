@@ -1,7 +1,7 @@
 /*
  * debwt.c -- host program with the reference's command line over libdebwt_hip.so.
  *
- *   deBWT -o OUT [-t T] [-k K] [-j DIR] [--device D] INPUT.fa[.gz]
+ *   deBWT -o OUT [-t T] [-k K] [-j DIR] [--device D | --gpus G [--devices a,b,...]] [--iupac SEED] INPUT.fa[.gz]
  *
  * Same contract as /root/reference/src/main.c:25-53,175-186: options are `flag value` pairs, INPUT last;
  * -k 12..32 (default 32); -t (default 8) = host threads of the FASTA ingest; -j accepted and ignored (no Jellyfish); OUT is probed by create+remove before any work
@@ -26,6 +26,8 @@ static void usage(void) {
                     "-k (optional): k-mer length (from 12 to 32, default 32)\n"
                     "-j (optional): jellyfish directory (accepted, ignored)\n"
                     "--device (optional): GPU ordinal (default 0)\n"
+                    "--gpus (optional): build with G GPUs (k-mer-prefix shards, one host thread per GPU, exchanges over xGMI)\n"
+                    "--devices (optional): comma-separated GPU ordinals of the G shards (default 0,1,...; may repeat)\n"
                     "--iupac (optional): seed; N and other ambiguity letters become pseudo-random bases of their sets\n"
                     "                    (what otherTool/transferN does, reproducibly)\n"
                     "reference: sequence in fasta format (plain or gzip)\n");
@@ -45,10 +47,62 @@ static int write_file(const char *path, const void *p, size_t bytes) {
     return w == bytes ? 0 : -1;
 }
 
+/* the outputs of src/insertCase3.c:115-131 */
+static int write_outputs(const char *obj, const uint64_t *bwt, uint64_t n, const uint64_t *hash_rows, uint64_t nrec, uint64_t dollar) {
+    size_t ol = strlen(obj);
+    char *p = malloc(ol + 3);
+    if (!p) return -1;
+    int rc = write_file(obj, bwt, (size_t)((n + 31) >> 5) * 8);
+    memcpy(p, obj, ol); memcpy(p + ol, ".#", 3);
+    if (!rc) rc = write_file(p, hash_rows, (nrec - 1) * 8);
+    memcpy(p + ol, ".$", 3);
+    if (!rc) rc = write_file(p, &dollar, 8);
+    free(p);
+    return rc;
+}
+
+/* --gpus G: the same program over G GPUs (debwt_multi_*: one host thread per GPU inside the library) */
+static int multi_main(const char *source, const char *obj, int k, int threads, int iupac, unsigned long long seed, int gpus,
+                      const int *devs) {
+    double t0 = now();
+    debwt_config cfg = {k, 0, 0, 0};
+    debwt_multi *m = NULL;
+    int rc = debwt_multi_create(&cfg, devs, gpus, &m);
+    if (rc) { fprintf(stderr, "debwt_multi_create (%d GPUs): %s\n", gpus, debwt_strerror(rc)); return 1; }
+    double t1 = now();
+    rc = debwt_multi_load_fasta(m, source, threads, iupac ? DEBWT_FASTA_IUPAC_RANDOM : 0u, seed);
+    if (rc) {
+        fprintf(stderr, "%s (sequence must be ACGT only unless --iupac is given, records > 32 bases)\n", debwt_multi_last_error(m));
+        debwt_multi_destroy(m);
+        return 1;
+    }
+    double t2 = now();
+    rc = debwt_multi_build(m);
+    if (rc) { fprintf(stderr, "build: %s %s\n", debwt_strerror(rc), debwt_multi_last_error(m)); debwt_multi_destroy(m); return 1; }
+    double t3 = now();
+    debwt_multi_stats st;
+    debwt_stats s0;
+    debwt_multi_get_stats(m, &st, &s0);
+    uint64_t *bwt = malloc((size_t)((st.n + 31) >> 5) * 8), *hash_rows = malloc((st.nrec ? st.nrec : 1) * 8), dollar = 0;
+    rc = (bwt && hash_rows) ? debwt_multi_fetch_bwt(m, bwt, hash_rows, &dollar) : DEBWT_ENOMEM;
+    if (!rc && write_outputs(obj, bwt, st.n, hash_rows, st.nrec, dollar)) rc = DEBWT_EINVAL;
+    double t4 = now();
+    if (!rc) {
+        printf("BWTLEN=%lu\n", (unsigned long)st.n);
+        printf("%u GPUs, %u exchange round(s): init %.3f s, read+pack+load (%d threads) %.3f s, build %.3f s, fetch+write %.3f s; "
+               "shard 0 received %.3f GB of k-mers and %.3f GB of blue entries\n", st.ngpus, st.rounds, t1 - t0, threads, t2 - t1,
+               t3 - t2, t4 - t3, st.key_bytes_in / 1e9, st.blue_bytes_in / 1e9);
+        fprintf(stderr, "success output bwt!\n");
+    } else fprintf(stderr, "fetch/write: %s\n", debwt_strerror(rc));
+    free(bwt); free(hash_rows);
+    debwt_multi_destroy(m);
+    return rc ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 4 || (argc & 1) == 1) { usage(); return 1; }            /* src/main.c:25 */
     const char *source = argv[argc - 1], *obj = NULL;
-    int k = 32, device = 0, iupac = 0;
+    int k = 32, device = 0, iupac = 0, gpus = 0, devs[256], ndevs = 0;
     unsigned long long iupac_seed = 0;
     long threads = 8;
     for (int i = 1; i < argc - 1; i += 2) {
@@ -61,6 +115,15 @@ int main(int argc, char **argv) {
             k = atoi(argv[i + 1]);
             if (k < 12 || k > 32) { fprintf(stderr, "-k: k-mer length (from 12 to 32, default 32)\n"); return 1; }
         } else if (!strcmp(argv[i], "--device")) device = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--gpus")) {
+            gpus = atoi(argv[i + 1]);
+            if (gpus < 1 || gpus > 255) { fprintf(stderr, "--gpus: 1 to 255\n"); return 1; }
+        } else if (!strcmp(argv[i], "--devices")) {
+            for (const char *p = argv[i + 1]; *p && ndevs < 255;) {
+                devs[ndevs++] = (int)strtol(p, (char **)&p, 10);
+                if (*p == ',') p++;
+            }
+        }
         else if (!strcmp(argv[i], "--iupac")) { iupac = 1; iupac_seed = strtoull(argv[i + 1], NULL, 10); }
         else { usage(); return 1; }
     }
@@ -71,6 +134,8 @@ int main(int argc, char **argv) {
     remove(obj);
 
     fprintf(stderr, "run deBWT (MI355X path): sequence file %s, output %s, k-mer length %d\n", source, obj, k);
+    if (gpus) return multi_main(source, obj, k, (int)(threads > 256 ? 256 : threads), iupac, iupac_seed, gpus,
+                                ndevs == gpus ? devs : NULL);
     double t0 = now();
     debwt_config cfg = {k, device, 0, 0};
     debwt_ctx *ctx = NULL;
@@ -81,27 +146,22 @@ int main(int argc, char **argv) {
     rc = debwt_load_fasta_opts(ctx, source, (int)(threads > 256 ? 256 : threads), iupac ? DEBWT_FASTA_IUPAC_RANDOM : 0u, iupac_seed);
     if (rc) {
         fprintf(stderr, "%s (sequence must be ACGT only unless --iupac is given, records > 32 bases)\n", debwt_last_error(ctx));
+        debwt_destroy(ctx);
         return 1;
     }
     double t2 = now();
     rc = debwt_build(ctx);
-    if (rc) { fprintf(stderr, "build: %s %s\n", debwt_strerror(rc), debwt_last_error(ctx)); return 1; }
+    if (rc) { fprintf(stderr, "build: %s %s\n", debwt_strerror(rc), debwt_last_error(ctx)); debwt_destroy(ctx); return 1; }
     double t3 = now();
     debwt_stats st;
     debwt_get_stats(ctx, &st);
     const uint64_t n = st.n, nrec = st.nrec;
     size_t nw = (size_t)((n + 31) >> 5);
     uint64_t *bwt = malloc(nw * 8), *hash_rows = malloc((nrec ? nrec : 1) * 8), dollar = 0;
-    if (!bwt || !hash_rows) return 1;
-    rc = debwt_fetch_bwt(ctx, bwt, hash_rows, &dollar);
-    if (rc) { fprintf(stderr, "fetch: %s\n", debwt_strerror(rc)); return 1; }
-    size_t ol = strlen(obj);
-    char *p = malloc(ol + 3);
-    if (write_file(obj, bwt, nw * 8)) return 1;                            /* src/insertCase3.c:115-119 */
-    memcpy(p, obj, ol); memcpy(p + ol, ".#", 3);
-    if (write_file(p, hash_rows, (nrec - 1) * 8)) return 1;                /* :121-125 */
-    memcpy(p + ol, ".$", 3);
-    if (write_file(p, &dollar, 8)) return 1;                               /* :127-131 */
+    rc = (bwt && hash_rows) ? debwt_fetch_bwt(ctx, bwt, hash_rows, &dollar) : DEBWT_ENOMEM;
+    if (rc) fprintf(stderr, "fetch: %s\n", debwt_strerror(rc));
+    else if (write_outputs(obj, bwt, n, hash_rows, nrec, dollar)) rc = DEBWT_EINVAL;   /* src/insertCase3.c:115-131 */
+    if (rc) { free(bwt); free(hash_rows); debwt_destroy(ctx); return 1; }
     double t4 = now();
     printf("BWTLEN=%lu\n", (unsigned long)st.n);                           /* src/collect#$.c:59 */
     printf("the case3num is %lu\nthe blueBoundNum is %lu\nthe redCapacity is %lu\nthe blueCapacity is %lu\n",
@@ -113,6 +173,6 @@ int main(int argc, char **argv) {
            st.ms_assemble, t4 - t3);
     fprintf(stderr, "success output bwt!\n");
     debwt_destroy(ctx);
-    free(bwt); free(hash_rows); free(p);
+    free(bwt); free(hash_rows);
     return 0;
 }

@@ -43,6 +43,14 @@ class DebwtVerifyReport(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class DebwtMultiStats(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_uint64), ("nrec", ctypes.c_uint64), ("ngpus", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
+                ("key_bytes_in", ctypes.c_uint64), ("blue_bytes_in", ctypes.c_uint64), ("ms_build", ctypes.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 # every symbol include/debwt_hip.h declares
 SYMBOLS = [
     "debwt_create", "debwt_destroy", "debwt_strerror", "debwt_last_error", "debwt_load_text",
@@ -53,7 +61,9 @@ SYMBOLS = [
     "debwt_shard_facts_export", "debwt_shard_classify_global", "debwt_shard_info", "debwt_shard_fetch",
     "debwt_shard_partition_keys", "debwt_shard_plan", "debwt_shard_ranges", "debwt_shard_sort_begin",
     "debwt_shard_sort_range", "debwt_shard_sort_end", "debwt_concat_rows", "debwt_shard_export", "debwt_census_words", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
-    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_verify_device", "debwt_pinned_alloc", "debwt_pinned_free",
+    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_verify_device", "debwt_multi_create", "debwt_multi_destroy", "debwt_multi_last_error",
+    "debwt_multi_load_text", "debwt_multi_load_fasta", "debwt_multi_build", "debwt_multi_fetch_bwt", "debwt_multi_get_stats",
+    "debwt_multi_verify", "debwt_multi_shard", "debwt_pinned_alloc", "debwt_pinned_free",
 ]
 
 
@@ -172,6 +182,26 @@ def lib():
     L.debwt_load_fasta_opts.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64]
     L.debwt_special_digest.restype = ctypes.c_int
     L.debwt_special_digest.argtypes = [u64p, ctypes.c_uint64, u64p, ctypes.c_uint64, ctypes.c_int, u64p]
+    L.debwt_multi_create.restype = ctypes.c_int
+    L.debwt_multi_create.argtypes = [ctypes.POINTER(DebwtConfig), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)]
+    L.debwt_multi_destroy.restype = None
+    L.debwt_multi_destroy.argtypes = [vp]
+    L.debwt_multi_last_error.restype = ctypes.c_char_p
+    L.debwt_multi_last_error.argtypes = [vp]
+    L.debwt_multi_load_text.restype = ctypes.c_int
+    L.debwt_multi_load_text.argtypes = [vp, u64p, ctypes.c_uint64, u64p, ctypes.c_uint64]
+    L.debwt_multi_load_fasta.restype = ctypes.c_int
+    L.debwt_multi_load_fasta.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64]
+    L.debwt_multi_build.restype = ctypes.c_int
+    L.debwt_multi_build.argtypes = [vp]
+    L.debwt_multi_fetch_bwt.restype = ctypes.c_int
+    L.debwt_multi_fetch_bwt.argtypes = [vp, u64p, u64p, u64p]
+    L.debwt_multi_get_stats.restype = ctypes.c_int
+    L.debwt_multi_get_stats.argtypes = [vp, ctypes.POINTER(DebwtMultiStats), ctypes.POINTER(DebwtStats)]
+    L.debwt_multi_shard.restype = vp
+    L.debwt_multi_shard.argtypes = [vp, ctypes.c_int]
+    L.debwt_multi_verify.restype = ctypes.c_int
+    L.debwt_multi_verify.argtypes = [vp, ctypes.POINTER(DebwtVerifyReport)]
     L.debwt_verify_device.restype = ctypes.c_int
     L.debwt_verify_device.argtypes = [vp, vp, u64p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(DebwtVerifyReport)]
     L.debwt_fetch_rows.restype = ctypes.c_int

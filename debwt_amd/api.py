@@ -206,6 +206,66 @@ class DeBWT:
         return p.value
 
 
+class MultiDeBWT:
+    """One BWT over several GPUs from one process (debwt_multi_*): one host thread per GPU, peer-to-peer exchanges.
+    devices: HIP ordinals of the shards (may repeat: several shards on one GPU)."""
+
+    def __init__(self, devices, k=32, tune=0):
+        self._L = _lib.lib()
+        cfg = _lib.DebwtConfig(k=k, device=0, sort_algo=0, reserved=tune)
+        dv = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = self._L.debwt_multi_create(ctypes.byref(cfg), dv, len(devices), ctypes.byref(h))
+        if rc:
+            raise DebwtError(rc)
+        self._h, self.n, self.nrec, self._keep = h, 0, 0, None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.debwt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc:
+            raise DebwtError(rc, self._L.debwt_multi_last_error(self._h).decode())
+
+    def _shard_ctx(self, shard):
+        return ctypes.c_void_p(self._L.debwt_multi_shard(self._h, shard))
+
+    def load_packed(self, words, n, sep):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        sep = np.ascontiguousarray(sep, dtype=np.uint64)
+        self._keep = (words, sep)
+        self._chk(self._L.debwt_multi_load_text(self._h, _p64(words), n, _p64(sep), len(sep)))
+        self.n, self.nrec = n, len(sep)
+
+    def load_records(self, records):
+        self.load_packed(*pack_records(records))
+
+    def build(self):
+        self._chk(self._L.debwt_multi_build(self._h))
+
+    def fetch(self):
+        words = np.empty((self.n + 31) // 32, dtype=np.uint64)
+        hrows = np.empty(max(self.nrec - 1, 1), dtype=np.uint64)
+        drow = np.empty(1, dtype=np.uint64)
+        self._chk(self._L.debwt_multi_fetch_bwt(self._h, _p64(words), _p64(hrows), _p64(drow)))
+        return words, hrows[:self.nrec - 1], int(drow[0])
+
+    def stats(self):
+        ms, s0 = _lib.DebwtMultiStats(), _lib.DebwtStats()
+        self._chk(self._L.debwt_multi_get_stats(self._h, ctypes.byref(ms), ctypes.byref(s0)))
+        return ms.as_dict(), s0.as_dict()
+
+    def verify_device(self):
+        rep = _lib.DebwtVerifyReport()
+        self._chk(self._L.debwt_multi_verify(self._h, ctypes.byref(rep)))
+        return rep.as_dict()
+
+
 def verify_inverse(words, n, hash_rows, dollar_row):
     """Inverse BWT by LF walk on the host (the job of the reference's dead LFsearch path)."""
     L = _lib.lib()

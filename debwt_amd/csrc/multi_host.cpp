@@ -1,0 +1,376 @@
+// multi_host.cpp -- one BWT over the GPUs of one node from ONE host process: debwt_multi_* (include/debwt_hip.h).
+//
+// The reference is a single process with a thread pool (src/main.c:30, pthreads); its multi-GPU counterpart keeps that
+// shape: one host thread per GPU drives that GPU's context through the debwt_shard_* stage calls -- the same sequence
+// debwt_amd/sharded.py runs with one process per GPU -- and the exchanges between the stages are direct peer-to-peer
+// copies over xGMI (every GPU PULLS its segments out of the senders' buffers: an alltoallv is world x (world - 1)
+// independent device-to-device copies, which is what RCCL's alltoallv decomposes into on a point-to-point fabric).
+// The threads meet at a barrier around every exchange.  Only the public C ABI and the HIP runtime are used here.
+#include "../../include/debwt_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr int BINS = 4096;
+constexpr int MAXR = 64;
+
+struct DevMem {
+    void *p = nullptr;
+    size_t cap = 0;
+    int dev = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        (void)hipSetDevice(dev);
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 16 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) return false;
+        cap = want;
+        return true;
+    }
+    void release() { if (p) { (void)hipSetDevice(dev); (void)hipFree(p); p = nullptr; cap = 0; } }
+};
+
+// all threads call sync(rc); it returns false on every thread as soon as any thread brought an error
+struct Rendezvous {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 1, waiting = 0, phase = 0;
+    int failed = 0;
+    bool sync(int rc) {
+        std::unique_lock<std::mutex> lk(m);
+        if (rc && !failed) failed = rc;
+        const int ph = phase;
+        if (++waiting == n) { waiting = 0; phase++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return phase != ph; });
+        return failed == 0;
+    }
+};
+
+}  // namespace
+
+struct debwt_multi {
+    int G = 0;
+    debwt_config cfg{};
+    std::vector<debwt_ctx *> ctx;
+    std::vector<int> dev;
+    std::vector<hipStream_t> stream;
+    std::vector<DevMem> xa, xb, facts, allfacts, sp, allsp, part;
+    DevMem parts, out;                     // on the first GPU: the gathered row ranges, the concatenated BWT
+    uint64_t n = 0, nrec = 0;
+    debwt_packed_text own{};                // text packed by debwt_multi_load_fasta (the contexts read it during a build)
+    std::vector<uint64_t> hash_rows;
+    uint64_t dollar_row = ~0ull;
+    std::string err;
+    bool built = false;
+    debwt_multi_stats st{};
+    // what the threads publish for each other
+    std::vector<std::vector<uint64_t>> hist, offs, boffs;
+    std::vector<std::vector<uint32_t>> cuts;
+    std::vector<uint64_t> nfacts, nblocks, brows, slen, rowbase, rows, nhash;
+    std::vector<std::vector<uint64_t>> hrows;
+    std::vector<uint64_t> drow;
+    Rendezvous rv;
+};
+
+namespace {
+
+void set_err(debwt_multi *m, int r, const char *what) {
+    std::lock_guard<std::mutex> lk(m->rv.m);
+    if (m->err.empty()) m->err = std::string("shard ") + std::to_string(r) + ": " + what + ": " + debwt_last_error(m->ctx[r]);
+}
+
+// rank r pulls: for every source s, `cnt(s)` elements of `esz` bytes from src_ptr(s) + src_off(s) into dst, in source
+// order; returns the number of elements received, or -1
+template <class PtrOf, class OffOf, class CntOf>
+long long pull(debwt_multi *m, int r, void *dst, size_t esz, PtrOf ptr_of, OffOf off_of, CntOf cnt_of) {
+    (void)hipSetDevice(m->dev[r]);
+    uint64_t o = 0;
+    for (int s = 0; s < m->G; s++) {
+        const uint64_t c = cnt_of(s);
+        if (c && hipMemcpyAsync((char *)dst + o * esz, (const char *)ptr_of(s) + off_of(s) * esz, c * esz, hipMemcpyDefault,
+                                m->stream[r]) != hipSuccess) return -1;
+        o += c;
+    }
+    if (hipStreamSynchronize(m->stream[r]) != hipSuccess) return -1;
+    return (long long)o;
+}
+
+void shard_thread(debwt_multi *m, int r) {
+    const int G = m->G;
+    debwt_ctx *c = m->ctx[r];
+    Rendezvous &rv = m->rv;
+    (void)hipSetDevice(m->dev[r]);
+    int rc;
+#define STEP(call, what) do { rc = (call); if (rc) set_err(m, r, what); } while (0)
+    // 1. census of the slices -> splitters over the shards (instance counts balanced on the summed census, the
+    //    reference's segCount idea, src/mySort.c:104-110), key ranges inside every shard
+    STEP(debwt_shard_begin(c, r, G), "shard_begin");
+    if (!rc) STEP(debwt_shard_histogram(c, m->hist[r].data()), "shard_histogram");
+    if (!rv.sync(rc)) return;
+    std::vector<uint64_t> total(BINS, 0), cum(BINS + 1, 0);
+    for (int s = 0; s < G; s++) for (int b = 0; b < BINS; b++) total[b] += m->hist[s][b];
+    for (int b = 0; b < BINS; b++) cum[b + 1] = cum[b] + total[b];
+    std::vector<uint32_t> bins(G + 1, BINS);
+    bins[0] = 0;
+    for (int s = 1; s < G; s++) {
+        const uint64_t target = cum[BINS] * (uint64_t)s / (uint64_t)G;
+        uint32_t b = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        bins[s] = std::min<uint32_t>(std::max(b, bins[s - 1]), BINS);
+    }
+    uint32_t nr = 0;
+    const uint64_t held = m->xa[r].cap + m->xb[r].cap + m->facts[r].cap + m->allfacts[r].cap + m->sp[r].cap + m->allsp[r].cap +
+                          m->part[r].cap + (r == 0 ? m->parts.cap + m->out.cap : 0);
+    STEP(debwt_shard_plan(c, total.data(), bins[r], bins[r + 1], cum[bins[r]], 1, held, &nr), "shard_plan");
+    std::vector<uint64_t> mk(MAXR, 0);
+    m->cuts[r].assign(MAXR + 1, 0);
+    if (!rc) STEP(debwt_shard_ranges(c, m->cuts[r].data(), mk.data(), MAXR), "shard_ranges");
+    m->cuts[r].resize(rc ? 1 : nr + 1);
+    if (!rv.sync(rc)) return;
+    size_t rounds = 0;
+    for (int s = 0; s < G; s++) rounds = std::max(rounds, m->cuts[s].size() - 1);
+    if (r == 0) m->st.rounds = (uint32_t)rounds;
+
+    // 2. the k-mer bucket exchange, one round per key range
+    STEP(debwt_shard_sort_begin(c), "shard_sort_begin");
+    if (!rv.sync(rc)) return;
+    for (size_t t = 0; t < rounds; t++) {
+        std::vector<uint8_t> tab(BINS, 0xFF);
+        for (int s = 0; s < G; s++)
+            if (t + 1 < m->cuts[s].size())
+                for (uint32_t b = m->cuts[s][t]; b < m->cuts[s][t + 1]; b++) tab[b] = (uint8_t)s;
+        uint64_t ns = 0;
+        for (int b = 0; b < BINS; b++) if (tab[b] != 0xFF) ns += m->hist[r][b];
+        rc = m->xa[r].ensure((ns + 64) * 8) ? 0 : DEBWT_ENOMEM;
+        if (!rc) STEP(debwt_shard_partition_keys(c, tab.data(), (uint64_t *)m->xa[r].p, m->xa[r].cap / 8, m->offs[r].data()),
+                      "shard_partition_keys");
+        if (!rv.sync(rc)) return;
+        uint64_t nrecv = 0;
+        for (int s = 0; s < G; s++) nrecv += m->offs[s][r + 1] - m->offs[s][r];
+        rc = m->xb[r].ensure((nrecv + 64) * 8) ? 0 : DEBWT_ENOMEM;
+        if (!rc && pull(m, r, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s) { return m->offs[s][r]; },
+                        [&](int s) { return m->offs[s][r + 1] - m->offs[s][r]; }) < 0) rc = DEBWT_EDEVICE;
+        if (r == 0) { uint64_t moved = 0; for (int s = 1; s < G; s++) moved += m->offs[s][1] - m->offs[s][0]; m->st.key_bytes_in += moved * 8; }
+        if (!rv.sync(rc)) return;                                   // every pull is done: the send buffers are free again
+        if (t + 1 < m->cuts[r].size()) STEP(debwt_shard_sort_range(c, (uint32_t)t, (uint64_t *)m->xb[r].p, nrecv), "shard_sort_range");
+        if (!rv.sync(rc)) return;
+    }
+    STEP(debwt_shard_sort_end(c), "shard_sort_end");
+
+    // 3. local classification totals, red table from everybody's facts
+    if (!rc) STEP(debwt_shard_classify_local(c, &m->nfacts[r], &m->nblocks[r], &m->brows[r]), "shard_classify_local");
+    if (!rc) rc = m->facts[r].ensure((m->nfacts[r] + 1) * 8) ? 0 : DEBWT_ENOMEM;
+    if (!rc) STEP(debwt_shard_facts_export(c, (uint64_t *)m->facts[r].p, m->facts[r].cap / 8), "shard_facts_export");
+    if (!rv.sync(rc)) return;
+    uint64_t allf = 0, qbase = 0, btotal = 0;
+    std::vector<uint32_t> first_block(G + 1, 0);
+    for (int s = 0; s < G; s++) {
+        allf += m->nfacts[s]; btotal += m->brows[s];
+        if (s < r) qbase += m->nblocks[s];
+        first_block[s + 1] = first_block[s] + (uint32_t)m->nblocks[s];
+    }
+    rc = m->allfacts[r].ensure((allf + 1) * 8) ? 0 : DEBWT_ENOMEM;
+    if (!rc && pull(m, r, m->allfacts[r].p, 8, [&](int s) { return m->facts[s].p; }, [&](int) { return (uint64_t)0; },
+                    [&](int s) { return m->nfacts[s]; }) < 0) rc = DEBWT_EDEVICE;
+    if (!rc) STEP(debwt_shard_classify_global(c, (const uint64_t *)m->allfacts[r].p, allf, qbase, btotal), "shard_classify_global");
+
+    // 4. SP code of the slices, symbols gathered everywhere
+    uint64_t bloc = 0;
+    if (!rc) STEP(debwt_shard_sp_flags(c, &m->slen[r], &bloc), "shard_sp_flags");
+    if (!rv.sync(rc)) return;
+    uint64_t sp_off = 0, sp_total = 0;
+    for (int s = 0; s < G; s++) { if (s < r) sp_off += m->slen[s]; sp_total += m->slen[s]; }
+    rc = m->sp[r].ensure(m->slen[r] + 64) ? 0 : DEBWT_ENOMEM;
+    if (!rc) STEP(debwt_shard_sp_emit(c, sp_off, (uint8_t *)m->sp[r].p, m->sp[r].cap), "shard_sp_emit");
+    if (!rv.sync(rc)) return;
+    rc = m->allsp[r].ensure(sp_total + 64) ? 0 : DEBWT_ENOMEM;
+    if (!rc && pull(m, r, m->allsp[r].p, 1, [&](int s) { return m->sp[s].p; }, [&](int) { return (uint64_t)0; },
+                    [&](int s) { return m->slen[s]; }) < 0) rc = DEBWT_EDEVICE;
+    if (!rc) STEP(debwt_shard_sp_import(c, (const uint8_t *)m->allsp[r].p, sp_total), "shard_sp_import");
+
+    // 5. blue entries of the slice -> the owners of their blocks
+    if (!rc) rc = m->xa[r].ensure((bloc + 64) * 8) ? 0 : DEBWT_ENOMEM;
+    if (!rc) STEP(debwt_shard_blue_route(c, first_block.data(), (uint64_t *)m->xa[r].p, m->xa[r].cap / 8, m->boffs[r].data()),
+                  "shard_blue_route");
+    if (!rv.sync(rc)) return;
+    uint64_t brecv = 0;
+    for (int s = 0; s < G; s++) brecv += m->boffs[s][r + 1] - m->boffs[s][r];
+    rc = m->xb[r].ensure((brecv + 64) * 8) ? 0 : DEBWT_ENOMEM;
+    if (!rc && pull(m, r, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s) { return m->boffs[s][r]; },
+                    [&](int s) { return m->boffs[s][r + 1] - m->boffs[s][r]; }) < 0) rc = DEBWT_EDEVICE;
+    if (r == 0) { uint64_t moved = 0; for (int s = 1; s < G; s++) moved += m->boffs[s][1] - m->boffs[s][0]; m->st.blue_bytes_in = moved * 8; }
+    if (!rv.sync(rc)) return;
+    STEP(debwt_shard_blue_place(c, (const uint64_t *)m->xb[r].p, brecv), "shard_blue_place");
+
+    // 6. owned blocks and rows
+    if (!rc) STEP(debwt_blue_sort(c), "blue_sort");
+    if (!rc) STEP(debwt_bwt_assemble(c), "bwt_assemble");
+    if (!rc) STEP(debwt_shard_info(c, &m->rowbase[r], &m->rows[r], &m->nhash[r]), "shard_info");
+    if (!rv.sync(rc)) return;
+
+    // 7. final concat on the first GPU: the packed row ranges are pulled there and shift-merged by row offset
+    uint64_t maxw = 0;
+    for (int s = 0; s < G; s++) maxw = std::max<uint64_t>(maxw, (m->rows[s] + 31) / 32 + 1);
+    rc = m->part[r].ensure(maxw * 8) ? 0 : DEBWT_ENOMEM;
+    if (!rc) STEP(debwt_shard_export(c, (uint64_t *)m->part[r].p, maxw), "shard_export");
+    m->hrows[r].assign(std::max<uint64_t>(m->nhash[r], 1), 0);
+    if (!rc) STEP(debwt_shard_fetch(c, nullptr, m->hrows[r].data(), &m->drow[r]), "shard_fetch");
+    m->hrows[r].resize(m->nhash[r]);
+    if (!rv.sync(rc)) return;
+    if (r == 0) {
+        rc = (m->parts.ensure(maxw * G * 8) && m->out.ensure(((m->n + 31) / 32 + 1) * 8)) ? 0 : DEBWT_ENOMEM;
+        if (!rc && pull(m, 0, m->parts.p, 8, [&](int s) { return m->part[s].p; }, [&](int) { return (uint64_t)0; },
+                        [&](int) { return maxw; }) < 0) rc = DEBWT_EDEVICE;
+        std::vector<uint64_t> poff(G), pbase(G), prows(G);
+        for (int s = 0; s < G; s++) { poff[s] = maxw * s; pbase[s] = m->rowbase[s]; prows[s] = m->rows[s]; }
+        if (!rc) STEP(debwt_concat_rows(c, (const uint64_t *)m->parts.p, (uint32_t)G, poff.data(), pbase.data(), prows.data(), m->n,
+                                        (uint64_t *)m->out.p), "concat_rows");
+        m->hash_rows.clear();
+        m->dollar_row = ~0ull;
+        for (int s = 0; s < G; s++) {
+            m->hash_rows.insert(m->hash_rows.end(), m->hrows[s].begin(), m->hrows[s].end());
+            if (m->drow[s] != ~0ull) m->dollar_row = m->drow[s];
+        }
+        std::sort(m->hash_rows.begin(), m->hash_rows.end());
+        if (!rc && (m->hash_rows.size() != m->nrec - 1 || m->dollar_row == ~0ull)) {
+            rc = DEBWT_EINTERNAL;
+            std::lock_guard<std::mutex> lk(rv.m);
+            if (m->err.empty()) m->err = "the shards' '#' / '$' rows do not add up";
+        }
+    }
+    (void)rv.sync(rc);
+#undef STEP
+}
+
+}  // namespace
+
+extern "C" int debwt_multi_create(const debwt_config *cfg, const int *devices, int ngpus, debwt_multi **out) {
+    if (!cfg || !out || ngpus < 1 || ngpus > 255) return DEBWT_EINVAL;
+    debwt_multi *m = new (std::nothrow) debwt_multi();
+    if (!m) return DEBWT_ENOMEM;
+    m->G = ngpus; m->cfg = *cfg;
+    m->ctx.assign(ngpus, nullptr); m->dev.resize(ngpus); m->stream.assign(ngpus, nullptr);
+    for (auto *v : {&m->xa, &m->xb, &m->facts, &m->allfacts, &m->sp, &m->allsp, &m->part}) v->resize(ngpus);
+    m->hist.assign(ngpus, std::vector<uint64_t>(BINS));
+    m->offs.assign(ngpus, std::vector<uint64_t>(ngpus + 1));
+    m->boffs.assign(ngpus, std::vector<uint64_t>(ngpus + 1));
+    m->cuts.assign(ngpus, {});
+    for (auto *v : {&m->nfacts, &m->nblocks, &m->brows, &m->slen, &m->rowbase, &m->rows, &m->nhash, &m->drow}) v->assign(ngpus, 0);
+    m->hrows.assign(ngpus, {});
+    m->rv.n = ngpus;
+    int rc = DEBWT_OK;
+    for (int r = 0; r < ngpus && !rc; r++) {
+        m->dev[r] = devices ? devices[r] : r;
+        debwt_config c1 = *cfg;
+        c1.device = m->dev[r];
+        rc = debwt_create(&c1, &m->ctx[r]);
+        if (rc) break;
+        for (auto *v : {&m->xa, &m->xb, &m->facts, &m->allfacts, &m->sp, &m->allsp, &m->part}) (*v)[r].dev = m->dev[r];
+        if (hipSetDevice(m->dev[r]) != hipSuccess || hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking) != hipSuccess)
+            rc = DEBWT_EDEVICE;
+    }
+    m->parts.dev = m->out.dev = m->dev[0];
+    if (!rc)                                                      // direct peer access where the GPUs differ (xGMI)
+        for (int a = 0; a < ngpus; a++)
+            for (int b = 0; b < ngpus; b++)
+                if (m->dev[a] != m->dev[b]) {
+                    int can = 0;
+                    (void)hipSetDevice(m->dev[a]);
+                    if (hipDeviceCanAccessPeer(&can, m->dev[a], m->dev[b]) == hipSuccess && can)
+                        (void)hipDeviceEnablePeerAccess(m->dev[b], 0);   // "already enabled" is fine
+                }
+    (void)hipGetLastError();
+    if (rc) { debwt_multi_destroy(m); return rc; }
+    *out = m;
+    return DEBWT_OK;
+}
+
+extern "C" void debwt_multi_destroy(debwt_multi *m) {
+    if (!m) return;
+    for (int r = 0; r < m->G; r++) {
+        for (auto *v : {&m->xa, &m->xb, &m->facts, &m->allfacts, &m->sp, &m->allsp, &m->part}) (*v)[r].release();
+        if (m->stream[r]) { (void)hipSetDevice(m->dev[r]); (void)hipStreamDestroy(m->stream[r]); }
+        if (m->ctx[r]) debwt_destroy(m->ctx[r]);
+    }
+    m->parts.release(); m->out.release();
+    if (m->own.words) debwt_free_packed(&m->own);
+    delete m;
+}
+
+extern "C" const char *debwt_multi_last_error(const debwt_multi *m) { return m ? m->err.c_str() : ""; }
+extern "C" debwt_ctx *debwt_multi_shard(debwt_multi *m, int shard) { return m && shard >= 0 && shard < m->G ? m->ctx[shard] : nullptr; }
+
+extern "C" int debwt_multi_load_text(debwt_multi *m, const uint64_t *packed, uint64_t n, const uint64_t *sep, uint64_t nrec) {
+    if (!m) return DEBWT_EINVAL;
+    m->built = false; m->err.clear();
+    for (int r = 0; r < m->G; r++) {                              // the same text into the HBM of every GPU
+        int rc = debwt_load_text(m->ctx[r], packed, n, sep, nrec);
+        if (rc) { m->err = std::string("load on GPU ") + std::to_string(m->dev[r]) + ": " + debwt_last_error(m->ctx[r]); return rc; }
+    }
+    m->n = n; m->nrec = nrec;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_multi_load_fasta(debwt_multi *m, const char *path, int threads, unsigned flags, uint64_t seed) {
+    if (!m || !path) return DEBWT_EINVAL;
+    debwt_packed_text pt;
+    char msg[256] = "";
+    int rc = debwt_pack_fasta_opts(path, threads, flags, seed, &pt, msg, sizeof msg);
+    if (rc) { m->err = msg; return rc; }
+    rc = debwt_multi_load_text(m, pt.words, pt.n, pt.sep, pt.nrec);
+    if (m->own.words) debwt_free_packed(&m->own);
+    m->own = pt;                                                  // the contexts read the host text during a build
+    return rc;
+}
+
+extern "C" int debwt_multi_build(debwt_multi *m) {
+    if (!m || !m->n) return DEBWT_ESTATE;
+    m->err.clear(); m->built = false;
+    m->rv.failed = 0; m->rv.waiting = 0;
+    m->st = debwt_multi_stats{};
+    m->st.ngpus = (uint32_t)m->G;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int r = 1; r < m->G; r++) th.emplace_back(shard_thread, m, r);
+    shard_thread(m, 0);
+    for (auto &t : th) t.join();
+    m->st.ms_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (m->rv.failed) return m->rv.failed;
+    m->built = true;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_multi_fetch_bwt(debwt_multi *m, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row) {
+    if (!m || !bwt || !dollar_row || (m->nrec > 1 && !hash_rows)) return DEBWT_EINVAL;
+    if (!m->built) return DEBWT_ESTATE;
+    (void)hipSetDevice(m->dev[0]);
+    if (hipMemcpy(bwt, m->out.p, (size_t)((m->n + 31) >> 5) * 8, hipMemcpyDeviceToHost) != hipSuccess) return DEBWT_EDEVICE;
+    if (m->nrec > 1) memcpy(hash_rows, m->hash_rows.data(), (m->nrec - 1) * 8);
+    *dollar_row = m->dollar_row;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_multi_get_stats(const debwt_multi *m, debwt_multi_stats *out, debwt_stats *shard0) {
+    if (!m || !out) return DEBWT_EINVAL;
+    *out = m->st;
+    out->n = m->n; out->nrec = m->nrec;
+    if (shard0) return debwt_get_stats(m->ctx[0], shard0);
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_multi_verify(debwt_multi *m, debwt_verify_report *rep) {
+    // inverse BWT of the concatenated result on the first GPU (it holds the text like every GPU)
+    if (!m || !rep) return DEBWT_EINVAL;
+    if (!m->built) return DEBWT_ESTATE;
+    return debwt_verify_device(m->ctx[0], (const uint64_t *)m->out.p, m->hash_rows.data(), m->dollar_row, 0, rep);
+}

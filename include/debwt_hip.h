@@ -226,6 +226,30 @@ int debwt_shard_export(debwt_ctx *ctx, uint64_t *d_words, uint64_t capacity);
 /* debwt_bwt_census over any packed rows in HBM (n rows at d_words) */
 int debwt_census_words(debwt_ctx *ctx, const uint64_t *d_words, uint64_t n, uint64_t counts[4]);
 
+/* ---- the same build from ONE host process: one host thread per GPU, exchanges as peer-to-peer copies over xGMI --------
+ * What the reference's single process with its thread pool (src/main.c:30) becomes on a node of GPUs: debwt_multi_build
+ * runs the exchange-mode stage sequence above on `ngpus` contexts (devices[i] = HIP ordinal of shard i; NULL = 0, 1, ...;
+ * ordinals may repeat -- several shards on one GPU -- which is how the path is tested on a one-GPU box), every shard
+ * pulling its keys / facts / SP symbols / blue entries out of the other shards' buffers with device-to-device copies,
+ * and leaves the concatenated BWT in the HBM of the first GPU.  cli/deBWT --gpus G is the C host on top of it. */
+typedef struct debwt_multi debwt_multi;
+typedef struct {
+    uint64_t n, nrec;
+    uint32_t ngpus, rounds;          /* exchange rounds = key ranges of the busiest shard */
+    uint64_t key_bytes_in;           /* bytes of k-mers shard 0 pulled from the other shards (all rounds) */
+    uint64_t blue_bytes_in;          /* bytes of blue entries shard 0 pulled from the other shards */
+    float ms_build;                  /* wall time of debwt_multi_build */
+} debwt_multi_stats;
+int debwt_multi_create(const debwt_config *cfg, const int *devices, int ngpus, debwt_multi **out);   /* cfg->device unused */
+void debwt_multi_destroy(debwt_multi *m);
+const char *debwt_multi_last_error(const debwt_multi *m);
+debwt_ctx *debwt_multi_shard(debwt_multi *m, int shard);      /* the context of one shard (debwt_set_range_cap, stats) */
+int debwt_multi_load_text(debwt_multi *m, const uint64_t *packed, uint64_t n, const uint64_t *sep, uint64_t nrec);
+int debwt_multi_load_fasta(debwt_multi *m, const char *path, int threads, unsigned flags, uint64_t seed);
+int debwt_multi_build(debwt_multi *m);
+int debwt_multi_fetch_bwt(debwt_multi *m, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row);
+int debwt_multi_get_stats(const debwt_multi *m, debwt_multi_stats *out, debwt_stats *shard0);
+
 /* ---- intermediates, for stage-by-stage parity ---------------------------------- */
 typedef enum {
     DEBWT_ARR_SORTED_KEYS = 1, /* u64 x n_main: (node<<2|pred) ascending                              */
@@ -282,6 +306,8 @@ typedef struct {
 } debwt_verify_report;
 int debwt_verify_device(debwt_ctx *ctx, const uint64_t *d_words, const uint64_t *hash_rows, uint64_t dollar_row,
                         uint64_t segments, debwt_verify_report *report);
+/* the same on the concatenated result of debwt_multi_build (first GPU; every GPU holds the text) */
+int debwt_multi_verify(debwt_multi *m, debwt_verify_report *report);
 
 #ifdef __cplusplus
 }

@@ -89,3 +89,28 @@ def test_cli_iupac_option(tmp_path):
     d.close()
     assert np.array_equal(np.fromfile(out, dtype=np.uint64), words)
     assert int(np.fromfile(out + ".$", dtype=np.uint64)[0]) == drow
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k,gpus", [("special_branches", 32, 2), ("shared_ends_duplicates", 16, 3), ("pan_fa", 32, 4)])
+def test_cli_multi_gpu_outputs_equal_reference_files(tmp_path, name, k, gpus):
+    """deBWT --gpus G: the C host over G shards (all on GPU 0 of the test box: --devices 0,0,...) writes the same three
+    files the reference writes."""
+    assert _have_cli()
+    out = str(tmp_path / "OUT")
+    if name == "pan_fa":                                   # a formula-defined golden input, written as FASTA here
+        from debwt_amd import fasta
+        entry = next(e for e in golden_manifest() if e["name"] == "pan_4x20k" and e["k"] == k)
+        fa = str(tmp_path / "pan.fa")
+        fasta.write_fasta(fa, golden_records(entry))
+    else:
+        entry = next(e for e in golden_manifest() if e["name"] == name and e["k"] == k)
+        fa = os.path.join(ROOT, "tests", "golden", name + ".fa")
+    r = subprocess.run([CLI, "-o", out, "-k", str(k), "-t", "4", "--gpus", str(gpus), "--devices", ",".join(["0"] * gpus), fa],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import hashlib
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()      # noqa: E731
+    assert sha(out) == entry["sha256"]["bwt"] and sha(out + ".#") == entry["sha256"]["hash"]
+    assert sha(out + ".$") == entry["sha256"]["dollar"]
+    assert f"{gpus} GPUs" in r.stdout
