@@ -13,7 +13,11 @@
  * (tests/golden/make_golden.py).  The k-mer counting step (a-1) is Jellyfish 2.x in the
  * reference (src/kmercounting.sh:8,11; un-vendored, absent from this image): its
  * arithmetic -- exact, non-canonical counts of every k-mer inside each record -- is
- * restated in orc_kmer_count() and pinned by definition (naive counting) only.
+ * restated in orc_kmer_count() and pinned by definition: tests/refformat.naive_kmer_counts
+ * (np.unique over the k-windows of every record) must equal it, the dump ref_driver feeds to
+ * the reference's mySort, and the reference's kmerInfo (tests/test_oracle.py, make_golden.py).
+ * Intermediates (red table, SP code) are pinned against the files the reference's
+ * generateBlocks / generateSP wrote (sha256 in tests/golden/manifest.json).
  *
  * Text model (reference src/main.c:18-23, src/collect#$.c:56-90): T = r0 # r1 # ... $,
  * alphabet A<C<G<T<#<$, all '#' compare equal and comparison continues past them.
