@@ -852,10 +852,11 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
     __shared__ u32 flag;
     __shared__ u32 smax;
     __shared__ u32 sub_n, sub_i, sub_base;
-    // sample-sort split of a large block (workgroup classes): 64 sampled rows, BLUE_BINS - 1 splitters
-    constexpr int SAMPLES = 64, BINS = (SPLIT && NT == 256) ? (CAP > 1024 ? 32 : 16) : 1;
+    // sample-sort split of a large block (workgroup classes): 64 sampled rows, BINS - 1 splitters (measured at 30 Gbp:
+    // 8, 16 or 32 ranges per block all give a blue stage of 0.48-0.50 s; 64 ranges overflow the sub-block table)
+    constexpr int BINS = (SPLIT && NT == 256) ? (CAP > 1024 ? 32 : 16) : 1, SAMPLES = 64;
     __shared__ u64 smp_w[SAMPLES], smp_x[SAMPLES], spl_w[BINS], spl_x[BINS];
-    __shared__ u32 bin_cnt[BINS], bin_start[BINS], bin_cur[BINS];
+    __shared__ u32 bin_cnt[BINS], bin_start[BINS], bin_cur[BINS], bin_slot[BINS];
     const u32 tid = threadIdx.x;
     if (Qdev) { u32 qd = *Qdev; Q = qd < Q ? qd : Q; }           // sub-block table: entries written so far (<= its capacity)
     for (u32 q = blockIdx.x; q < Q; q += gridDim.x) {
@@ -928,6 +929,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                 for (int b = 0; b < BINS; b++) {
                     bin_start[b] = acc; acc += bin_cnt[b];
                     big = bin_cnt[b] > big ? bin_cnt[b] : big;
+                    bin_slot[b] = nonempty;                     // its entry in the sub-block table, counted from sub_base
                     nonempty += bin_cnt[b] ? 1u : 0u;
                 }
                 sub_n = 0;                                      // 0: no hand-off
@@ -942,14 +944,10 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                     const u32 b = sg[x];
                     blue[b0 + bin_start[b] + atomicAdd(&bin_cur[b], 1u)] = se[x];
                 }
-                if (tid == 0) {
-                    u32 e = sub_base;
-                    for (int b = 0; b < BINS; b++)
-                        if (bin_cnt[b]) {
-                            sub.start[e] = b0 + bin_start[b]; sub.freq[e] = bin_cnt[b]; sub.j0[e] = j0 + bin_start[b];
-                            sub.depth[e] = (u32)d0;
-                            e++;
-                        }
+                if (tid < BINS && bin_cnt[tid]) {
+                    const u32 e = sub_base + bin_slot[tid];
+                    sub.start[e] = b0 + bin_start[tid]; sub.freq[e] = bin_cnt[tid]; sub.j0[e] = j0 + bin_start[tid];
+                    sub.depth[e] = (u32)d0;
                 }
                 handed = true; active = false;
             } else {
