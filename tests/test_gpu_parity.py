@@ -426,6 +426,50 @@ def test_multi_range_with_large_blocks_and_many_records(api, oracle):
     d.close()
 
 
+def test_context_reuse_across_range_caps_and_repeated_stage_calls(api, oracle):
+    """One context through what a host may do with it: a build in many key ranges, then the cap lifted and a single-range
+    build (the range fields of the last multi-range build must not leak into it), classification called twice, a load
+    with rejected arguments in between."""
+    from debwt_amd import synth
+    recs = synth.pan_genome(60_000, 3)
+    ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), 32)
+    d = api.DeBWT(k=32)
+    d.load_records(recs)
+    d.set_range_cap(4096)
+    d.build()
+    a = d.fetch()
+    d.set_range_cap(1 << 31)
+    d.build()
+    b = d.fetch()
+    for w, h, dr in (a, b):
+        assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od
+    d.kmer_sort_rle()
+    d.classify()
+    q1 = d.stats()["blue_bound_num"]
+    d.classify()                                               # again: the block tables start over, nothing is appended twice
+    assert d.stats()["blue_bound_num"] == q1
+    d.sp_generate(); d.blue_sort(); d.bwt_assemble()
+    w, h, dr = d.fetch()
+    assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od
+    with pytest.raises(api.DebwtError):
+        d.load_packed(np.zeros(8, dtype=np.uint64), 100, np.array([50], dtype=np.uint64))   # last separator is not n-1
+    d.build()                                                  # rejected arguments leave the loaded text untouched
+    w, h, dr = d.fetch()
+    assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od
+    d.close()
+
+
+def test_shard_world_limit(api):
+    from debwt_amd import _lib, synth
+    d = api.DeBWT(k=32)
+    d.load_records(synth.pan_genome(5000, 2))
+    L = _lib.lib()
+    assert L.debwt_shard_begin(d._h, 0, 256) == -1             # owner tables hold bytes, 0xFF = none
+    assert L.debwt_shard_begin(d._h, 3, 3) == -1
+    assert L.debwt_shard_begin(d._h, 0, 255) == 0
+    d.close()
+
+
 @pytest.mark.parametrize("entry", [e for e in MANIFEST if e["k"] >= 24], ids=golden_id)
 def test_minimizer_prefilter_matches_reference_golden(api, entry):
     """The SP stage's prefilter indexed by minimizers (the form large texts use; tune bit 12 forces it at any size), with
