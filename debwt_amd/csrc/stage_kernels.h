@@ -836,6 +836,9 @@ struct BlueSub {
 #ifndef BLUE_SAMPLE_SPLIT
 #define BLUE_SAMPLE_SPLIT 1
 #endif
+#ifndef BLUE_RANK_MAX
+#define BLUE_RANK_MAX 128u   // workgroup kernels: tie groups up to this size are ordered by counting ranks
+#endif
 template <int NT, int CAP, int SPLIT>
 __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, const u64 *__restrict__ bstart,
                                                      const u32 *__restrict__ mi_freq, const u64 *__restrict__ mi_j0,
@@ -854,14 +857,22 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
     __shared__ u32 sub_n, sub_i, sub_base;
     // sample-sort split of a large block (workgroup classes): 64 sampled rows, BINS - 1 splitters (measured at 30 Gbp:
     // 8, 16 or 32 ranges per block all give a blue stage of 0.48-0.50 s; 64 ranges overflow the sub-block table)
-    constexpr int BINS = (SPLIT && NT == 256) ? (CAP > 1024 ? 32 : 16) : 1, SAMPLES = 64;
+    constexpr int BINS = (SPLIT && NT == 256) ? CAP / 32 : 1, SAMPLES = BINS > 1 ? 4 * BINS : 64;
     __shared__ u64 smp_w[SAMPLES], smp_x[SAMPLES], spl_w[BINS], spl_x[BINS];
     __shared__ u32 bin_cnt[BINS], bin_start[BINS], bin_cur[BINS], bin_slot[BINS];
     const u32 tid = threadIdx.x;
     if (Qdev) { u32 qd = *Qdev; Q = qd < Q ? qd : Q; }           // sub-block table: entries written so far (<= its capacity)
-    for (u32 q = blockIdx.x; q < Q; q += gridDim.x) {
+    // The kernel of a size class walks the whole block table and skips the blocks of the other classes: 64 table
+    // entries per step (one per lane, the same in every wave of the workgroup), a ballot picks the blocks to sort -- one
+    // dependent global load per 64 entries instead of one per entry (the sub-block queue of a 30 Gbp build holds
+    // several 10^7 entries for each of its three kernels to walk).
+    for (u64 q0 = (u64)blockIdx.x * 64; q0 < Q; q0 += (u64)gridDim.x * 64) {
+      const u64 ql = q0 + (tid & 63u);
+      const u32 ml = ql < Q ? mi_freq[ql] : 0u;
+      u64 todo = __ballot(ml > lo_excl && ml <= (u32)CAP);
+      for (; todo; todo &= todo - 1) {
+        const u32 q = (u32)(q0 + (u32)__builtin_ctzll(todo));
         const u32 m = mi_freq[q];
-        if (m <= lo_excl || m > CAP) continue;
         const u64 d0 = depth0 ? depth0[q] : 0;
         u32 maxg = m;
         const u64 b0 = bstart[q];
@@ -882,7 +893,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
         __syncthreads();
         bool active = (flag & (flag - 1)) != 0;               // >= 2 distinct symbols in the block
         __syncthreads();
-        bool handed = false;
+        bool handed = false, preloaded = false;
         if (BLUE_SAMPLE_SPLIT && SPLIT && NT == 256 && active && sub.cap) {
             // Sample-sort split: instead of sorting up to 2048 rows with workgroup-wide bitonic rounds, cut the block
             // into BINS ranges of the first 42 SP symbols (splitters from a sorted sample of 64 rows) and queue every
@@ -933,13 +944,44 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                     nonempty += bin_cnt[b] ? 1u : 0u;
                 }
                 sub_n = 0;                                      // 0: no hand-off
-                if (big <= (u32)SPLIT) {
+                smax = big;
+                if (big > BLUE_RANK_MAX && big <= (u32)SPLIT) {
                     const u32 base = atomicAdd(sub.count, nonempty);
                     if ((u64)base + nonempty <= (u64)sub.cap) { sub_n = nonempty; sub_base = base; }
                 }
             }
             __syncthreads();
-            if (sub_n) {
+            if (smax <= BLUE_RANK_MAX) {
+                // Every range is small enough to be ordered by counting ranks: keep the block here.  The rows move into
+                // range order in LDS, a range becomes a tie group of the first round, whose windows are loaded already --
+                // no hand-off of every range and no second gather of its windows by the wave kernels; only groups that
+                // stay tied behind these 42 symbols with more than one BWT symbol (about 1 % in a pan-genome) are queued.
+                constexpr int EPT = CAP / NT;
+                u32 npos[EPT];
+                u64 ne[EPT], nw[EPT], nx[EPT];
+#pragma unroll
+                for (int c = 0; c < EPT; c++) {
+                    const u32 x = tid + (u32)c * NT;
+                    npos[c] = 0xFFFFFFFFu;
+                    if (x < m) {
+                        const u32 b = sg[x];
+                        npos[c] = bin_start[b] + atomicAdd(&bin_cur[b], 1u);
+                        ne[c] = se[x]; nw[c] = sw[x]; nx[c] = sx[x];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < EPT; c++)
+                    if (npos[c] != 0xFFFFFFFFu) { se[npos[c]] = ne[c]; sw[npos[c]] = nw[c]; sx[npos[c]] = nx[c]; }
+                __syncthreads();
+                if (tid < BINS && bin_cnt[tid]) {
+                    const u32 g = bin_start[tid];
+                    gcnt[g] = bin_cnt[tid]; gmsk[g] = 0x3u;
+                    for (u32 y = g; y < g + bin_cnt[tid]; y++) sg[y] = g;
+                }
+                maxg = smax;
+                preloaded = true;
+            } else if (sub_n) {
                 for (u32 x = tid; x < m; x += NT) {
                     const u32 b = sg[x];
                     blue[b0 + bin_start[b] + atomicAdd(&bin_cur[b], 1u)] = se[x];
@@ -956,7 +998,8 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             __syncthreads();
         }
         for (u64 depth = 0; active; depth++) {
-            // 1. next window of every unresolved row
+            // 1. next window of every unresolved row (the sample-sort split has loaded those of its round already)
+            if (!(preloaded && depth == 0))
             for (u32 x = tid; x < m; x += NT) {
                 u32 g = sg[x];
                 bool unresolved = gcnt[g] > 1 && (gmsk[g] & (gmsk[g] - 1));
@@ -966,9 +1009,22 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                 sx[x] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
             }
             __syncthreads();
+            {   // Rows that tie deeply -- the copies of a repeat in every genome of a collection share hundreds of SP
+                // symbols -- have equal windows round after round: when no unresolved row differs from the first row of
+                // its group there is nothing to order and no group to split, the block moves on to the next windows.
+                u32 differs = 0;
+                for (u32 x = tid; x < m; x += NT) {
+                    const u32 g = sg[x];
+                    if (gcnt[g] > 1 && (gmsk[g] & (gmsk[g] - 1))) differs |= (sw[x] != sw[g] || sx[x] != sx[g]) ? 1u : 0u;
+                }
+                if (!__syncthreads_or((int)differs) && !(preloaded && depth == 0)) {
+                    active = (d0 + depth + 1) * (2 * SP_WIN) < S + 2 * SP_WIN;
+                    continue;
+                }
+            }
             // 2. order every unresolved group by window: small groups by counting ranks inside the group
             //    (cost ~ group size), otherwise a bitonic network on (group, window) over the whole block
-            if (maxg <= 32) {
+            if (maxg <= (NT == 256 ? BLUE_RANK_MAX : 32u)) {
                 constexpr int EPT = CAP / NT;
                 u32 npos[EPT];
                 u64 ne[EPT], nw[EPT], nx[EPT];
@@ -1108,6 +1164,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                 mchar[j0 + x] = (u8)(e & 15);
             }
         __syncthreads();
+      }
     }
 }
 
