@@ -9,7 +9,11 @@
 #define RS_ITEMS 16
 #endif
 #define RS_TILE (RS_BLOCK * RS_ITEMS)   // keys ranked per workgroup iteration
-#define RS_MAXCHUNKS 2048               // workgroups per pass (8 per CU)
+#ifndef RS_MAXCHUNKS
+#define RS_MAXCHUNKS 16384              // most workgroups (chunks) of a pass; see rs_plan
+#endif
+#define RS_MINCHUNKS 2048               // 8 per CU
+#define RS_CHUNK_TILES 64               // tiles a chunk should hold when there are more than RS_MINCHUNKS chunks
 #define RS_RADIX 256
 
 struct RadixWorkspace {
