@@ -1295,7 +1295,8 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
             const u64 *d_list = d_offs + nover;
             u32 grid = (u32)((total + 255) / 256);
             rs_over_move<<<grid, 256, 0, stream>>>(src, scratch, d_list, d_offs, nover, total, 0);
-            u64 *r = rs_lsd(stream, scratch, tmp, total, 0, key_bits, ws, nullptr, 0, nullptr);
+            // (the auxiliary kernel names: these short passes must not dilute the profile of the key-range passes)
+            u64 *r = rs_lsd(stream, scratch, tmp, total, 0, key_bits, ws, nullptr, 0, nullptr, nullptr, true);
             rs_over_move<<<grid, 256, 0, stream>>>(src, r, d_list, d_offs, nover, total, 1);
             if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;   // offs is host memory
         }
