@@ -137,7 +137,20 @@ def main():
     if args.backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    D.init(backend=args.backend, device_id=torch.device("cuda", local_rank), force=args.force_sharded)
+    # RCCL prints a version banner to stdout when its first communicator comes up: send it to stderr, stdout carries
+    # the one JSON line
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        D.init(backend=args.backend, device_id=torch.device("cuda", local_rank), force=args.force_sharded)
+        if world > 1 or args.force_sharded:
+            D.sum_over_ranks(1, tensor_device="cuda" if args.backend == "nccl" else "cpu")
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     tdev = "cuda" if args.backend == "nccl" else "cpu"
     device = torch.device("cuda", local_rank)
     sharded = (world > 1 and args.mode != "replicas") or args.force_sharded
