@@ -487,18 +487,28 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
     lds_barrier();
     const u64 nwords = beg < end ? (end - beg + 31) >> 5 : 0;
     u32 ndense = 0;                                           // keys in the tile buffer (uniform)
+    // this lane's words of the next round are fetched while the current round is worked on (two workgroups per CU do
+    // not hide a global load that is waited for right away)
+    u64 nw0 = 0, nw1 = 0, nwp = 0, nsa = 0, nsb = 0;
+    auto fetch = [&](u64 wb) {
+        const u64 i0 = beg + ((wb + tid) << 5);
+        if (wb < nwords && i0 < end) {
+            const u64 p = ts.pos0 + i0, g = p >> 5;
+            nw0 = ts.text[g]; nw1 = ts.text[g + 1];
+            nwp = g ? ts.text[g - 1] : 3ull;                   // the 'T' that stands at separators goes before the text
+            nsa = ts.sepbits[p >> 6]; nsb = ts.sepbits[(p >> 6) + 1];
+        }
+    };
+    fetch(0);
     for (u64 wbase = 0;; wbase += SC_NT) {
         const bool more = wbase < nwords;                     // uniform; the round after the last word flushes the rest
         const u64 idx0 = beg + ((wbase + tid) << 5);          // first item of this lane's word
         u32 m = 0;
-        u64 w0 = 0, w1 = 0, wp = 0;
-        u64 g = 0;
+        const u64 w0 = nw0, w1 = nw1, wp = nwp, sa = nsa, sbw = nsb;
+        if (more) fetch(wbase + SC_NT);
         if (more && idx0 < end) {
-            const u64 p = ts.pos0 + idx0;                      // text position, a multiple of 32
-            g = p >> 5;
-            w0 = ts.text[g]; w1 = ts.text[g + 1];
-            wp = g ? ts.text[g - 1] : 3ull;                    // the 'T' that stands at separators goes before the text
-            const u64 sb = sep_window(ts.sepbits, p);          // bit t: separator at p + t
+            const u32 shp = (u32)((ts.pos0 + idx0) & 63ull);   // 0 or 32
+            const u64 sb = shp ? (sa >> 32) | (sbw << 32) : sa; // bit t: separator at the word's position + t
             const u32 lim = end - idx0 < 32 ? (u32)(end - idx0) : 32u;
 #pragma unroll
             for (u32 t = 0; t < 32; t++) {
