@@ -963,6 +963,59 @@ __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ ke
     for (u32 i = lane; i < cnt; i += 64) keys[s + i] = A[RL_PAD(i)];
 }
 
+// The unfit stretches of the counting finish, sorted where they lie: one workgroup per stretch of the list
+// rs_local_count_kernel wrote (a stretch = the buckets between two wave-tile starts, so it is bucket-aligned and can be
+// sorted on its own).  The 4096-key tiles of rs_local_kernel<256> are cut on a fixed raster and every unfit stretch
+// marks the two or three tiles that overlap it: in a collection of many genomes, where a quarter of the wave tiles
+// are unfit, 70 % of all tiles ended up in the network, each re-sorting up to 4096 keys around a stretch of ~1500.
+// A stretch above 4096 keys goes to the list of the all-HBM path, as before.
+__global__ __launch_bounds__(256) void rs_local_unfit_kernel(u64 *__restrict__ keys, u64 n, const u64 *__restrict__ bnd,
+                                                             u32 nwtiles, const u32 *__restrict__ unfit,
+                                                             const u32 *__restrict__ nunfit, u32 *__restrict__ over,
+                                                             u32 over_cap) {
+    constexpr int KPT = 16, NT = 256;
+    constexpr u32 CAP = NT * KPT;
+    __shared__ u64 A[CAP + CAP / 16];
+    const u32 tid = threadIdx.x;
+    const u32 nu = *nunfit;
+    for (u32 i = blockIdx.x; i < nu; i += gridDim.x) {
+        const u32 t = unfit[i];
+        const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
+        const u64 cnt64 = e - s;
+        __syncthreads();                                              // A of the stretch before has been read
+        if (cnt64 > CAP) {
+            // often one long run of equal keys (a repeat family's k-mer in every genome): nothing to do when in order
+            u32 bad = 0;
+            for (u64 j = s + tid; j + 1 < e && !bad; j += NT) bad = keys[j] > keys[j + 1] ? 1u : 0u;
+            if (__syncthreads_or((int)bad) && tid == 0) {
+                const u32 idx = atomicAdd(&over[0], 1u);
+                if (idx < over_cap) {
+                    u64 *list = reinterpret_cast<u64 *>(over + 4);
+                    list[2 * idx] = s; list[2 * idx + 1] = cnt64;
+                }
+            }
+            continue;
+        }
+        const u32 cnt = (u32)cnt64;
+        for (u32 j = tid; j < CAP; j += NT) A[RL_PAD(j)] = j < cnt ? keys[s + j] : ~0ull;
+        __syncthreads();
+        u64 k[KPT];
+#pragma unroll
+        for (int r = 0; r < KPT; r++) k[r] = A[RL_PAD(tid * KPT + r)];
+        u32 bad = 0;
+#pragma unroll
+        for (int r = 0; r + 1 < KPT; r++) bad |= k[r] > k[r + 1] ? 1u : 0u;
+        if (tid + 1 < NT) bad |= k[KPT - 1] > A[RL_PAD((tid + 1) * KPT)] ? 1u : 0u;
+        if (!__syncthreads_or((int)bad)) continue;                    // in order already
+        if (cnt <= CAP / 2) rl_network<11>(k, A, tid, tid < NT / 2);
+        else rl_network<12>(k, A, tid, true);
+#pragma unroll
+        for (int r = 0; r < KPT; r++) A[RL_PAD(tid * KPT + r)] = k[r];
+        __syncthreads();
+        for (u32 j = tid; j < cnt; j += NT) keys[s + j] = A[RL_PAD(j)];
+    }
+}
+
 // exclusive scan of the tile counts: within blocks of 4096 tiles (tex) + the block offsets (boff), added by the readers
 #define RLT_BLOCK 4096
 __global__ __launch_bounds__(256) void rs_tile_scan1_kernel(const u32 *__restrict__ tcnt, u32 nwtiles,
@@ -1269,10 +1322,12 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
         rle_boff = rle_bsum + rle_nb(n);
         (void)hipMemsetAsync(rle_ctr, 0, 16, stream);
         rs_local_count_kernel<<<nwtiles, 64, 0, stream>>>(src, n, pshift, mark, rle_bnd, rle_unfit, rle_ctr, rle_tcnt, sink->mchar);
+        rs_local_unfit_kernel<<<nwtiles < 16384u ? nwtiles : 16384u, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr,
+                                                                                        ws.over, ws.over_cap);
     } else {
         rs_local_kernel<64><<<nwtiles, 64, 0, stream>>>(src, n, pshift, ws.over, ws.over_cap, mark);
+        rs_local_kernel<256><<<ntiles, 256, 0, stream>>>(src, n, pshift, ws.over, ws.over_cap, mark);
     }
-    rs_local_kernel<256><<<ntiles, 256, 0, stream>>>(src, n, pshift, ws.over, ws.over_cap, mark);
     (void)hipMemcpyAsync(ws.h_over, ws.over, 16, hipMemcpyDeviceToHost, stream);
     if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;
     u32 nover = ws.h_over[0];
