@@ -118,10 +118,18 @@ namespace {
 
 int ensure(debwt_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return DEBWT_OK;
+    static const bool trace = getenv("DEBWT_TRACE_ALLOC") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t old = b.cap;
     if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const auto t1 = std::chrono::steady_clock::now();
     size_t want = bytes + bytes / 16 + 256;
     HIPCHK(c, hipMalloc(&b.p, want));
     b.cap = want;
+    if (trace && want > (64u << 20))
+        fprintf(stderr, "ensure: %.2f GB (was %.2f): sync+free %.1f ms, malloc %.1f ms\n", want / 1e9, old / 1e9,
+                std::chrono::duration<float, std::milli>(t1 - t0).count(),
+                std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t1).count());
     return DEBWT_OK;
 }
 #define ENSURE(c, b, bytes) do { int r_ = ensure((c), (b), (bytes)); if (r_) return r_; } while (0)
