@@ -866,9 +866,12 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
     // entries per step (one per lane, the same in every wave of the workgroup), a ballot picks the blocks to sort -- one
     // dependent global load per 64 entries instead of one per entry (the sub-block queue of a 30 Gbp build holds
     // several 10^7 entries for each of its three kernels to walk).
-    for (u64 q0 = (u64)blockIdx.x * 64; q0 < Q; q0 += (u64)gridDim.x * 64) {
+    // (a table too short to give every workgroup 64 entries is walked one entry per workgroup and step, as before:
+    // otherwise a few workgroups would sort 64 blocks each one after the other while the rest idle)
+    const u32 E = (u64)Q >= (u64)gridDim.x * 64 ? 64u : 1u;
+    for (u64 q0 = (u64)blockIdx.x * E; q0 < Q; q0 += (u64)gridDim.x * E) {
       const u64 ql = q0 + (tid & 63u);
-      const u32 ml = ql < Q ? mi_freq[ql] : 0u;
+      const u32 ml = ((tid & 63u) < E && ql < Q) ? mi_freq[ql] : 0u;
       u64 todo = __ballot(ml > lo_excl && ml <= (u32)CAP);
       for (; todo; todo &= todo - 1) {
         const u32 q = (u32)(q0 + (u32)__builtin_ctzll(todo));
