@@ -121,10 +121,12 @@ def main():
     ap.add_argument("--tune", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # gloo: ranks may share one GPU (tests)
     ap.add_argument("--force-sharded", action="store_true", help=argparse.SUPPRESS)   # the N>1 code path at N = 1 (tests)
-    ap.add_argument("--mode", choices=["exchange", "scan", "replicas"], default="exchange",
-                    help="N>1: 'exchange' (default) = ONE collection built by N k-mer-prefix shards with the key and "
-                         "blue-entry all_to_all exchanges; 'scan' = the same shards, every GPU scanning the whole text "
-                         "instead of exchanging keys; 'replicas' = N independent collections (no collective)")
+    ap.add_argument("--mode", choices=["auto", "exchange", "rescan", "scan", "replicas"], default="auto",
+                    help="N>1: ONE collection built by N k-mer-prefix shards; SP symbols, facts, blue entries and the "
+                         "final rows always travel over RCCL.  'exchange' = the 8-byte keys travel too (all_to_all per "
+                         "key range); 'rescan' = every GPU reads its own copy of the text once per key range instead; "
+                         "'auto' (default) = the cheaper of the two by the library's cost model (debwt_shard_key_mode); "
+                         "'scan' = no bulk exchange at all; 'replicas' = N independent collections (no collective)")
     args = ap.parse_args()
 
     import torch
@@ -175,7 +177,7 @@ def main():
     d.load_packed(text.a, n, sep)                 # text -> HBM before the timed region
     t_load = time.perf_counter() - t0
 
-    acc = {"pass_ms": 0.0, "pass_launches": 0, "stage": {}, "timed": False, "xfer": {}}
+    acc = {"pass_ms": 0.0, "pass_launches": 0, "stage": {}, "timed": False, "xfer": {}, "info": {}}
     shard_ws = SH.Workspace(d, device, mode=args.mode) if sharded else None
 
     def step():
@@ -183,7 +185,10 @@ def main():
             info = SH.build_sharded(d, shard_ws)          # collectives and the final concat inside
             if acc["timed"]:
                 for key, v in info.items():
-                    acc["xfer"][key] = acc["xfer"].get(key, 0.0) + v / args.steps
+                    if isinstance(v, (int, float)):
+                        acc["xfer"][key] = acc["xfer"].get(key, 0.0) + v / args.steps
+                    else:
+                        acc["info"][key] = v
         else:
             d.build()                                     # synchronous: returns after the context's stream drained
         if acc["timed"]:
@@ -260,7 +265,7 @@ def main():
                 traffic = None
         if sharded:
             par = (f"one collection of {nrec} records ({n} bases) built by {world} k-mer-prefix shards "
-                   f"({args.mode} mode), text replicated in the HBM of every GPU, result concatenated on rank 0")
+                   f"(keys: {acc['info'].get('keys', args.mode)}), text replicated in the HBM of every GPU, result concatenated on rank 0")
         elif world > 1:
             par = f"{world} independent collections, one per GPU"
         else:
@@ -288,6 +293,7 @@ def main():
         }
         if sharded:
             line["exchange"] = {k_: round(v, 3) for k_, v in acc["xfer"].items()}
+            line["exchange"].update(acc["info"])
         if args.gpus == 1 and not args.no_cpu_baseline:
             threads = SN.default_threads()
             ref = cpu_reference(syn.codes(0, 0, min(args.cpu_sample, int(syn._lens[0]))), args.k, threads)

@@ -1,7 +1,7 @@
 /*
  * debwt.c -- host program with the reference's command line over libdebwt_hip.so.
  *
- *   deBWT -o OUT [-t T] [-k K] [-j DIR] [--device D | --gpus G [--devices a,b,...]] [--iupac SEED] INPUT.fa[.gz]
+ *   deBWT -o OUT [-t T] [-k K] [-j DIR] [--device D | --gpus G [--devices a,b,...] [--keys auto|exchange|rescan]] [--iupac SEED] INPUT.fa[.gz]
  *
  * Same contract as /root/reference/src/main.c:25-53,175-186: options are `flag value` pairs, INPUT last;
  * -k 12..32 (default 32); -t (default 8) = host threads of the FASTA ingest; -j accepted and ignored (no Jellyfish); OUT is probed by create+remove before any work
@@ -28,6 +28,8 @@ static void usage(void) {
                     "--device (optional): GPU ordinal (default 0)\n"
                     "--gpus (optional): build with G GPUs (k-mer-prefix shards, one host thread per GPU, exchanges over xGMI)\n"
                     "--devices (optional): comma-separated GPU ordinals of the G shards (default 0,1,...; may repeat)\n"
+                    "--keys (optional): with --gpus, how the k-mers reach their shard: exchange (alltoallv of the keys), rescan (every\n"
+                    "       GPU reads its own copy of the text), auto (default: the cheaper one by the library's cost model)\n"
                     "--iupac (optional): seed; N and other ambiguity letters become pseudo-random bases of their sets\n"
                     "                    (what otherTool/transferN does, reproducibly)\n"
                     "reference: sequence in fasta format (plain or gzip)\n");
@@ -63,12 +65,13 @@ static int write_outputs(const char *obj, const uint64_t *bwt, uint64_t n, const
 
 /* --gpus G: the same program over G GPUs (debwt_multi_*: one host thread per GPU inside the library) */
 static int multi_main(const char *source, const char *obj, int k, int threads, int iupac, unsigned long long seed, int gpus,
-                      const int *devs) {
+                      const int *devs, int key_mode) {
     double t0 = now();
     debwt_config cfg = {k, 0, 0, 0};
     debwt_multi *m = NULL;
     int rc = debwt_multi_create(&cfg, devs, gpus, &m);
     if (rc) { fprintf(stderr, "debwt_multi_create (%d GPUs): %s\n", gpus, debwt_strerror(rc)); return 1; }
+    debwt_multi_set_key_mode(m, key_mode);
     double t1 = now();
     rc = debwt_multi_load_fasta(m, source, threads, iupac ? DEBWT_FASTA_IUPAC_RANDOM : 0u, seed);
     if (rc) {
@@ -89,8 +92,9 @@ static int multi_main(const char *source, const char *obj, int k, int threads, i
     double t4 = now();
     if (!rc) {
         printf("BWTLEN=%lu\n", (unsigned long)st.n);
-        printf("%u GPUs, %u exchange round(s): init %.3f s, read+pack+load (%d threads) %.3f s, build %.3f s, fetch+write %.3f s; "
-               "shard 0 received %.3f GB of k-mers and %.3f GB of blue entries\n", st.ngpus, st.rounds, t1 - t0, threads, t2 - t1,
+        printf("%u GPUs, keys %s, %u key round(s): init %.3f s, read+pack+load (%d threads) %.3f s, build %.3f s, fetch+write %.3f s; "
+               "shard 0 received %.3f GB of k-mers and %.3f GB of blue entries\n", st.ngpus,
+               st.key_mode == DEBWT_KEYS_EXCHANGE ? "exchanged" : "rescanned", st.rounds, t1 - t0, threads, t2 - t1,
                t3 - t2, t4 - t3, st.key_bytes_in / 1e9, st.blue_bytes_in / 1e9);
         fprintf(stderr, "success output bwt!\n");
     } else fprintf(stderr, "fetch/write: %s\n", debwt_strerror(rc));
@@ -102,7 +106,7 @@ static int multi_main(const char *source, const char *obj, int k, int threads, i
 int main(int argc, char **argv) {
     if (argc < 4 || (argc & 1) == 1) { usage(); return 1; }            /* src/main.c:25 */
     const char *source = argv[argc - 1], *obj = NULL;
-    int k = 32, device = 0, iupac = 0, gpus = 0, devs[256], ndevs = 0;
+    int k = 32, device = 0, iupac = 0, gpus = 0, devs[256], ndevs = 0, key_mode = -1;
     unsigned long long iupac_seed = 0;
     long threads = 8;
     for (int i = 1; i < argc - 1; i += 2) {
@@ -124,6 +128,12 @@ int main(int argc, char **argv) {
                 if (*p == ',') p++;
             }
         }
+        else if (!strcmp(argv[i], "--keys")) {
+            if (!strcmp(argv[i + 1], "exchange")) key_mode = DEBWT_KEYS_EXCHANGE;
+            else if (!strcmp(argv[i + 1], "rescan")) key_mode = DEBWT_KEYS_RESCAN;
+            else if (!strcmp(argv[i + 1], "auto")) key_mode = -1;
+            else { usage(); return 1; }
+        }
         else if (!strcmp(argv[i], "--iupac")) { iupac = 1; iupac_seed = strtoull(argv[i + 1], NULL, 10); }
         else { usage(); return 1; }
     }
@@ -135,7 +145,7 @@ int main(int argc, char **argv) {
 
     fprintf(stderr, "run deBWT (MI355X path): sequence file %s, output %s, k-mer length %d\n", source, obj, k);
     if (gpus) return multi_main(source, obj, k, (int)(threads > 256 ? 256 : threads), iupac, iupac_seed, gpus,
-                                ndevs == gpus ? devs : NULL);
+                                ndevs == gpus ? devs : NULL, key_mode);
     double t0 = now();
     debwt_config cfg = {k, device, 0, 0};
     debwt_ctx *ctx = NULL;

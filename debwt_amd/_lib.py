@@ -45,7 +45,8 @@ class DebwtVerifyReport(ctypes.Structure):
 
 class DebwtMultiStats(ctypes.Structure):
     _fields_ = [("n", ctypes.c_uint64), ("nrec", ctypes.c_uint64), ("ngpus", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
-                ("key_bytes_in", ctypes.c_uint64), ("blue_bytes_in", ctypes.c_uint64), ("ms_build", ctypes.c_float)]
+                ("key_bytes_in", ctypes.c_uint64), ("blue_bytes_in", ctypes.c_uint64), ("ms_build", ctypes.c_float),
+                ("key_mode", ctypes.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -63,7 +64,8 @@ SYMBOLS = [
     "debwt_shard_sort_range", "debwt_shard_sort_end", "debwt_concat_rows", "debwt_shard_export", "debwt_census_words", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
     "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_verify_device", "debwt_multi_create", "debwt_multi_destroy", "debwt_multi_last_error",
     "debwt_multi_load_text", "debwt_multi_load_fasta", "debwt_multi_build", "debwt_multi_fetch_bwt", "debwt_multi_get_stats",
-    "debwt_multi_verify", "debwt_multi_shard", "debwt_pinned_alloc", "debwt_pinned_free",
+    "debwt_multi_verify", "debwt_multi_shard", "debwt_pinned_alloc", "debwt_pinned_free", "debwt_shard_key_mode",
+    "debwt_multi_set_key_mode",
 ]
 
 
@@ -140,6 +142,11 @@ def lib():
     L.debwt_shard_plan.restype = ctypes.c_int
     L.debwt_shard_plan.argtypes = [vp, u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int,
                                    ctypes.c_uint64, u32p]
+    L.debwt_shard_key_mode.restype = ctypes.c_int
+    L.debwt_shard_key_mode.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(ctypes.c_double)]
+    L.debwt_multi_set_key_mode.restype = ctypes.c_int
+    L.debwt_multi_set_key_mode.argtypes = [vp, ctypes.c_int]
     L.debwt_shard_ranges.restype = ctypes.c_int
     L.debwt_shard_ranges.argtypes = [vp, u32p, u64p, ctypes.c_uint32]
     L.debwt_shard_sort_begin.restype = ctypes.c_int

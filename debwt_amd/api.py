@@ -245,6 +245,10 @@ class MultiDeBWT:
     def load_records(self, records):
         self.load_packed(*pack_records(records))
 
+    def set_key_mode(self, mode):
+        """"exchange", "rescan" or "auto" (the library's cost model decides): how the keys reach their shards."""
+        self._chk(self._L.debwt_multi_set_key_mode(self._h, {"exchange": 0, "rescan": 1, "auto": -1}[mode]))
+
     def build(self):
         self._chk(self._L.debwt_multi_build(self._h))
 

@@ -1309,16 +1309,40 @@ extern "C" int debwt_shard_plan(debwt_ctx *c, const uint64_t *hist4096, uint32_t
         // key buffer A); the later stages hold ~3.5 bytes per position of the shard's share (row symbols, blue
         // entries and their routed form, BWT) and ~1.25 bytes per position of the whole text (2-bit text, flag
         // masks, SP code and its gather buffers, node table, the concatenated BWT on the gathering rank)
-        int rc = default_range_cap(c, exchange ? 40 : 30,
-                                   c->n / (u64)c->shard_world / 2 * 7 + c->n / 4 * 5 + (8ull << 30), caller_held_bytes, &cap);
+        // exchange == 2 (keys rescanned, SP code and blue entries sliced): the caller's two blue-entry buffers come
+        // after the sort, ~2 bytes per position of the share (8 bytes x 2 x ~0.1 multi-in positions per base)
+        const u64 share = c->n / (u64)c->shard_world;
+        int rc = default_range_cap(c, exchange == 1 ? 40 : 30,
+                                   share / 2 * 7 + (exchange == 2 ? share * 2 : 0) + c->n / 4 * 5 + (8ull << 30),
+                                   caller_held_bytes, &cap);
         if (rc) return rc;
     }
     int rc = cut_ranges(c, reinterpret_cast<const u64 *>(hist4096), bin_lo, bin_hi, cap, m);
     if (rc) return rc;
-    c->shard_planned = true; c->exchange = exchange != 0; c->plan_valid = false;
+    c->shard_planned = true; c->exchange = exchange == 1; c->plan_valid = false;
     c->stage = ST_LOADED;
     *nranges = (u32)c->ranges.size();
     return DEBWT_OK;
+}
+
+// Key exchange or key rescan (include/debwt_hip.h).  Per-GPU milliseconds of what differs between the two, calibrated
+// on 30 Gbp builds in a process group of one (profiles/r02_v14_bench_30G_keys_*.json):
+//   rescan    a first radix pass that reads the whole text and keeps one key range takes 32.3 ms per 30 Gbp read, the
+//             histogram pass before it about as much                          -> 2.2 ms per Gbp read and key range
+//   exchange  sort stage 2195 ms against 1230 ms: the slice is read once per round, its keys are written grouped by
+//             owner, copied (208 ms of that: 6.9 ms per Gbp when the copy stays in HBM) and then take an ordinary first
+//             pass                                                            -> 40 ms per Gbp of the shard's share
+//             plus 8 n / world^2 bytes over every link
+extern "C" int debwt_shard_key_mode(uint64_t n, int world, double link_gbytes_per_s, double *exchange_ms, double *rescan_ms) {
+    if (world < 1) world = 1;
+    const double link = link_gbytes_per_s > 0 ? link_gbytes_per_s : 48.0;
+    const double gbp = (double)n * 1e-9, share = gbp / world;
+    const double ranges = std::max(1.0, std::ceil(share / 4.29));          // < 2^32 - 2^20 keys per range
+    const double t_rescan = ranges * gbp * 2.2;
+    const double t_exchange = share * 40.0 + share / world * 6.9 + (world > 1 ? share / world * 8.0 / link * 1e3 : 0.0);
+    if (exchange_ms) *exchange_ms = t_exchange;
+    if (rescan_ms) *rescan_ms = t_rescan;
+    return t_exchange < t_rescan ? DEBWT_KEYS_EXCHANGE : DEBWT_KEYS_RESCAN;
 }
 
 extern "C" int debwt_shard_ranges(debwt_ctx *c, uint32_t *bin_bounds, uint64_t *m_keys, uint32_t capacity) {

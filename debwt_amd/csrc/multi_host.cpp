@@ -73,6 +73,7 @@ struct debwt_multi {
     uint64_t dollar_row = ~0ull;
     std::string err;
     bool built = false;
+    int key_mode = -1;                      // DEBWT_KEYS_EXCHANGE / DEBWT_KEYS_RESCAN, -1: debwt_shard_key_mode decides
     debwt_multi_stats st{};
     // what the threads publish for each other
     std::vector<std::vector<uint64_t>> hist, offs, boffs;
@@ -131,7 +132,9 @@ void shard_thread(debwt_multi *m, int r) {
     uint32_t nr = 0;
     const uint64_t held = m->xa[r].cap + m->xb[r].cap + m->facts[r].cap + m->allfacts[r].cap + m->sp[r].cap + m->allsp[r].cap +
                           m->part[r].cap + (r == 0 ? m->parts.cap + m->out.cap : 0);
-    STEP(debwt_shard_plan(c, total.data(), bins[r], bins[r + 1], cum[bins[r]], 1, held, &nr), "shard_plan");
+    const int keys = m->key_mode >= 0 ? m->key_mode : debwt_shard_key_mode(m->n, G, 0.0, nullptr, nullptr);
+    const bool exchange = keys == DEBWT_KEYS_EXCHANGE;
+    STEP(debwt_shard_plan(c, total.data(), bins[r], bins[r + 1], cum[bins[r]], exchange ? 1 : 2, held, &nr), "shard_plan");
     std::vector<uint64_t> mk(MAXR, 0);
     m->cuts[r].assign(MAXR + 1, 0);
     if (!rc) STEP(debwt_shard_ranges(c, m->cuts[r].data(), mk.data(), MAXR), "shard_ranges");
@@ -139,12 +142,14 @@ void shard_thread(debwt_multi *m, int r) {
     if (!rv.sync(rc)) return;
     size_t rounds = 0;
     for (int s = 0; s < G; s++) rounds = std::max(rounds, m->cuts[s].size() - 1);
-    if (r == 0) m->st.rounds = (uint32_t)rounds;
+    if (r == 0) { m->st.rounds = (uint32_t)rounds; m->st.key_mode = (uint32_t)keys; }
 
-    // 2. the k-mer bucket exchange, one round per key range
-    STEP(debwt_shard_sort_begin(c), "shard_sort_begin");
+    // 2. the keys of the shard's ranges: read from the shard's own copy of the text (key rescan) ...
+    if (!exchange) STEP(debwt_kmer_sort_rle(c), "kmer_sort_rle");
+    // ... or the k-mer bucket exchange, one round per key range
+    if (exchange) STEP(debwt_shard_sort_begin(c), "shard_sort_begin");
     if (!rv.sync(rc)) return;
-    for (size_t t = 0; t < rounds; t++) {
+    for (size_t t = 0; exchange && t < rounds; t++) {
         std::vector<uint8_t> tab(BINS, 0xFF);
         for (int s = 0; s < G; s++)
             if (t + 1 < m->cuts[s].size())
@@ -165,7 +170,7 @@ void shard_thread(debwt_multi *m, int r) {
         if (t + 1 < m->cuts[r].size()) STEP(debwt_shard_sort_range(c, (uint32_t)t, (uint64_t *)m->xb[r].p, nrecv), "shard_sort_range");
         if (!rv.sync(rc)) return;
     }
-    STEP(debwt_shard_sort_end(c), "shard_sort_end");
+    if (exchange) STEP(debwt_shard_sort_end(c), "shard_sort_end");
 
     // 3. local classification totals, red table from everybody's facts
     if (!rc) STEP(debwt_shard_classify_local(c, &m->nfacts[r], &m->nblocks[r], &m->brows[r]), "shard_classify_local");
@@ -331,6 +336,12 @@ extern "C" int debwt_multi_load_fasta(debwt_multi *m, const char *path, int thre
     if (m->own.words) debwt_free_packed(&m->own);
     m->own = pt;                                                  // the contexts read the host text during a build
     return rc;
+}
+
+extern "C" int debwt_multi_set_key_mode(debwt_multi *m, int key_mode) {
+    if (!m || key_mode < -1 || key_mode > DEBWT_KEYS_RESCAN) return DEBWT_EINVAL;
+    m->key_mode = key_mode;
+    return DEBWT_OK;
 }
 
 extern "C" int debwt_multi_build(debwt_multi *m) {

@@ -3,7 +3,7 @@
 Every rank holds the whole 2-bit text (n/4 bytes: all-gathering the text costs 1/32 of an alltoallv of the
 64-bit k-mers and removes the halo).  Rank r sorts and classifies the keys of one prefix range -- in several
 key ranges, one exchange round each, when they do not fit its HBM at once -- and owns the contiguous BWT rows
-of those nodes and their multi-in blocks.  The exchanges of the default ("exchange") mode:
+of those nodes and their multi-in blocks.  The exchanges of a build whose keys travel ("exchange" mode):
 
   all_gather  4096-bin k-mer prefix census of every rank's text slice   -> splitters (balanced instance counts,
                                                                            the reference's segCount idea,
@@ -20,8 +20,12 @@ of those nodes and their multi-in blocks.  The exchanges of the default ("exchan
 over torch.distributed ("nccl" = RCCL over xGMI on the GPU node, tensors stay in HBM; "gloo" in the tests, where
 the ranks may even share one GPU and the tensors are staged through host memory).
 
-"scan" mode has no bulk exchange: every rank reads the whole text, keeps the keys of its ranges in the first radix
-pass and computes the SP code in full -- good for 2-4 GPUs, O(n) text work per GPU.
+"rescan" mode drops the first ALL_TO_ALL: every rank holds the text anyway, so it reads all of it once per key range
+and keeps the keys of its ranges in the first radix pass -- n/4 bytes from its own HBM per range instead of
+8 n / world bytes over the fabric; everything after the sort is sliced and exchanged as above.  "auto" (the default)
+asks the library's cost model (debwt_shard_key_mode) which of the two is cheaper; on one node of up to 8 GPUs that
+is "rescan".  "scan" mode has no bulk exchange at all: keys as in "rescan", and the SP code computed in full on every
+rank (tests; O(n) text work per GPU).
 """
 import ctypes
 import os
@@ -36,6 +40,7 @@ from .api import DebwtError
 
 SHARD_BINS = 4096
 MAX_RANGES = 64            # key ranges (exchange rounds) a shard may need
+MODES = ("auto", "exchange", "rescan", "scan")
 
 
 # ---- pure host logic (tested on CPU) ---------------------------------------------------------------------------
@@ -111,6 +116,8 @@ def _on_device():
 # on send/recv, and a 30 Gbp build moves up to 3.75 GB per peer: every collective here is cut into calls of at most
 # P2P_MAX bytes per peer message.
 P2P_MAX = int(os.environ.get("DEBWT_P2P_MAX_BYTES", str(1 << 29)))
+# sustained one-direction rate of one GPU-to-GPU link for the key-path cost model (0: the library's default)
+LINK_GBYTES_PER_S = float(os.environ.get("DEBWT_LINK_GBYTES_PER_S", "0"))
 
 
 def _global_max(value):
@@ -185,8 +192,8 @@ class Workspace:
     """Exchange buffers of one rank: GPU tensors that grow on demand and live across builds, so that a steady-state
     build allocates nothing and the library's own buffers never compete with a caching allocator's leftovers."""
 
-    def __init__(self, d, device=None, mode="exchange"):
-        assert mode in ("exchange", "scan")
+    def __init__(self, d, device=None, mode="auto"):
+        assert mode in MODES
         self.d, self.mode = d, mode
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.buf = {}
@@ -242,15 +249,20 @@ def build_sharded(d, ws=None, mode=None, device=None):
     """Run the sharded stage sequence on this rank's context `d` (text already loaded, the same text on every rank)
     and concatenate the shards' rows on rank 0 (ws.result).  Returns a dict of what the exchanges moved and took."""
     if ws is None:
-        ws = Workspace(d, device, mode or "exchange")
+        ws = Workspace(d, device, mode or "auto")
     L = _lib.lib()
     rank, world = dist.get_rank(), dist.get_world_size()
     device = ws.device
-    exchange = ws.mode == "exchange"
+    est_x, est_r = ctypes.c_double(), ctypes.c_double()
+    choice = L.debwt_shard_key_mode(d.n, world, LINK_GBYTES_PER_S, ctypes.byref(est_x), ctypes.byref(est_r))
+    keys = ws.mode if ws.mode != "auto" else ("exchange" if choice == 0 else "rescan")
+    exchange = keys == "exchange"               # the keys travel
+    sliced = keys != "scan"                     # SP code and blue entries by text slice, then exchanged
     u64p, u8p, u32p = (ctypes.POINTER(t) for t in (ctypes.c_uint64, ctypes.c_uint8, ctypes.c_uint32))
     sync = lambda: torch.cuda.synchronize(device)            # torch's stream <-> the context's own stream
     info = {"key_exchange_ms": 0.0, "key_exchange_GB": 0.0, "blue_exchange_ms": 0.0, "blue_exchange_GB": 0.0,
-            "facts_sp_gather_ms": 0.0, "concat_ms": 0.0, "rounds": 0}
+            "facts_sp_gather_ms": 0.0, "concat_ms": 0.0, "rounds": 0, "keys": keys,
+            "model_ms": {"exchange": round(est_x.value, 1), "rescan": round(est_r.value, 1)}}
 
     # 1. census of the slices -> splitters over the shards, key ranges inside every shard
     _chk(d, L.debwt_shard_begin(d._h, rank, world))
@@ -261,7 +273,8 @@ def build_sharded(d, ws=None, mode=None, device=None):
     bins, cum = plan_splitters(total, world)
     nr = ctypes.c_uint32()
     _chk(d, L.debwt_shard_plan(d._h, np.ascontiguousarray(total).ctypes.data_as(u64p), bins[rank], bins[rank + 1],
-                               int(cum[bins[rank]]), 1 if exchange else 0, ws.held_bytes(), ctypes.byref(nr)))
+                               int(cum[bins[rank]]), 1 if exchange else (2 if sliced else 0), ws.held_bytes(),
+                               ctypes.byref(nr)))
     bounds = np.zeros(MAX_RANGES + 1, dtype=np.uint32)
     mkeys = np.zeros(MAX_RANGES, dtype=np.uint64)
     _chk(d, L.debwt_shard_ranges(d._h, bounds.ctypes.data_as(u32p), mkeys.ctypes.data_as(u64p), MAX_RANGES))
@@ -307,7 +320,7 @@ def build_sharded(d, ws=None, mode=None, device=None):
     info["facts_sp_gather_ms"] += (time.perf_counter() - t0) * 1e3
     _chk(d, L.debwt_shard_classify_global(d._h, ctypes.c_void_p(facts.data_ptr()), nfacts, qbase, blue_total))
 
-    if exchange:
+    if sliced:
         # 4. SP code: flags of my slice, offsets from the slice lengths (the reference's spSplit prefix,
         #    src/generateSP.c:152-157), symbols all-gathered
         s_loc, b_loc = ctypes.c_uint64(), ctypes.c_uint64()

@@ -159,18 +159,31 @@ void debwt_pinned_free(void *p);
  * fit HBM at once -- and owns the BWT rows and the multi-in blocks of those nodes.
  * The collectives (bracketed) are the caller's (debwt_amd/sharded.py uses torch.distributed: RCCL or gloo).
  *
- * Exchange mode (the default; per-GPU work is O(n / world): every shard scans only its 1/world slice of the text):
- *   load -> shard_begin -> shard_histogram -> [all-gather of the slice censuses] -> shard_plan -> shard_ranges ->
- *   [all-gather of the range cuts] -> shard_sort_begin ->
+ * The keys reach their shard in one of two ways (debwt_shard_key_mode picks; everything after the sort is the same):
+ * Key exchange (every shard scans only its 1/world slice of the text and ships 8-byte keys):
+ *   load -> shard_begin -> shard_histogram -> [all-gather of the slice censuses] -> shard_plan(exchange = 1) ->
+ *   shard_ranges -> [all-gather of the range cuts] -> shard_sort_begin ->
  *   per exchange round t:  shard_partition_keys (keys of the slice that fall into round t's ranges, grouped by owner)
  *                          -> [alltoallv of 8-byte keys: the k-mer bucket exchange] -> shard_sort_range(t) ->
- *   shard_sort_end -> shard_classify_local -> shard_facts_export -> [all-gather of the fact lists] ->
+ *   shard_sort_end -> ...
+ * Key rescan (every shard holds the text anyway: it reads all of it once per key range and keeps its own keys --
+ * n/4 bytes from its HBM instead of 8 n / world bytes from the fabric):
+ *   ... -> shard_plan(exchange = 2) -> kmer_sort_rle -> ...
+ * Then, sliced again (per-GPU work O(n / world)):
+ *   shard_classify_local -> shard_facts_export -> [all-gather of the fact lists] ->
  *   shard_classify_global -> shard_sp_flags -> [all-gather of the slice SP lengths] -> shard_sp_emit ->
  *   [all-gather of the slice SP symbols] -> shard_sp_import -> shard_blue_route -> [alltoallv of 8-byte blue entries]
  *   -> shard_blue_place -> blue_sort -> bwt_assemble -> shard_info -> [gather of the packed row ranges] -> concat_rows.
- * Scan mode (no bulk exchange; every shard reads the whole text and keeps the keys of its ranges):
+ * Scan mode (no bulk exchange at all: tests and 2-GPU hosts without peer access):
  *   ... shard_plan(exchange = 0) or shard_set_range -> kmer_sort_rle -> shard_classify_local -> ... ->
  *   shard_classify_global -> sp_generate -> blue_sort -> bwt_assemble. */
+#define DEBWT_KEYS_EXCHANGE 0
+#define DEBWT_KEYS_RESCAN 1
+/* Cost model of the two key paths for n text positions on `world` GPUs that each hold the text; link_gbytes_per_s:
+ * sustained rate of one GPU-to-GPU link in one direction (<= 0: 48, i.e. 5/8 of an xGMI link's 76.8 GB/s).
+ * Returns DEBWT_KEYS_EXCHANGE or DEBWT_KEYS_RESCAN, the estimated per-GPU milliseconds in *exchange_ms, *rescan_ms
+ * (either may be NULL).  The constants are measured ones, see DESIGN.md section 7. */
+int debwt_shard_key_mode(uint64_t n, int world, double link_gbytes_per_s, double *exchange_ms, double *rescan_ms);
 int debwt_shard_begin(debwt_ctx *ctx, int rank, int world);           /* world <= 255 */
 /* counts of this shard's slice of text positions by the top 12 bits of their key: 4096 words (host) */
 int debwt_shard_histogram(debwt_ctx *ctx, uint64_t *hist4096);
@@ -179,8 +192,10 @@ int debwt_shard_histogram(debwt_ctx *ctx, uint64_t *hist4096);
 int debwt_shard_set_range(debwt_ctx *ctx, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_keys, uint64_t m_base);
 /* the same from the summed census hist4096 (host), cut into as many key ranges as the free HBM (or debwt_set_range_cap)
  * asks for: the reference's segCount balancing (src/mySort.c:104-110) applied twice, over GPUs and over rounds.
- * exchange != 0: the keys of every range will arrive through debwt_shard_sort_range.  caller_held_bytes: device
- * memory the caller already holds for the exchanges of this build (counted as available: it is reused). */
+ * exchange: 1 = the keys of every range will arrive through debwt_shard_sort_range; 0 = the shard reads them from
+ * its text (debwt_kmer_sort_rle); 2 = the same, and the caller will allocate the two buffers of the blue-entry
+ * exchange after the sort (room is left for them).  caller_held_bytes: device memory the caller already holds for
+ * the exchanges of this build (counted as available: it is reused). */
 int debwt_shard_plan(debwt_ctx *ctx, const uint64_t *hist4096, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_base,
                      int exchange, uint64_t caller_held_bytes, uint32_t *nranges);
 /* the cuts of debwt_shard_plan: range i = bins [bin_bounds[i], bin_bounds[i+1]) with m_keys[i] keys */
@@ -228,7 +243,7 @@ int debwt_census_words(debwt_ctx *ctx, const uint64_t *d_words, uint64_t n, uint
 
 /* ---- the same build from ONE host process: one host thread per GPU, exchanges as peer-to-peer copies over xGMI --------
  * What the reference's single process with its thread pool (src/main.c:30) becomes on a node of GPUs: debwt_multi_build
- * runs the exchange-mode stage sequence above on `ngpus` contexts (devices[i] = HIP ordinal of shard i; NULL = 0, 1, ...;
+ * runs the sharded stage sequence above (keys exchanged or rescanned) on `ngpus` contexts (devices[i] = HIP ordinal of shard i; NULL = 0, 1, ...;
  * ordinals may repeat -- several shards on one GPU -- which is how the path is tested on a one-GPU box), every shard
  * pulling its keys / facts / SP symbols / blue entries out of the other shards' buffers with device-to-device copies,
  * and leaves the concatenated BWT in the HBM of the first GPU.  cli/deBWT --gpus G is the C host on top of it. */
@@ -239,6 +254,7 @@ typedef struct {
     uint64_t key_bytes_in;           /* bytes of k-mers shard 0 pulled from the other shards (all rounds) */
     uint64_t blue_bytes_in;          /* bytes of blue entries shard 0 pulled from the other shards */
     float ms_build;                  /* wall time of debwt_multi_build */
+    uint32_t key_mode;               /* DEBWT_KEYS_EXCHANGE or DEBWT_KEYS_RESCAN: how the keys reached their shards */
 } debwt_multi_stats;
 int debwt_multi_create(const debwt_config *cfg, const int *devices, int ngpus, debwt_multi **out);   /* cfg->device unused */
 void debwt_multi_destroy(debwt_multi *m);
@@ -246,6 +262,8 @@ const char *debwt_multi_last_error(const debwt_multi *m);
 debwt_ctx *debwt_multi_shard(debwt_multi *m, int shard);      /* the context of one shard (debwt_set_range_cap, stats) */
 int debwt_multi_load_text(debwt_multi *m, const uint64_t *packed, uint64_t n, const uint64_t *sep, uint64_t nrec);
 int debwt_multi_load_fasta(debwt_multi *m, const char *path, int threads, unsigned flags, uint64_t seed);
+/* DEBWT_KEYS_EXCHANGE / DEBWT_KEYS_RESCAN, or -1 (the default): debwt_shard_key_mode decides at every build */
+int debwt_multi_set_key_mode(debwt_multi *m, int key_mode);
 int debwt_multi_build(debwt_multi *m);
 int debwt_multi_fetch_bwt(debwt_multi *m, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row);
 int debwt_multi_get_stats(const debwt_multi *m, debwt_multi_stats *out, debwt_stats *shard0);

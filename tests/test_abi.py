@@ -123,3 +123,20 @@ def test_special_region_module_threads_agree(monkeypatch):
     words, n, sep = api.pack_records(recs)
     ref = digest(1, 32)
     assert digest(5, 32) == ref and digest(8, 32) == ref
+
+
+def test_key_mode_cost_model():
+    """debwt_shard_key_mode (host only): on one node of 2..8 GPUs the keys are cheaper to re-read from each GPU's copy of
+    the text than to ship; the exchange wins once a shard's slice is small against the text and the links are fast."""
+    import ctypes
+    from debwt_amd import _lib
+    L = _lib.lib()
+    x, r = ctypes.c_double(), ctypes.c_double()
+    for world in (1, 2, 4, 8):
+        assert L.debwt_shard_key_mode(30_000_000_000, world, 0.0, ctypes.byref(x), ctypes.byref(r)) == 1
+        assert 0 < r.value < x.value
+    assert L.debwt_shard_key_mode(30_000_000_000, 64, 0.0, ctypes.byref(x), ctypes.byref(r)) == 0
+    slow = x.value
+    assert L.debwt_shard_key_mode(30_000_000_000, 64, 400.0, ctypes.byref(x), ctypes.byref(r)) == 0 and x.value < slow
+    one = L.debwt_shard_key_mode(3_100_000_000, 1, 0.0, ctypes.byref(x), ctypes.byref(r))
+    assert one in (0, 1) and x.value > 0 and r.value > 0

@@ -92,8 +92,9 @@ def test_cli_iupac_option(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,k,gpus", [("special_branches", 32, 2), ("shared_ends_duplicates", 16, 3), ("pan_fa", 32, 4)])
-def test_cli_multi_gpu_outputs_equal_reference_files(tmp_path, name, k, gpus):
+@pytest.mark.parametrize("name,k,gpus,keys", [("special_branches", 32, 2, "exchange"), ("shared_ends_duplicates", 16, 3, "auto"),
+                                              ("pan_fa", 32, 4, "rescan"), ("pan_fa", 32, 2, "exchange")])
+def test_cli_multi_gpu_outputs_equal_reference_files(tmp_path, name, k, gpus, keys):
     """deBWT --gpus G: the C host over G shards (all on GPU 0 of the test box: --devices 0,0,...) writes the same three
     files the reference writes."""
     assert _have_cli()
@@ -106,11 +107,11 @@ def test_cli_multi_gpu_outputs_equal_reference_files(tmp_path, name, k, gpus):
     else:
         entry = next(e for e in golden_manifest() if e["name"] == name and e["k"] == k)
         fa = os.path.join(ROOT, "tests", "golden", name + ".fa")
-    r = subprocess.run([CLI, "-o", out, "-k", str(k), "-t", "4", "--gpus", str(gpus), "--devices", ",".join(["0"] * gpus), fa],
+    r = subprocess.run([CLI, "-o", out, "-k", str(k), "-t", "4", "--gpus", str(gpus), "--devices", ",".join(["0"] * gpus), "--keys", keys, fa],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     import hashlib
     sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()      # noqa: E731
     assert sha(out) == entry["sha256"]["bwt"] and sha(out + ".#") == entry["sha256"]["hash"]
     assert sha(out + ".$") == entry["sha256"]["dollar"]
-    assert f"{gpus} GPUs" in r.stdout
+    assert f"{gpus} GPUs, keys {'exchanged' if keys == 'exchange' else 'rescanned'}" in r.stdout

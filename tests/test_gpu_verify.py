@@ -133,11 +133,13 @@ def test_multi_gpu_host_from_one_process(api, oracle, devices, case, k, cap, mon
     if cap:
         for r in range(len(devices)):
             api._lib.lib().debwt_set_range_cap(m._shard_ctx(r), cap)
-    for _ in range(2):                                        # reusable
+    for mode, want in (("exchange", 0), ("rescan", 1), ("auto", 1), ("exchange", 0)):   # reusable, in either key mode
+        m.set_key_mode(mode)
         m.build()
-    w, h, dr = m.fetch()
-    assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od
-    ms, s0 = m.stats()
-    assert ms["ngpus"] == len(devices) and (ms["rounds"] > 1) == bool(cap)
+        w, h, dr = m.fetch()
+        assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od
+        ms, s0 = m.stats()
+        assert ms["ngpus"] == len(devices) and (ms["rounds"] > 1) == bool(cap) and ms["key_mode"] == want
+        assert (ms["key_bytes_in"] > 0) == (want == 0 and len(devices) > 1)
     assert m.verify_device()["ok"] == 1
     m.close()

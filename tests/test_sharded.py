@@ -78,7 +78,7 @@ WORKER = textwrap.dedent("""
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["scan", "exchange"])
+@pytest.mark.parametrize("mode", ["scan", "exchange", "rescan", "auto"])
 @pytest.mark.parametrize("world,case,k,cap", [(2, "pan", 32, 0), (3, "pan", 20, 0), (2, "many", 32, 0), (4, "chrom", 32, 0),
                                               (2, "pan", 32, 100_000), (3, "chrom", 24, 150_000), (4, "many", 32, 8192)])
 def test_sharded_build_equals_oracle(tmp_path, oracle, world, case, k, mode, cap):
@@ -86,7 +86,7 @@ def test_sharded_build_equals_oracle(tmp_path, oracle, world, case, k, mode, cap
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / "res.npz")
-    port = str(29540 + world + (10 if mode == "exchange" else 0) + (20 if cap else 0))
+    port = str(29540 + world + 10 * ["scan", "exchange", "rescan", "auto"].index(mode) + (40 if cap else 0))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     if cap:
         env["DEBWT_P2P_MAX_BYTES"] = "65536"               # collectives in many calls, as above RCCL's 1 GiB message limit
