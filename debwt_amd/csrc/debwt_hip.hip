@@ -53,7 +53,7 @@ struct debwt_ctx {
     // device buffers
     DevBuf rs_rle, text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
-        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist, dest_tab, qbounds, qcursor;
+        hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist, dest_tab, qbounds, qcursor, qlist, qwave;
     u32 *h_over = nullptr;      // pinned mirror of rs_over
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
@@ -83,6 +83,8 @@ struct debwt_ctx {
     u64 s0 = 0, s1 = 0;         // special suffixes [s0, s1) fall into this shard's node range
     bool facts_ready = false;
     u64 n_hash_local = 0;
+    bool route_direct = false;  // SP pass 1 keeps the block ids of the multi-in positions (qlist: one run per wave, found
+    u64 gq0 = 0;                //   through qwave, group gq0 first; qwave[0] is the bump counter), pass 2 writes routed entries
     bool exchange = false;      // sharded exchange mode: the keys of every range arrive by alltoallv in a caller buffer
     bool shard_planned = false; // `ranges` were cut by debwt_shard_plan from the global census
     u64 *sort_a = nullptr, *sort_b = nullptr;   // the two key buffers of the range being sorted
@@ -244,7 +246,7 @@ static std::vector<DevBuf *> all_buffers(debwt_ctx *c) {
             &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew,
             &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
             &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0,
-            &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf, &c->vidx, &c->vtmp};
+            &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf, &c->vidx, &c->vtmp, &c->qlist, &c->qwave};
 }
 
 extern "C" const char *debwt_strerror(int code) {
@@ -852,6 +854,19 @@ static int sp_prepare(debwt_ctx *c) {
 //   sp_emit    SP symbols of the slice at their global offset, work list of the slice's multi-in positions
 //   sp_finish  packed SP code of the WHOLE text (after all slices / after the slices' symbols were all-gathered)
 #define SP_SLICE_GROUPS (1ull << 26)
+static SpBlockIds sp_block_ids(debwt_ctx *c) {
+    if (!c->route_direct) return SpBlockIds{nullptr, nullptr, nullptr, 0};
+    return SpBlockIds{c->qlist.as<u32>(), c->qwave.as<unsigned long long>(), c->qwave.as<u64>() + 1, c->gq0};
+}
+// room for the block ids of the multi-in positions among `groups` text groups that start at group gq0
+static int sp_block_ids_begin(debwt_ctx *c, u64 gq0, u64 groups) {
+    c->route_direct = true; c->gq0 = gq0;
+    ENSURE(c, c->qlist, (std::min<u64>(groups * 32, c->Btotal) + 64) * 4);
+    ENSURE(c, c->qwave, ((groups + 63) / 64 + 2) * 8);
+    HIPCHK(c, hipMemsetAsync(c->qwave.p, 0, 8, c->stream));
+    return DEBWT_OK;
+}
+
 static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
     int rc;
     if (g1 - g0 > (1ull << 27) - 2) { c->err = "text slice of the SP stage exceeds 2^32 positions"; return DEBWT_ERANGE; }
@@ -860,11 +875,13 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
     if (ng && c->mzfilter)
         k_sp_flags<1><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
-            c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1);
+            c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
+            sp_block_ids(c));
     else if (ng)
         k_sp_flags<0><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
-            c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1);
+            c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
+            sp_block_ids(c));
     SpCountF fc{c->momask.as<u32>() + g0, c->mimask.as<u32>() + g0};
     if ((rc = cp_count2(c, fc, ng, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
     if ((rc = sync_check(c))) return rc;
@@ -873,15 +890,17 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
     return DEBWT_OK;
 }
 
-static int sp_emit(debwt_ctx *c, u64 sp_off) {
+// routed: nullptr -> work list of the multi-in positions (mi_list); else the slice's B_slice routed blue entries go there
+static int sp_emit(debwt_ctx *c, u64 sp_off, u64 *routed = nullptr, int qshift = 0) {
     const u64 ng = c->g1 - c->g0;
     c->sp_off = sp_off;
     // the SP symbol buffer grows with the slices (S is ~0.1 n, the worst case n)
     ENSURE_KEEP(c, c->spsym, sp_off + c->S_local + 64, c->shard_world > 1 ? 0 : sp_off);
-    ENSURE(c, c->mi_list, c->B_slice * 16 + 64);
+    if (!routed) ENSURE(c, c->mi_list, c->B_slice * 16 + 64);
     if (ng) {
         SpEmitArgs ea{c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->momask.as<u32>(), c->mimask.as<u32>(),
-                      c->spsym.as<u8>(), c->mi_list.as<ulonglong2>(), c->g0, sp_off};
+                      c->spsym.as<u8>(), routed ? nullptr : c->mi_list.as<ulonglong2>(), c->g0, sp_off,
+                      routed, qshift, sp_block_ids(c)};
         u32 nchunks; u64 chunk;
         plan_chunks(ng, &nchunks, &chunk);
         k_sp_emit<<<nchunks, DEBWT_BLOCK, 0, c->stream>>>(ea, ng, chunk, cp_area(c, 0), cp_area(c, 1));
@@ -917,15 +936,17 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     const bool route_sort = c->shard_world == 1 && c->Q > 0 && c->n < (1ull << (qshift - 3)) &&
                             c->B < 0xFFFFFFF0ull - (1ull << 20) &&      // the radix passes index with 32 bits
                             !(c->cfg.reserved & 32);
+    c->route_direct = false;
     for (u64 g0 = 0; g0 < ngroups; g0 += SP_SLICE_GROUPS) {
         const u64 g1 = std::min(ngroups, g0 + SP_SLICE_GROUPS);
+        // route_sort: pass 1 keeps the block ids of the slice's multi-in positions, pass 2 writes the routed entries
+        if (route_sort && (rc = sp_block_ids_begin(c, g0, g1 - g0))) return rc;
         if ((rc = sp_flags(c, g0, g1))) return rc;
-        if ((rc = sp_emit(c, S))) return rc;
-        if (c->B_slice && route_sort) {
+        if (route_sort) {
             if (Bseen + c->B_slice > c->B) { c->err = "multi-in positions exceed the block total"; return DEBWT_EINTERNAL; }
-            k_blue_route_q<<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-                c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, qshift, c->blue.as<u64>() + Bseen);
-        } else if (c->B_slice) {
+            if ((rc = sp_emit(c, S, c->blue.as<u64>() + Bseen, qshift))) return rc;
+        } else if ((rc = sp_emit(c, S))) return rc;
+        if (c->B_slice && !route_sort) {
             if (c->abs32)
                 k_blue_fill<1><<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
                     c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, c->blk_start.as<u64>(),
@@ -1310,10 +1331,11 @@ extern "C" int debwt_shard_plan(debwt_ctx *c, const uint64_t *hist4096, uint32_t
         // entries and their routed form, BWT) and ~1.25 bytes per position of the whole text (2-bit text, flag
         // masks, SP code and its gather buffers, node table, the concatenated BWT on the gathering rank)
         // exchange == 2 (keys rescanned, SP code and blue entries sliced): the caller's two blue-entry buffers come
-        // after the sort, ~2 bytes per position of the share (8 bytes x 2 x ~0.1 multi-in positions per base)
+        // after the sort, ~2 bytes per position of the share (8 bytes x 2 x ~0.1 multi-in positions per base); a sliced
+        // SP stage (exchange != 0) keeps the block ids of the slice's multi-in positions (4 bytes each) between its passes
         const u64 share = c->n / (u64)c->shard_world;
         int rc = default_range_cap(c, exchange == 1 ? 40 : 30,
-                                   share / 2 * 7 + (exchange == 2 ? share * 2 : 0) + c->n / 4 * 5 + (8ull << 30),
+                                   share / 2 * 7 + (exchange ? share / 2 : 0) + (exchange == 2 ? share * 2 : 0) + c->n / 4 * 5 + (8ull << 30),
                                    caller_held_bytes, &cap);
         if (rc) return rc;
     }
@@ -1461,6 +1483,7 @@ extern "C" int debwt_shard_sp_flags(debwt_ctx *c, uint64_t *sp_symbols, uint64_t
     c->sub.clear();
     c->S_rank = c->B_rank = 0;
     const u64 G0 = p0 >> 5, G1 = (p1 + 31) >> 5;
+    if ((rc = sp_block_ids_begin(c, G0, G1 - G0 + 1))) return rc;     // block ids of the slice's multi-in positions
     for (u64 g0 = G0; g0 < G1 || c->sub.empty(); g0 += SP_SLICE_GROUPS) {
         const u64 g1 = std::min(G1, g0 + SP_SLICE_GROUPS);
         if ((rc = sp_flags(c, g0, g1))) return rc;
@@ -1500,10 +1523,7 @@ extern "C" int debwt_shard_sp_emit(debwt_ctx *c, uint64_t sp_offset, uint8_t *d_
         SpCountF fc{c->momask.as<u32>() + sl.g0, c->mimask.as<u32>() + sl.g0};
         if ((rc = cp_count2(c, fc, sl.g1 - sl.g0, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
         c->S_local = sl.S; c->B_slice = sl.B;
-        if ((rc = sp_emit(c, off))) return rc;
-        if (sl.B)
-            k_blue_route_q<<<grid_for(sl.B, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
-                c->mi_list.as<ulonglong2>(), sl.B, c->htab.as<HSlot>(), c->hbits, qshift, routed + bseen);
+        if ((rc = sp_emit(c, off, routed + bseen, qshift))) return rc;
         off += sl.S; bseen += sl.B;
         if ((rc = sync_check(c))) return rc;
     }

@@ -551,6 +551,18 @@ __device__ __forceinline__ u32 red_lookup(const HSlot *__restrict__ htab, int hb
     }
 }
 
+// the same with the slot read as one 16-byte word: flags and the block id of `node` (q is meaningful for a multi-in node)
+__device__ __forceinline__ u32 red_lookup_q(const HSlot *__restrict__ htab, int hbits, u64 node, u32 *q) {
+    const u32 mask = (1u << hbits) - 1u;
+    u32 h = red_hash(node, hbits);
+    for (;;) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&htab[h]);
+        if (v.x == 0ull) return 0u;
+        if ((v.x >> 2) == node) { *q = (u32)(v.y >> 32); return (u32)(v.x & 3); }
+        h = (h + 1) & mask;
+    }
+}
+
 // rows of the special suffixes: rank among the node instances + own rank (src/INandOut.c:419-439)
 // (number of instances with key <= X) = first row of the first distinct key above X
 __global__ void k_special_rows(const u64 *__restrict__ dk, const u32 *__restrict__ dstart, u64 D, u64 M,
@@ -564,6 +576,14 @@ __global__ void k_special_rows(const u64 *__restrict__ dk, const u32 *__restrict
 // ---------------------------------------------------------------------------------------------------
 // SP code + blue entries (multiGenerateSP, src/generateSP.c:534-683)
 
+// block ids of the multi-in positions, handed from pass 1 to pass 2 (list == nullptr: not kept)
+struct SpBlockIds {
+    u32 *list;                 // the ids, one run per wave of pass 1
+    unsigned long long *count; // bump counter of `list`
+    u64 *wave_base;            // first id of the wave that starts at group g0 + 64 * index
+    u64 g0;
+};
+
 // pass 1: one lane = 32 consecutive positions = one text word (coalesced 8-byte loads); per position the
 // node is a shift of the 128-bit (w0,w1) pair; flags go out as two 32-bit masks per group
 template <int MZ>
@@ -572,16 +592,20 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
                                                            const u32 *__restrict__ rbits, int pb,
                                                            const u64 *__restrict__ branch, u64 nbranch,
                                                            u32 *__restrict__ momask, u32 *__restrict__ mimask,
-                                                           u64 g0, u64 g1) {
+                                                           u64 g0, u64 g1, SpBlockIds ids) {
+    // block ids of the lane's multi-in positions until the wave knows where they go (a lane reads only its own 32 words)
+    __shared__ u32 lq[DEBWT_BLOCK * 32];
     u64 g = g0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= g1) return;
+    const bool active = g < g1;
+    if (!ids.list && !active) return;
+    u32 mo = 0, mi = 0;
+    if (active) {
     const u64 w0 = text[g], w1 = text[g + 1];
     const u64 sb = sep_window(sepbits, g << 5);
     const u64 kmask = (1ull << K) - 1ull;
     const u64 i0 = g << 5;
     u32 lim = (n - i0) < 32 ? (u32)(n - i0) : 32u;
     const u32 inrange = lim == 32 ? 0xFFFFFFFFu : ((1u << lim) - 1u);
-    u32 mo = 0, mi = 0;
     // phase 1: which positions hold a node that may be in the red table
     u32 cand = 0, spec = 0;
     if (MZ) {
@@ -629,10 +653,11 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
         u32 t = (u32)__ffs(cand) - 1u;
         cand &= cand - 1u;
         u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
-        u32 fl;
-        red_lookup(htab, hbits, win >> (64 - 2 * K), &fl);
+        u32 q = 0;
+        const u32 fl = red_lookup_q(htab, hbits, win >> (64 - 2 * K), &q);      // key, cursor and block id: one 16-byte slot
         mo |= (fl & 1u) << t;
         mi |= ((fl >> 1) & 1u) << t;
+        if (ids.list && (fl & 2u)) lq[threadIdx.x * 32 + t] = q;
     }
     // special module: multi-out iff listed in specialBranch (src/generateSP.c:612-624)
     if (nbranch) {
@@ -646,6 +671,29 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
     }
     momask[g] = mo;
     mimask[g] = mi;
+    }
+    if (!ids.list) return;
+    // The block id of a multi-in node sat in the table line the search fetched: pass 2 gets it from here instead of
+    // searching the table again.  The ids of a wave (64 lanes = 2048 positions) go out as one run, in position order,
+    // wherever the bump counter puts it; pass 2 finds the run through wave_base and the lane's rank in the wave.
+    const u32 cnt = (u32)__popc(mi);
+    u32 incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 v = __shfl_up(incl, d, 64);
+        if ((int)lane_id() >= d) incl += v;
+    }
+    const u32 total = __shfl(incl, 63, 64);
+    u64 base = 0;
+    if (lane_id() == 0 && total) base = atomicAdd(ids.count, (unsigned long long)total);
+    base = ((u64)__shfl((u32)(base >> 32), 0, 64) << 32) | __shfl((u32)base, 0, 64);
+    if (lane_id() == 0 && active) ids.wave_base[(g - ids.g0) >> 6] = base;
+    u64 o = base + incl - cnt;
+    while (mi) {
+        const u32 t = (u32)__ffs(mi) - 1u;
+        mi &= mi - 1u;
+        ids.list[o++] = lq[threadIdx.x * 32 + t];
+    }
 }
 
 // pass 2 (over groups of 32 positions): spIndex = exclusive scan of the multi-out bits.  SP symbols are
@@ -661,6 +709,9 @@ struct SpEmitArgs {
     u8 *spsym; ulonglong2 *mi_list;
     u64 g0;                    // first group of the slice (the scan arrays are indexed relative to it)
     u64 sp_base;               // SP symbols emitted by the slices before this one
+    // routed != nullptr: a multi-in position becomes block id << qshift | spIndex << 3 | pred at once (the word
+    // k_blue_route_q makes from the work list), the block id from pass 1's list
+    u64 *routed; int qshift; SpBlockIds ids;
 };
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngroups, u64 chunk,
                                                           const u32 *__restrict__ off_mo,
@@ -681,6 +732,22 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
         u32 omi = base_mi + ex[1];
         u32 all = mo | mi;
         u64 w0 = 0, w1 = 0, wp = 0, sbp = 0;
+        // block ids of the lane: its run starts at the wave's base + the lane's rank in the wave (the waves of this
+        // tile are the waves of pass 1); read 4 ahead of their use
+        const u32 *qrun = nullptr;
+        u32 qn = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        if (a.routed) {
+            const u32 wex = ex[1] - __shfl(ex[1], 0, 64);
+            if (mi) {
+                qrun = a.ids.list + a.ids.wave_base[(g - a.ids.g0) >> 6] + wex;
+                qn = (u32)__popc(mi);
+                q0 = qrun[0];
+                if (qn > 1) q1 = qrun[1];
+                if (qn > 2) q2 = qrun[2];
+                if (qn > 3) q3 = qrun[3];
+                qrun += 4;
+            }
+        }
         if (mi) {                                              // the group's text words, the word and separators before it
             w0 = a.text[g]; w1 = a.text[g + 1];
             if (g) { wp = a.text[g - 1]; sbp = sep_window(a.sepbits, (g << 5) - 1); }
@@ -695,7 +762,12 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
                 if (i == 0) pred = 5;
                 else if ((sbp >> t) & 1ull) pred = 4;          // bit t of sbp = position i-1
                 else pred = t ? ((w0 >> (2 * (32 - t))) & 3ull) : (wp & 3ull);
-                a.mi_list[omi++] = make_ulonglong2(win >> (64 - 2 * a.K), (off << 4) | pred);
+                if (a.routed) {
+                    a.routed[omi++] = ((u64)q0 << a.qshift) | (off << 3) | pred;
+                    q0 = q1; q1 = q2; q2 = q3;
+                    if (qn > 4) { q3 = *qrun++; qn--; }
+                } else
+                    a.mi_list[omi++] = make_ulonglong2(win >> (64 - 2 * a.K), (off << 4) | pred);
             }
             if ((mo >> t) & 1u) {
                 // the symbol K ahead; the separator itself when it follows the window (src/generateSP.c:626-660)
