@@ -709,8 +709,8 @@ struct SpEmitArgs {
     u8 *spsym; ulonglong2 *mi_list;
     u64 g0;                    // first group of the slice (the scan arrays are indexed relative to it)
     u64 sp_base;               // SP symbols emitted by the slices before this one
-    // routed != nullptr: a multi-in position becomes block id << qshift | spIndex << 3 | pred at once (the word
-    // k_blue_route_q makes from the work list), the block id from pass 1's list
+    // routed != nullptr: a multi-in position becomes block id << qshift | spIndex << 3 | pred at once, the block id
+    // from pass 1's list (no work list, no second search of the node table)
     u64 *routed; int qshift; SpBlockIds ids;
 };
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngroups, u64 chunk,
@@ -806,22 +806,11 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const ulonglong2 *__r
     }
 }
 
-// Atomic-free blue fill: a multi-in position -> (block id << qshift | spIndex << 3 | pred); sorting these words by
+// Atomic-free blue fill: k_sp_emit turns a multi-in position into (block id << qshift | spIndex << 3 | pred); sorting these words by
 // their block bits puts every entry into its block (the blocks' blue slots are the exclusive scan of their sizes in
 // block order), k_blue_strip turns them into blue entries (pred | spIndex << 4).  A sharded build routes the same
 // words (global block ids) to the shard that owns the block, where k_blue_place puts them into the block through a
 // cursor per owned block.
-__global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_route_q(const ulonglong2 *__restrict__ mi_list, u64 B,
-                                                               const HSlot *__restrict__ htab, int hbits, int qshift,
-                                                               u64 *__restrict__ out) {
-    u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    ulonglong2 it = mi_list[b];
-    u32 fl;
-    u32 h = red_lookup(htab, hbits, it.x, &fl);
-    u64 q = h == 0xFFFFFFFFu ? 0ull : (u64)htab[h].q;            // every multi-in position has its node in the table
-    out[b] = (q << qshift) | ((it.y >> 4) << 3) | (it.y & 7ull);
-}
 __global__ void k_blue_strip(const u64 *__restrict__ src, u64 *__restrict__ dst, u64 n, int qshift) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
