@@ -1004,14 +1004,16 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
     // rounds: every pending block is split in the same five launches (batches of at most LS_BATCH_ROWS rows of
     // scratch), one synchronisation per batch; the ranges a batch reports as still too large are the next round's
     // blocks: a range of ties one pair of windows deeper, any other range on finer splitters.  A run of one symbol or a
-    // tandem repeat ties for as long as it lasts and sheds 42 SP symbols per round -- rounds are cheap (a few launches
-    // over the rows still pending), the bitonic network with its symbol-by-symbol comparator is only the last resort.
+    // tandem repeat ties for as long as it lasts and would shed 42 SP symbols per round: a range of ties that is most of
+    // its block gets a PIVOT round next (LsBlock::pivot, stage_kernels.h), which measures how far every row follows one
+    // row of the block and so halves what is left of a periodic stretch -- 805 rounds became ~40 on
+    // scripts/gpu_lowcomplexity.py.  The bitonic network with its symbol-by-symbol comparator is only the last resort.
     constexpr u64 LS_BATCH_ROWS = 1ull << 28;
-    struct Work { u64 b0, j0; u32 m, depth; };
+    struct Work { u64 b0, j0; u32 m, depth, pivot; };
     std::vector<Work> work, next;
     u32 maxm = 0;
     for (u64 t = 0; t < c->nlarge; t++) {
-        work.push_back(Work{desc3[3 * t], desc3[3 * t + 1], (u32)desc3[3 * t + 2], 0u});
+        work.push_back(Work{desc3[3 * t], desc3[3 * t + 1], (u32)desc3[3 * t + 2], 0u, 0u});
         maxm = std::max(maxm, (u32)desc3[3 * t + 2]);
     }
     c->st.blue_max_block = maxm;
@@ -1034,7 +1036,7 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
                 u32 nb = 8;
                 while (nb < LS_MAXBINS && (u64)nb * 384 < wk.m) nb <<= 1;
                 u32 ns = std::min<u32>(LS_SAMPLES, std::max<u32>(64u, nb * 8u));
-                desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs, wk.depth, 0u});
+                desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs, wk.depth, wk.pivot});
                 rows += (wk.m + 1u) & ~1u;
                 wgs += (wk.m + 255u) / 256u;
             }
@@ -1074,9 +1076,15 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
                 if (res[i]) { const Work &wk = work[w0 + i]; if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc; }
             for (const LsOver &o : over) {
                 const Work &wk = work[w0 + o.blk];
-                const u64 deeper = ((u64)wk.depth + 2) * (2 * SP_WIN);
-                if (o.ties && deeper < c->S + 2 * SP_WIN) next.push_back(Work{wk.b0 + o.st, wk.j0 + o.st, o.cnt, wk.depth + 1});
-                else if (!o.ties && o.cnt < wk.m) next.push_back(Work{wk.b0 + o.st, wk.j0 + o.st, o.cnt, wk.depth});
+                // a range of ties shares o.adv more pairs of windows (1 after a window round); one that is most of
+                // its block is a stretch that keeps tying: pivot round next.  After a pivot round a range of ties is
+                // smaller than its block (the pivot row itself is not in it), so the rounds end.
+                const u64 deeper = ((u64)wk.depth + o.adv + 1) * (2 * SP_WIN);
+                // (rows that left the pivot at once -- adv 0 after a pivot round -- show no such stretch: window round)
+                const u32 pivot = (o.ties && (u64)o.cnt * 4 > wk.m && (!wk.pivot || o.adv >= 1) && !(c->cfg.reserved & 8192)) ? 1u : 0u;
+                if (o.ties && (o.adv || wk.pivot) && deeper < c->S + 2 * SP_WIN && o.cnt < wk.m + (wk.pivot ? 0u : 1u))
+                    next.push_back(Work{wk.b0 + o.st, wk.j0 + o.st, o.cnt, wk.depth + o.adv, pivot});
+                else if (!o.ties && o.cnt < wk.m) next.push_back(Work{wk.b0 + o.st, wk.j0 + o.st, o.cnt, wk.depth, wk.pivot});
                 else if ((rc = bitonic_large(c, wk.b0 + o.st, o.cnt, wk.j0 + o.st))) return rc;
             }
             w0 = w1;

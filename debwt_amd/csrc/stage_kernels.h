@@ -1243,10 +1243,23 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
 #define LS_SAMPLES 4096
 #define LS_MAXBINS 1024                // splitters + 1
 #define LS_MAXR (2 * LS_MAXBINS)       // ranges: below splitter 0, equal to it, between 0 and 1, equal to 1, ...
-struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0, depth, pad; };   // row0: first scratch row; wg0: first 256-row
-                                                                        // workgroup; depth: windows already equal
-struct LsOver { u32 blk, st, cnt, ties; };                              // a range above BLUE_LDS_CAP rows: block of the
-                                                                        // batch, first row, rows, 1 = rows tie with a splitter
+struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0, depth, pivot; };  // row0: first scratch row; wg0: first 256-row
+                                                                        // workgroup; depth: window pairs already equal;
+                                                                        // pivot: 1 = keys of a pivot round (k_ls_windows)
+struct LsOver { u32 blk, st, cnt, ties, adv; };                         // a range above BLUE_LDS_CAP rows: block of the
+                                                                        // batch, first row, rows, 1 = rows tie with a
+                                                                        // splitter, window pairs they are known to share
+// Pivot round, for rows that keep tying (a run of one symbol or a tandem repeat ties for as long as it lasts, and a
+// window round sheds only 42 SP symbols of it): every row is compared with ONE row of the block, the pivot, pair of
+// windows by pair, until they differ -- after t pairs.  Rows below the pivot order by t ascending (the one that leaves
+// the common prefix first is the smaller), rows above it by t descending, so key = t | TCAP | 2 TCAP - t stands in for
+// the windows of a window round; rows with the same key share t more pairs (not t + 1: pair t differs from the
+// pivot's, not necessarily among them).  All rows of a run that outlast the pivot's leave with the pivot's own t in one
+// range: with the pivot in the middle of the block a round halves what is left of a periodic stretch.
+#define LS_TCAP 65536u
+__device__ __forceinline__ u32 ls_pivot_adv(u64 key) {
+    return key < LS_TCAP ? (u32)key : (key == LS_TCAP ? LS_TCAP : (u32)(2 * LS_TCAP - key));
+}
 struct LargeSplit {
     const LsBlock *blk; u32 nblk;
     u64 *w, *x, *en;                  // per row: first two windows, entry (copy)
@@ -1268,8 +1281,26 @@ __global__ __launch_bounds__(256) void k_ls_windows(const u64 *__restrict__ blue
     if (i >= B.m) return;
     const u64 e = blue[B.b0 + i];
     const u64 pos = (e >> 4) + (u64)B.depth * (2 * SP_WIN);
-    const bool live = pos < S;
     ls.en[B.row0 + i] = e;
+    if (B.pivot) {
+        const u64 ppos = (blue[B.b0 + (B.m >> 1)] >> 4) + (u64)B.depth * (2 * SP_WIN);
+        u64 key = LS_TCAP;                                   // equal to the pivot for as long as we look
+        for (u32 t = 0; t < LS_TCAP && i != (B.m >> 1); t++) {
+            const u64 a = pos + (u64)t * (2 * SP_WIN), b = ppos + (u64)t * (2 * SP_WIN);
+            const bool la = a < S, lb = b < S;
+            if (!la && !lb) break;                           // both behind the end: zeros from here on
+            const u64 aw = la ? sp_window(spn, a) : 0ull, ax = la ? sp_window(spn, a + SP_WIN) : 0ull;
+            const u64 bw = lb ? sp_window(spn, b) : 0ull, bx = lb ? sp_window(spn, b + SP_WIN) : 0ull;
+            if (aw != bw || ax != bx) {
+                key = (aw != bw ? aw < bw : ax < bx) ? (u64)t : (u64)(2 * LS_TCAP - t);
+                break;
+            }
+        }
+        ls.w[B.row0 + i] = key;
+        ls.x[B.row0 + i] = 0ull;
+        return;
+    }
+    const bool live = pos < S;
     ls.w[B.row0 + i] = live ? sp_window(spn, pos) : 0ull;
     ls.x[B.row0 + i] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
 }
@@ -1361,13 +1392,18 @@ __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub s
         ls.res[blockIdx.x] = full;
     }
     __syncthreads();
+    // pairs of windows the rows of the tie range (h = 1) share beyond B.depth: those of a pivot round the pairs their
+    // key counts, those of a window round the pair just compared (the host checks that a deeper pair exists; a
+    // sub-block starts conservatively at B.depth there, as before)
+    const u32 adv_tie = B.pivot ? (tid + 1 < B.nb ? ls_pivot_adv(ls.spl_w[(size_t)blockIdx.x * LS_MAXBINS + tid]) : 0u) : 1u;
     for (int h = 0; h < 2; h++) {
         if (c[h] >= 1 && c[h] <= BLUE_LDS_CAP && !full) {
             const u32 e = base + my[h];
-            sub.start[e] = B.b0 + st[h]; sub.freq[e] = c[h]; sub.j0[e] = B.j0 + st[h]; sub.depth[e] = B.depth;
+            sub.start[e] = B.b0 + st[h]; sub.freq[e] = c[h]; sub.j0[e] = B.j0 + st[h];
+            sub.depth[e] = B.depth + (h && B.pivot ? adv_tie : 0u);
         }
         if (c[h] > BLUE_LDS_CAP && !full)                                   // h = 1: a range of ties
-            ls.over[atomicAdd(ls.nover, 1u)] = LsOver{blockIdx.x, st[h], c[h], (u32)h};
+            ls.over[atomicAdd(ls.nover, 1u)] = LsOver{blockIdx.x, st[h], c[h], (u32)h, h ? adv_tie : 0u};
     }
 }
 __global__ __launch_bounds__(256) void k_ls_scatter(u64 *__restrict__ blue, LargeSplit ls) {

@@ -226,6 +226,31 @@ def test_hip_large_blocks_with_long_ties(api, oracle):
         d.close()
 
 
+@pytest.mark.parametrize("seed,runs,maxrun", [(5, 40, 9000), (6, 12, 30000)])
+def test_hip_periodic_stretches_pivot_rounds(api, oracle, seed, runs, maxrun):
+    """Runs of one symbol and tandem repeats of 2..6-symbol units, thousands of symbols long: the rows of their nodes
+    tie for as long as the stretch lasts, in blocks far above the LDS capacity.  The pivot rounds of the large-block
+    split (default), window rounds only (reserved bit 13) and the bitonic network alone (bit 10) must all give the
+    oracle's BWT."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for _ in range(runs):
+        parts.append(np.full(int(rng.integers(200, maxrun)), int(rng.integers(0, 4)), dtype=np.uint8))
+        parts.append(np.tile(rng.integers(0, 4, size=int(rng.integers(2, 7))).astype(np.uint8), int(rng.integers(50, maxrun // 10))))
+        parts.append(rng.integers(0, 4, size=int(rng.integers(100, 3000))).astype(np.uint8))
+    recs = [np.concatenate(parts[:len(parts) // 2]), np.concatenate(parts[len(parts) // 2:])]
+    ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), 32)
+    for tune in (0, 8192) + ((1024,) if maxrun < 10000 else ()):       # the network's comparator walks the whole tie
+        d = api.DeBWT(k=32, tune=tune)
+        d.load_records(recs)
+        d.build()
+        words, hrows, drow = d.fetch()
+        st = d.stats()
+        assert st["blue_large_blocks"] >= 1 and st["blue_max_block"] > 2048
+        assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od, tune
+        d.close()
+
+
 def test_hip_large_tie_ranges_go_deeper(api, oracle):
     """3000 exact copies of a segment full of branching nodes: the rows of a node early in the segment tie for more than
     the 42 SP symbols a split looks at, in groups above the LDS capacity -- those ranges are split again one pair of
