@@ -536,8 +536,11 @@ static int sort_begin(debwt_ctx *c) {
         build_special_tables(c->h_text, n, c->h_sep.data(), c->nrec, c->K, &c->special);
         c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     });
-    // several ranges read off the text: the chunk histograms of every range's first pass from ONE scan of the text
-    c->shared_hist = P > 1 && P <= RS_MAX_RANGES && !c->exchange;
+    // several ranges read off the text: the chunk histograms of every range's first pass from ONE scan of the text (a
+    // lane per text word, radix_text_hist_ranges); a single range of a long text takes the same kernel -- it is twice
+    // as fast as the histogram pass of the sort itself (a shard of 8 reads the whole text for its one range)
+    c->shared_hist = P <= RS_MAX_RANGES && !c->exchange &&
+                     (P > 1 || (P == 1 && n >= (1ull << 26) && radix_first_shift(c->ranges[0].M, 2 * c->cfg.k, c->cfg.sort_algo) > 0));
     if (c->shared_hist) {
         const int kb = 2 * c->cfg.k;
         std::vector<u8> rob(SHARD_BINS, 0xFF);
