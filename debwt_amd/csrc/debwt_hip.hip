@@ -490,8 +490,8 @@ static int plan_ranges(debwt_ctx *c) {
     }
     ENSURE(c, c->shard_hist, SHARD_BINS * 8);
     HIPCHK(c, hipMemsetAsync(c->shard_hist.p, 0, SHARD_BINS * 8, c->stream));
-    k_prefix_hist<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), 0, c->n, c->K,
-                                                        c->shard_hist.as<u64>());
+    k_prefix_hist_words<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), 0, c->n, c->K,
+                                                              c->shard_hist.as<u64>());
     std::vector<u64> hist(SHARD_BINS);
     HIPCHK(c, hipMemcpyAsync(hist.data(), c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
     int rc = sync_check(c);
@@ -1304,8 +1304,12 @@ extern "C" int debwt_shard_histogram(debwt_ctx *c, uint64_t *hist4096) {
     // this shard counts the positions of its text slice: the census itself is data-parallel over the text
     u64 p0, p1;
     shard_slice(c, &p0, &p1);
-    k_prefix_hist<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), p0, p1, c->K,
-                                                        c->shard_hist.as<u64>());
+    if (p0 & 31ull)
+        k_prefix_hist<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), p0, p1, c->K,
+                                                            c->shard_hist.as<u64>());
+    else
+        k_prefix_hist_words<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), p0, p1, c->K,
+                                                                  c->shard_hist.as<u64>());
     HIPCHK(c, hipMemcpyAsync(hist4096, c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
     return sync_check(c);
 }
