@@ -816,9 +816,9 @@ static int sp_prepare(debwt_ctx *c) {
     // Smaller K (or cfg.reserved bit 11: tests): one bit per hashed node, 8 bits per red node; while the node table
     // still fits the Infinity Cache (<= 256 MB) the bitmap is held at L2 size (2 MB, down to 2..4 bits per node).
     // cfg.reserved & 15 = delta + 8 overrides the size (tuning).
-    // The plain bitmap wins while it stays L2-sized (250 Mbp: SP stage 3.3 ms against 3.5 ms); cfg.reserved bit 12
-    // forces the minimizer filter for any size (tests).
-    c->mzfilter = c->K >= 24 && !(c->cfg.reserved & 2048) && (hbits >= 23 || (c->cfg.reserved & 4096));
+    // The plain bitmap is kept for small node tables (below 2^20 slots: a few Mbp); from there on the minimizer filter
+    // wins (250 Mbp: SP stage 3.16 ms against 3.41 ms).  cfg.reserved bit 12 forces it for any size (tests).
+    c->mzfilter = c->K >= 24 && !(c->cfg.reserved & 2048) && (hbits >= 20 || (c->cfg.reserved & 4096));
     int pb;
     if (c->mzfilter) {
         pb = 10;
@@ -1363,7 +1363,7 @@ extern "C" int debwt_shard_plan(debwt_ctx *c, const uint64_t *hist4096, uint32_t
 }
 
 // Key exchange or key rescan (include/debwt_hip.h).  Per-GPU milliseconds of what differs between the two, calibrated
-// on 30 Gbp builds in a process group of one (profiles/r02_v14_bench_30G_keys_*.json):
+// on 30 Gbp builds in a process group of one (profiles/r02_v19_bench_30G_keys_*.json):
 //   rescan    a first radix pass that reads the whole text and keeps one key range takes 32.3 ms per 30 Gbp read, the
 //             histogram pass before it about as much                          -> 2.2 ms per Gbp read and key range
 //   exchange  sort stage 2195 ms against 1230 ms: the slice is read once per round, its keys are written grouped by
