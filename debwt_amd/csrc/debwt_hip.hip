@@ -1130,9 +1130,17 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
         k_blue_refine<64, 128, 0><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
                                                            c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q, 0u,
                                                            c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, none);
-        k_blue_refine<64, BLUE_WAVE_CAP, 128><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
+        // 129..256 rows: one wave per block with the LDS of that capacity (9 KB per workgroup, 17 of them per CU);
+        // 257..512 rows: 18 KB per block allow 8 workgroups per CU -- four waves each rather than one: these kernels wait
+        // on SP gathers, what they need is waves in flight (measured at 30 Gbp: 129..512 rows by one wave and 18 KB each
+        // 86 + 156 ms for blocks + queued ranges; now 6.5 + 67 and 22 + 78 ms)
+        k_blue_refine<64, 256, 128><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
+                                                           c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
+                                                           128u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(),
+                                                           nullptr, nullptr, sub);
+        k_blue_refine<256, BLUE_WAVE_CAP, 128><<<(u32)std::min<u64>(Q, 1u << 14), 256, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
                                                                      c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
-                                                                     128u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(),
+                                                                     256u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(),
                                                                      nullptr, nullptr, sub);
         u32 g2 = (u32)std::min<u64>(Q, 1u << 12);
         // collections of many genomes put most rows into blocks of 513..1024 rows: those get a kernel of their own
@@ -1156,8 +1164,12 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
         k_blue_refine<64, 128, 0><<<gs, 64, 0, c->stream>>>(
             c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 0u,
             c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
-        k_blue_refine<64, BLUE_WAVE_CAP, 0><<<gs, 64, 0, c->stream>>>(
+        k_blue_refine<64, 256, 0><<<gs, 64, 0, c->stream>>>(
             c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 128u,
+            c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
+        // (257..512 queued rows are one deep tie group as a rule: four waves per block gather its windows four times as wide)
+        k_blue_refine<256, BLUE_WAVE_CAP, 0><<<std::min<u32>(gs, 1u << 14), 256, 0, c->stream>>>(
+            c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 256u,
             c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
         if (c->nlarge)                                             // only the split of large blocks queues more than 512 rows
             k_blue_refine<256, BLUE_LDS_CAP, 0><<<std::min<u32>(gs, 1u << 12), 256, 0, c->stream>>>(
