@@ -213,11 +213,17 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_ranges_words_kernel(TextKeyS
         const u64 sa = ts.sepbits[p >> 6], sbw = ts.sepbits[(p >> 6) + 1];
         const u64 sb = (p & 32ull) ? (sa >> 32) | (sbw << 32) : sa;        // bit t: separator at the word's position + t
         const u32 lim = end - idx0 < 32 ? (u32)(end - idx0) : 32u;
+        u32 ok = lim < 32 ? (1u << lim) - 1u : 0xFFFFFFFFu;
+        if (sb) {                                              // a separator within 64 positions: rare, tested apart
+#pragma unroll
+            for (u32 t = 0; t < 32; t++)
+                if ((sb >> t) & kmask) ok &= ~(1u << t);
+        }
 #pragma unroll
         for (u32 t = 0; t < 32; t++) {
             const u32 top = t ? (u32)(((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) >> 32) : (u32)(w0 >> 32);
             const u32 gi = rob[top >> 20];
-            if (gi != 0xFFu && t < lim && ((sb >> t) & kmask) == 0ull) atomicAdd(&h[gi][(top >> rsh[gi]) & 255u], 1u);
+            if (gi != 0xFFu && ((ok >> t) & 1u)) atomicAdd(&h[gi][(top >> rsh[gi]) & 255u], 1u);
         }
     }
     __syncthreads();
@@ -551,8 +557,12 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
                 const u32 pre = t <= 26 ? (u32)(w0 >> (52 - 2 * t)) & 0xFFFu
                                         : (u32)(((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) >> 52);
                 const bool in = AUX ? stab[pre] != 0xFFu : (pre - lo12) < span12;
-                const bool ok = in && ((sb >> t) & kmask) == 0ull;
-                m |= (ok ? 1u : 0u) << t;
+                m |= (in ? 1u : 0u) << t;
+            }
+            if (sb) {                                          // a separator within 64 positions: rare, tested apart
+#pragma unroll
+                for (u32 t = 0; t < 32; t++)
+                    if ((sb >> t) & kmask) m &= ~(1u << t);
             }
             if (lim < 32) m &= (1u << lim) - 1u;
         }
