@@ -9,9 +9,11 @@ syn = SN.Synth.named(wl)
 words, census = syn.words()
 m = api.MultiDeBWT([0] * shards, k=32)
 m.load_packed(words, syn.n, syn.sep())
-t0 = time.time(); m.build(); t1 = time.time() - t0
-t0 = time.time(); m.build(); t2 = time.time() - t0
-ms, s0 = m.stats()
-rep = m.verify_device()
-print(f"{wl}: {shards} shards on one GPU, first build {t1:.2f} s, second {t2*1e3:.0f} ms = {syn.n/t2/1e9:.2f} Gbp/s; {ms}; inverse BWT ok={rep['ok']} ({rep['segments']} segments, {rep['ms_walk']:.0f} ms)")
+for mode in ("rescan", "exchange"):
+    m.set_key_mode(mode)
+    t0 = time.time(); m.build(); t1 = time.time() - t0
+    t0 = time.time(); m.build(); t2 = time.time() - t0
+    ms, s0 = m.stats()
+    rep = m.verify_device()
+    print(f"{wl}: {shards} shards on one GPU, keys {mode}: first build {t1:.2f} s, second {t2*1e3:.0f} ms = {syn.n/t2/1e9:.2f} Gbp/s; {ms}; inverse BWT ok={rep['ok']} ({rep['segments']} segments, {rep['ms_walk']:.0f} ms)", flush=True)
 m.close()
