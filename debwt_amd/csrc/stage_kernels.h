@@ -772,9 +772,11 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
                 qrun += 4;
             }
         }
-        if (mi) {                                              // the group's text words, the word and separators before it
+        u64 sbn = 0;                                           // bit b: separator at the group's position + b
+        if (all) {                                             // the group's text words, the word and separators before it
             w0 = a.text[g]; w1 = a.text[g + 1];
-            if (g) { wp = a.text[g - 1]; sbp = sep_window(a.sepbits, (g << 5) - 1); }
+            if (g) { wp = a.text[g - 1]; sbp = sep_window(a.sepbits, (g << 5) - 1); sbn = sbp >> 1; }
+            else sbn = sep_window(a.sepbits, 0);
         }
         while (all) {
             u32 t = (u32)__ffs(all) - 1u;
@@ -795,9 +797,12 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
             }
             if ((mo >> t) & 1u) {
                 // the symbol K ahead; the separator itself when it follows the window (src/generateSP.c:626-660)
-                u64 j = i + (u64)a.K;
+                // (position i + K is symbol t + K <= 62 of the group's word pair: no load)
+                const u32 b = t + (u32)a.K;
+                const u64 j = i + (u64)a.K;
                 u8 sy;
-                if (sep_at(a.sepbits, j)) sy = (j == a.n - 1) ? 5 : 4; else sy = (u8)text_symbol(a.text, j);
+                if ((sbn >> b) & 1ull) sy = (j == a.n - 1) ? 5 : 4;
+                else sy = (u8)((b < 32 ? w0 >> (2 * (31 - b)) : w1 >> (2 * (63 - b))) & 3ull);
                 a.spsym[off++] = sy;
             }
         }
