@@ -1375,7 +1375,7 @@ extern "C" int debwt_shard_plan(debwt_ctx *c, const uint64_t *hist4096, uint32_t
 }
 
 // Key exchange or key rescan (include/debwt_hip.h).  Per-GPU milliseconds of what differs between the two, calibrated
-// on 30 Gbp builds in a process group of one (profiles/r02_v21_bench_30G_keys_*.json):
+// on 30 Gbp builds in a process group of one (profiles/r02_v22_bench_30G_keys_*.json):
 //   rescan    a first radix pass that reads the whole text and keeps one key range takes 32.3 ms per 30 Gbp read, the
 //             histogram pass before it about as much                          -> 2.2 ms per Gbp read and key range
 //   exchange  sort stage 2195 ms against 1230 ms: the slice is read once per round, its keys are written grouped by
@@ -1592,16 +1592,35 @@ extern "C" int debwt_shard_blue_route(debwt_ctx *c, const uint32_t *first_block_
     return DEBWT_OK;
 }
 
-extern "C" int debwt_shard_blue_place(debwt_ctx *c, const uint64_t *d_entries, uint64_t count) {
+extern "C" int debwt_shard_blue_place(debwt_ctx *c, uint64_t *d_entries, uint64_t count) {
     if (!c || (!d_entries && count)) return DEBWT_EINVAL;
     if (c->stage < ST_SP) return DEBWT_ESTATE;
     if (count != c->B) { c->err = "received blue entries differ from the rows of the owned blocks"; return DEBWT_EINTERNAL; }
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int qshift = routed_qshift(c);
+    // As on one GPU (debwt_sp_generate): sorting the routed words by their block bits puts every entry into its block --
+    // the owned blocks are a contiguous range of block ids and their blue slots the exclusive scan of their sizes -- and
+    // k_blue_strip leaves pred | spIndex << 4.  The passes alternate between the caller's buffer (scratch from here on)
+    // and `blue`.  (One cursor atomic and one scattered 8-byte store per entry, k_blue_place, took 177 ms for the 3.1 G
+    // entries of 30 Gbp against 91 ms; it stays for entries that the 32-bit passes cannot index and for cfg.reserved
+    // bit 5.)
+    if (count >= 2 && count < 0xFFFFFFF0ull - (1ull << 20) && !(c->cfg.reserved & 32)) {
+        ENSURE(c, c->rs_over, radix_over_bytes(count));
+        u64 *src = reinterpret_cast<u64 *>(d_entries), *dst = c->blue.as<u64>();
+        for (int shift = qshift; shift < 64; shift += 8) {
+            hipError_t e = hipSuccess;
+            u64 *r = radix_sort_bits(c->stream, src, dst, count, shift, std::min(shift + 8, 64), radix_ws(c), &e);
+            if (e != hipSuccess || r != dst) { c->err = std::string("blue entry sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
+            std::swap(src, dst);
+        }
+        k_blue_strip<<<grid_for(count, 256), 256, 0, c->stream>>>(src, c->blue.as<u64>(), count, qshift);
+        return sync_check(c);
+    }
     ENSURE(c, c->qcursor, c->Q * 4 + 64);
     if (c->Q) HIPCHK(c, hipMemsetAsync(c->qcursor.p, 0, c->Q * 4, c->stream));
     if (count)
         k_blue_place<<<grid_for(count, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>((const u64 *)d_entries, count,
-                                                                                 (u32)c->qbase, (u32)c->Q, routed_qshift(c),
+                                                                                 (u32)c->qbase, (u32)c->Q, qshift,
                                                                                  c->qcursor.as<u32>(), c->blk_start.as<u64>(),
                                                                                  c->blue.as<u64>());
     return sync_check(c);

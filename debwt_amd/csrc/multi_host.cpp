@@ -215,7 +215,7 @@ void shard_thread(debwt_multi *m, int r) {
                     [&](int s) { return m->boffs[s][r + 1] - m->boffs[s][r]; }) < 0) rc = DEBWT_EDEVICE;
     if (r == 0) { uint64_t moved = 0; for (int s = 1; s < G; s++) moved += m->boffs[s][1] - m->boffs[s][0]; m->st.blue_bytes_in = moved * 8; }
     if (!rv.sync(rc)) return;
-    STEP(debwt_shard_blue_place(c, (const uint64_t *)m->xb[r].p, brecv), "shard_blue_place");
+    STEP(debwt_shard_blue_place(c, (uint64_t *)m->xb[r].p, brecv), "shard_blue_place");
 
     // 6. owned blocks and rows
     if (!rc) STEP(debwt_blue_sort(c), "blue_sort");

@@ -223,7 +223,9 @@ int debwt_shard_sp_import(debwt_ctx *ctx, const uint8_t *d_src, uint64_t sp_tota
 /* first_block_of_shard: world+1 host words (exclusive scan of the shards' block counts) */
 int debwt_shard_blue_route(debwt_ctx *ctx, const uint32_t *first_block_of_shard, uint64_t *d_out, uint64_t capacity,
                            uint64_t *offs);
-int debwt_shard_blue_place(debwt_ctx *ctx, const uint64_t *d_entries, uint64_t count);
+/* d_entries: the `count` routed entries this shard received (DEVICE); the buffer is used as scratch and holds nothing
+ * meaningful afterwards */
+int debwt_shard_blue_place(debwt_ctx *ctx, uint64_t *d_entries, uint64_t count);
 /* Final concat on one GPU: d_parts holds the shards' packed row ranges (part i from word part_word_off[i], one spare
  * word behind each, rows [row_base[i], row_base[i] + rows[i])); the ranges are not 32-row aligned and are
  * shift-merged into d_out (ceil(n/32) DEVICE words), as src/generateSP.c:379-405 joins SP segments. */

@@ -118,9 +118,10 @@ def test_config2_properties(api, workload):
     assert digests[0] == digests[1]
 
 
-@pytest.mark.parametrize("devices,case,k,cap", [([0, 0], "pan", 32, 0), ([0, 0, 0], "chrom", 24, 150_000),
-                                                ([0] * 8, "many", 32, 0), ([0] * 5, "pan", 20, 60_000), ([0], "pan", 32, 0)])
-def test_multi_gpu_host_from_one_process(api, oracle, devices, case, k, cap, monkeypatch):
+@pytest.mark.parametrize("devices,case,k,cap,tune", [([0, 0], "pan", 32, 0, 0), ([0, 0, 0], "chrom", 24, 150_000, 0),
+                                                     ([0] * 8, "many", 32, 0, 0), ([0] * 5, "pan", 20, 60_000, 0),
+                                                     ([0], "pan", 32, 0, 0), ([0, 0, 0], "pan", 32, 0, 32)])
+def test_multi_gpu_host_from_one_process(api, oracle, devices, case, k, cap, tune, monkeypatch):
     """debwt_multi_build: one host thread per shard, exchanges as device-to-device copies -- here with all shards on
     the box's one GPU (on a node the ordinals differ and the copies cross xGMI).  2, 3, 5 and 8 shards, with several
     exchange rounds per shard where a range cap is set, against the oracle; then the device inverse BWT."""
@@ -128,7 +129,7 @@ def test_multi_gpu_host_from_one_process(api, oracle, devices, case, k, cap, mon
     recs = {"pan": lambda: synth.pan_genome(300_000, 3), "many": lambda: synth.pan_genome(20_000, 9, seed=5),
             "chrom": lambda: synth.chromosomes(2_000_000, 4)}[case]()
     ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), k)
-    m = api.MultiDeBWT(devices, k=k)
+    m = api.MultiDeBWT(devices, k=k, tune=tune)               # tune 32: blue entries placed through block cursors
     m.load_records(recs)
     if cap:
         for r in range(len(devices)):
