@@ -118,6 +118,34 @@ def test_config2_properties(api, workload):
     assert digests[0] == digests[1]
 
 
+@pytest.mark.parametrize("workload", ["pan4x3.1G", "pan10x3G"])
+def test_config3_config4_collections_on_one_gpu(api, workload):
+    """BASELINE.json configs[3] and configs[4] name 4 and 8 GPUs; their collections -- 4 x GRCh38-sized = 12.4 Gbp and
+    10 genomes x 3.0 Gbp = 30 Gbp, the size the metric is quoted on -- also fit ONE MI355X (key ranges one after the
+    other), so the build itself is tested here at full size: symbol census = the text's, '#' rows complete and ascending,
+    '$' row present, and the inverse BWT walked on the device reproduces the text (1.2e10 / 3e10 LF steps).  The sharded
+    form of the same builds is what bench.py --gpus N runs (and tests/test_sharded.py checks at small sizes)."""
+    from debwt_amd import synth_native as SN
+    syn = SN.Synth.named(workload)
+    text = SN.PinnedArray(syn.nwords)
+    census = syn.words_into(text.ptr)
+    d = api.DeBWT(k=32)
+    d.load_packed(text.a, syn.n, syn.sep())
+    d.build()
+    st = d.stats()
+    assert st["n"] == syn.n and st["nrec"] == syn.nrec and st["n_main"] == syn.n - syn.nrec * 31
+    got = d.bwt_census().astype(np.int64)
+    want = census.astype(np.int64).copy()
+    want[3] += syn.nrec
+    assert (got == want).all()
+    _, h, dr = d.fetch_small()
+    assert len(h) == syn.nrec - 1 and (np.diff(h.astype(np.int64)) > 0).all() and 0 <= dr < syn.n
+    r = d.verify_device()
+    assert r["inverse_bwt_ok"] and r["inverse_bwt"]["steps"] == syn.n - 1 and r["inverse_bwt"]["mismatches"] == 0, r
+    d.close()
+    text.free()
+
+
 @pytest.mark.parametrize("devices,case,k,cap,tune", [([0, 0], "pan", 32, 0, 0), ([0, 0, 0], "chrom", 24, 150_000, 0),
                                                      ([0] * 8, "many", 32, 0, 0), ([0] * 5, "pan", 20, 60_000, 0),
                                                      ([0], "pan", 32, 0, 0), ([0, 0, 0], "pan", 32, 0, 32)])
