@@ -1,6 +1,6 @@
 """Randomised parity run against the oracle: random small collections (the generator of tests/test_gpu_parity.py plus
-larger repeat-heavy ones), random k, random key-range caps and the alternative device paths (cursor atomics, 64-bit
-cursors, no tie-group hand-off).  python scripts/gpu_fuzz.py [cases=300] [seed=1]"""
+larger repeat-heavy ones, runs of one symbol and tandem repeats), random k, random key-range caps and the alternative device paths (cursor atomics, 64-bit
+cursors, no tie-group hand-off, either SP prefilter, no pivot rounds).  python scripts/gpu_fuzz.py [cases=300] [seed=1]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -14,8 +14,17 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time(); bad = 0
 for c in range(cases):
-    kind = int(rng.integers(0, 4))
-    if kind == 0:
+    kind = int(rng.integers(0, 5))
+    if kind == 4:                            # periodic stretches: the pivot rounds of the large-block split
+        parts = []
+        for _ in range(int(rng.integers(2, 30))):
+            parts.append(np.full(int(rng.integers(50, 6000)), int(rng.integers(0, 4)), dtype=np.uint8))
+            parts.append(np.tile(rng.integers(0, 4, size=int(rng.integers(2, 7))).astype(np.uint8), int(rng.integers(20, 800))))
+            parts.append(rng.integers(0, 4, size=int(rng.integers(40, 1500))).astype(np.uint8))
+        cut = int(rng.integers(1, len(parts)))
+        recs = [np.concatenate(parts[:cut]), np.concatenate(parts[cut:])] if rng.integers(0, 2) else [np.concatenate(parts)]
+        recs = [r for r in recs if len(r) > 32]
+    elif kind == 0:
         recs = _adversarial(rng)
     elif kind == 1:
         recs = synth.pan_genome(int(rng.integers(2000, 60000)), int(rng.integers(1, 9)), seed=int(rng.integers(1, 1 << 30)))
@@ -28,7 +37,7 @@ for c in range(cases):
     else:
         recs = [rng.integers(0, 4, size=int(rng.integers(33, 3000))).astype(np.uint8) for _ in range(int(rng.integers(1, 40)))]
     k = int(rng.choice([12, 13, 16, 20, 24, 27, 31, 32]))
-    tune = int(rng.choice([0, 0, 32, 48, 128, 160, 256, 4096, 4096 + 32, 4096 + 6]))
+    tune = int(rng.choice([0, 0, 0, 32, 48, 128, 160, 256, 2048, 4096, 4096 + 32, 4096 + 6, 8192, 8192 + 128]))
     cap = int(rng.choice([0, 0, 4096, 20000, 300000]))
     sym = O.sym_from_codes(recs)
     ow, oh, od, ost = O.build_bwt(sym, k)
