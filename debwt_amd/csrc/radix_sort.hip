@@ -636,6 +636,8 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
 #endif                                 // fits whenever no bucket in it exceeds RL_CAP - RL_H keys
 #define RLW_CAP 1024                   // keys a single wave finishes (16 per lane, no barriers at all)
 #define RLW_H (RLW_CAP * 7 / 8)
+#define RLU_LONG 16u                   // unfit stretches of this many raster tiles or more: run-length encoded by several workgroups
+#define RLU_ROWS 64                    //   grid rows of that launch
 #ifndef RL_MAX_ROUNDS
 #define RL_MAX_ROUNDS 16               // merge-split rounds before a wave tile falls back to the full network
 #endif
@@ -965,7 +967,12 @@ __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ ke
     if (lane == 0) bnd[blockIdx.x] = s;
     if (s >= e) { if (lane == 0) tcnt[blockIdx.x] = 0; return; }
     if (e - s > CAP) {
-        if (lane == 0) unfit[atomicAdd(nunfit, 1u)] = blockIdx.x;              // counted by rs_unfit_rle<0>
+        if (lane == 0) {
+            unfit[atomicAdd(nunfit, 1u)] = blockIdx.x;                         // counted by rs_unfit_rle<0>
+            // a stretch of RLU_LONG raster tiles or more is listed again from the end of the array (the tiles inside it
+            // are empty, so the two lists never meet): several workgroups share its run-length encoding
+            if ((e - x0) / RLW_H >= RLU_LONG) unfit[gridDim.x - 1u - atomicAdd(nunfit + 2, 1u)] = blockIdx.x;
+        }
         u32 bad = 0;
         for (u64 i = s + lane; i + 1 < e && !bad; i += 64) bad = keys[i] > keys[i + 1] ? 1u : 0u;
         if (__ballot(bad != 0) == 0ull) return;
@@ -1133,9 +1140,14 @@ __global__ __launch_bounds__(256) void rs_tile_emit_kernel(const u64 *__restrict
     }
 }
 
-// One workgroup per unfit stretch, 8 consecutive keys per thread and step (16-byte loads).  A stretch that is one run of
-// equal keys (a homopolymer's k-mer: millions of instances) is recognised by its ends and has exactly one head.
-template <int EMIT>
+// Unfit stretches, 8 consecutive keys per thread and step (16-byte loads).  A stretch that is one run of equal keys (a
+// homopolymer's k-mer: millions of instances) is recognised by its ends and has exactly one head.  A long stretch is
+// cut into pieces along the raster of the wave tiles: the tiles that lie wholly inside it have nothing of their own
+// (rs_local_count found their range empty), so piece k counts into tcnt[t + k] and emits at tex[t + k] -- position
+// order is tile order.  LONG = 0: every stretch of fewer than RLU_LONG pieces, one workgroup each; LONG = 1: the long
+// list (rs_local_count), the workgroups of grid row y take the pieces y, y + gridDim.y, ... of a stretch (a repeat
+// family with 10^6 copies gives stretches of millions of keys that one workgroup used to walk alone).
+template <int EMIT, int LONG>
 __global__ __launch_bounds__(256) void rs_unfit_rle_kernel(const u64 *__restrict__ keys, u64 n,
                                                            const u64 *__restrict__ bnd, u32 nwtiles,
                                                            const u32 *__restrict__ unfit, const u32 *__restrict__ nunfit,
@@ -1145,65 +1157,75 @@ __global__ __launch_bounds__(256) void rs_unfit_rle_kernel(const u64 *__restrict
     constexpr u32 V = 8, STEP = 256 * V;
     __shared__ u32 wsum[4];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const u32 nu = *nunfit;
+    const u32 nu = LONG ? nunfit[2] : nunfit[0];
     for (u32 i = blockIdx.x; i < nu; i += gridDim.x) {
-        const u32 t = unfit[i];
+        const u32 t = LONG ? unfit[nwtiles - 1u - i] : unfit[i];
         const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
-        u32 run = EMIT ? tex[t] + boff[t / RLT_BLOCK] : 0u;                 // distinct keys before the tile
+        const u64 x0 = (u64)t * RLW_H;
+        const u64 K64 = (e - x0) / RLW_H;                                    // raster tiles wholly inside [x0, e)
+        const u32 K = K64 < 1 ? 1u : (u32)K64;
+        if (!LONG && K >= RLU_LONG) continue;                                // the long list's
         const u64 kfirst = keys[s];
         const bool one_run = kfirst == keys[e - 1];                          // sorted: every key of the stretch is equal
-        if (one_run) {
-            if (!EMIT) { if (tid == 0) tcnt[t] = 1; continue; }
-            if (tid == 0) { dk[run] = kfirst; dstart[run] = (u32)s; }
-            const u8 sy = (u8)(kfirst & 3);
-            for (u64 j = s + tid; j < e; j += 256) mchar[j] = sy;
-            continue;
-        }
-        for (u64 p = s; p < e; p += STEP) {
-            const u64 j0 = p + (u64)tid * V;
-            u64 k[V + 1];
-            const bool whole = j0 + V <= e && ((j0 & 1ull) == 0);
-            if (whole) {
+        for (u32 k = LONG ? blockIdx.y : 0u; k < K; k += LONG ? gridDim.y : 1u) {
+            const u64 lo = x0 + (u64)k * RLW_H, hi = k + 1 == K ? e : lo + RLW_H;
+            const u64 ps = lo > s ? lo : s, pe = hi;                         // the piece's part of the stretch
+            u32 run = EMIT ? tex[t + k] + boff[(t + k) / RLT_BLOCK] : 0u;   // distinct keys before the piece
+            if (ps >= pe) { if (!EMIT && tid == 0) tcnt[t + k] = 0; continue; }
+            if (one_run) {
+                if (!EMIT) { if (tid == 0) tcnt[t + k] = ps == s ? 1u : 0u; continue; }
+                if (tid == 0 && ps == s) { dk[run] = kfirst; dstart[run] = (u32)s; }
+                const u8 sy = (u8)(kfirst & 3);
+                for (u64 j = ps + tid; j < pe; j += 256) mchar[j] = sy;
+                continue;
+            }
+            for (u64 p = ps; p < pe; p += STEP) {
+                const u64 j0 = p + (u64)tid * V;
+                u64 kk[V + 1];
+                const bool whole = j0 + V <= pe && ((j0 & 1ull) == 0);
+                if (whole) {
 #pragma unroll
-                for (u32 q = 0; q < V; q += 2) {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + j0 + q);
-                    k[1 + q] = v.x; k[2 + q] = v.y;
+                    for (u32 q = 0; q < V; q += 2) {
+                        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + j0 + q);
+                        kk[1 + q] = v.x; kk[2 + q] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (u32 q = 0; q < V; q++) kk[1 + q] = j0 + q < pe ? keys[j0 + q] : 0ull;
                 }
-            } else {
-#pragma unroll
-                for (u32 q = 0; q < V; q++) k[1 + q] = j0 + q < e ? keys[j0 + q] : 0ull;
-            }
-            k[0] = (j0 > s && j0 < e) ? keys[j0 - 1] : 0ull;
-            u32 heads = 0;
-#pragma unroll
-            for (u32 q = 0; q < V; q++) {
-                const u64 j = j0 + q;
-                if (j < e && (j == s || k[q] != k[1 + q])) heads |= 1u << q;
-            }
-            const u32 cnt = (u32)__popc(heads);
-            const u32 incl = wave_scan_incl(cnt);
-            if (lane == 63) wsum[w] = incl;
-            __syncthreads();
-            u32 before = incl - cnt, tot = 0;
-#pragma unroll
-            for (u32 x = 0; x < 4; x++) { const u32 v = wsum[x]; before += x < w ? v : 0u; tot += v; }
-            if (EMIT && j0 < e) {
-                u64 off = (u64)run + before;
+                kk[0] = (j0 > s && j0 < pe) ? keys[j0 - 1] : 0ull;
+                u32 heads = 0;
 #pragma unroll
                 for (u32 q = 0; q < V; q++) {
                     const u64 j = j0 + q;
-                    if (j < e) {
-                        mchar[j] = (u8)(k[1 + q] & 3);
-                        if ((heads >> q) & 1u) { dk[off] = k[1 + q]; dstart[off] = (u32)j; off++; }
+                    if (j < pe && (j == s || kk[q] != kk[1 + q])) heads |= 1u << q;
+                }
+                const u32 cnt = (u32)__popc(heads);
+                const u32 incl = wave_scan_incl(cnt);
+                if (lane == 63) wsum[w] = incl;
+                __syncthreads();
+                u32 before = incl - cnt, tot = 0;
+#pragma unroll
+                for (u32 x = 0; x < 4; x++) { const u32 v = wsum[x]; before += x < w ? v : 0u; tot += v; }
+                if (EMIT && j0 < pe) {
+                    u64 off = (u64)run + before;
+#pragma unroll
+                    for (u32 q = 0; q < V; q++) {
+                        const u64 j = j0 + q;
+                        if (j < pe) {
+                            mchar[j] = (u8)(kk[1 + q] & 3);
+                            if ((heads >> q) & 1u) { dk[off] = kk[1 + q]; dstart[off] = (u32)j; off++; }
+                        }
                     }
                 }
+                run += tot;
+                __syncthreads();
             }
-            run += tot;
-            __syncthreads();
+            if (!EMIT && tid == 0) tcnt[t + k] = run;
         }
-        if (!EMIT && tid == 0) tcnt[t] = run;
     }
 }
+
 
 // workspace of the counting finish, nw tiles in nb scan blocks:
 //   [nunfit, total, pad, pad][bnd u64 x nw][tcnt u32 x nw][unfit u32 x nw][tex u32 x nw][bsum u32 x nb][boff u32 x nb]
@@ -1421,12 +1443,16 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
     if (sink) {
         const u32 ug = nwtiles < 2048u ? nwtiles : 2048u;
         const u32 nb = (nwtiles + RLT_BLOCK - 1) / RLT_BLOCK;
-        rs_unfit_rle_kernel<0><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
+        rs_unfit_rle_kernel<0, 0><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
+                                                       rle_boff, sink->dk, sink->dstart, sink->mchar);
+                rs_unfit_rle_kernel<0, 1><<<dim3(64, RLU_ROWS), 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
                                                        rle_boff, sink->dk, sink->dstart, sink->mchar);
         rs_tile_scan1_kernel<<<nb, 256, 0, stream>>>(rle_tcnt, nwtiles, rle_tex, rle_bsum);
         rs_tile_scan2_kernel<<<1, 1024, 0, stream>>>(rle_bsum, nb, rle_boff, rle_ctr + 1);
         rs_tile_emit_kernel<<<(nwtiles + 3) / 4, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_tex, rle_boff, sink->dk, sink->dstart);
-        rs_unfit_rle_kernel<1><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
+        rs_unfit_rle_kernel<1, 0><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
+                                                       rle_boff, sink->dk, sink->dstart, sink->mchar);
+                rs_unfit_rle_kernel<1, 1><<<dim3(64, RLU_ROWS), 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
                                                        rle_boff, sink->dk, sink->dstart, sink->mchar);
         (void)hipMemcpyAsync(sink->h_total, rle_ctr + 1, sizeof(u32), hipMemcpyDeviceToHost, stream);
         sink->done = true;

@@ -251,6 +251,27 @@ def test_hip_periodic_stretches_pivot_rounds(api, oracle, seed, runs, maxrun):
         d.close()
 
 
+@pytest.mark.parametrize("k", [32, 20])
+def test_hip_long_unfit_stretch_of_the_key_sort(api, oracle, k):
+    """A run of one symbol with 10 % substitutions: nearly half of its k-mers share their first 8 symbols -- one bucket of
+    the two top radix passes with 10^5 keys that differ further down.  The bucket leaves through the all-HBM path and its
+    run-length encoding is shared by several workgroups along the raster of the wave tiles (rs_unfit_rle_kernel<*, 1>)."""
+    rng = np.random.default_rng(17)
+    run = np.zeros(260_000, dtype=np.uint8)
+    hit = rng.random(len(run)) < 0.10
+    run[hit] = rng.integers(1, 4, size=int(hit.sum()))
+    recs = [np.concatenate([rng.integers(0, 4, size=5000).astype(np.uint8), run, rng.integers(0, 4, size=5000).astype(np.uint8)]),
+            rng.integers(0, 4, size=700).astype(np.uint8)]
+    ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), k)
+    d = api.DeBWT(k=k)
+    d.load_records(recs)
+    for _ in range(2):
+        d.build()
+        words, hrows, drow = d.fetch()
+        assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
+    d.close()
+
+
 def test_hip_large_tie_ranges_go_deeper(api, oracle):
     """3000 exact copies of a segment full of branching nodes: the rows of a node early in the segment tie for more than
     the 42 SP symbols a split looks at, in groups above the LDS capacity -- those ranges are split again one pair of
