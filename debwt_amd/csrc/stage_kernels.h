@@ -929,6 +929,8 @@ struct BlueSub {
 #ifndef BLUE_RANK_MAX
 #define BLUE_RANK_MAX 128u   // workgroup kernels: tie groups up to this size are ordered by counting ranks
 #endif
+#define GC_CNT(v) ((v) & 0xFFFFu)
+#define GC_UNRES(v) (((v) & 0xFFFFu) > 1u && (((v) >> 16) & (((v) >> 16) - 1u)) != 0u)   // several rows, several symbols
 template <int NT, int CAP, int SPLIT>
 __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, const u64 *__restrict__ bstart,
                                                      const u32 *__restrict__ mi_freq, const u64 *__restrict__ mi_j0,
@@ -938,9 +940,10 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
     __shared__ u64 se[CAP];     // entries
     __shared__ u64 sw[CAP];     // current window, first 21 symbols
     __shared__ u64 sx[CAP];     //                 next 21 symbols
-    __shared__ u32 sg[CAP];     // tie group = index of its first row
-    __shared__ u32 gcnt[CAP];   // rows per group   (also scratch for the boundary scan)
-    __shared__ u32 gmsk[CAP];   // BWT symbols present per group
+    // 30 bytes of LDS per row (36 with 32-bit group ids and separate census words): the workgroups a CU holds are what
+    // these kernels run on
+    __shared__ unsigned short sg[CAP];   // tie group = index of its first row
+    __shared__ u32 gcm[CAP];    // per group: rows (low 16 bits) | BWT symbols present (high 16 bits)
     __shared__ u32 wtot[NT / 64 + 1];
     __shared__ u32 flag;
     __shared__ u32 smax;
@@ -978,8 +981,8 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             if (x < m) {
                 u64 e = blue[b0 + x];
                 se[x] = e; sg[x] = 0; mask |= 1u << (e & 15);
-            } else { se[x] = ~0ull; sg[x] = 0xFFFFFFFFu; sw[x] = ~0ull; sx[x] = ~0ull; }
-            gcnt[x] = m; gmsk[x] = 0x3u;                      // round 0: one group, unresolved
+            } else { se[x] = ~0ull; sg[x] = 0xFFFFu; sw[x] = ~0ull; sx[x] = ~0ull; }
+            gcm[x] = m | (0x3u << 16);                      // round 0: one group, unresolved
         }
         __syncthreads();
         if (mask) atomicOr(&flag, mask);
@@ -1069,7 +1072,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                 __syncthreads();
                 if (tid < BINS && bin_cnt[tid]) {
                     const u32 g = bin_start[tid];
-                    gcnt[g] = bin_cnt[tid]; gmsk[g] = 0x3u;
+                    gcm[g] = bin_cnt[tid] | (0x3u << 16);
                     for (u32 y = g; y < g + bin_cnt[tid]; y++) sg[y] = g;
                 }
                 maxg = smax;
@@ -1095,7 +1098,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             if (!(preloaded && depth == 0))
             for (u32 x = tid; x < m; x += NT) {
                 u32 g = sg[x];
-                bool unresolved = gcnt[g] > 1 && (gmsk[g] & (gmsk[g] - 1));
+                bool unresolved = GC_UNRES(gcm[g]);
                 u64 pos = (se[x] >> 4) + (d0 + depth) * (2 * SP_WIN);
                 bool live = unresolved && pos < S;
                 sw[x] = live ? sp_window(spn, pos) : 0ull;
@@ -1108,7 +1111,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                 u32 differs = 0;
                 for (u32 x = tid; x < m; x += NT) {
                     const u32 g = sg[x];
-                    if (gcnt[g] > 1 && (gmsk[g] & (gmsk[g] - 1))) differs |= (sw[x] != sw[g] || sx[x] != sx[g]) ? 1u : 0u;
+                    if (GC_UNRES(gcm[g])) differs |= (sw[x] != sw[g] || sx[x] != sx[g]) ? 1u : 0u;
                 }
                 if (!__syncthreads_or((int)differs) && !(preloaded && depth == 0)) {
                     active = (d0 + depth + 1) * (2 * SP_WIN) < S + 2 * SP_WIN;
@@ -1127,8 +1130,9 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                     npos[c] = 0xFFFFFFFFu;
                     if (x < m) {
                         u32 g = sg[x];
-                        u32 cnt = gcnt[g];
-                        if (cnt > 1 && (gmsk[g] & (gmsk[g] - 1))) {
+                        const u32 gc = gcm[g];
+                        u32 cnt = GC_CNT(gc);
+                        if (GC_UNRES(gc)) {
                             u64 wx = sw[x], xx = sx[x];
                             u32 rank = 0;
                             for (u32 y = g; y < g + cnt; y++) {
@@ -1203,7 +1207,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                         u32 x = xb + c;
                         u32 v = loc[c] > excl ? loc[c] : excl;
                         if (x < m) sg[x] = v - 1;
-                        gcnt[x] = 0; gmsk[x] = 0;
+                        gcm[x] = 0;
                     }
                 }
             }
@@ -1212,14 +1216,14 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             // 4. census of the new groups
             for (u32 x = tid; x < m; x += NT) {
                 u32 g = sg[x];
-                atomicAdd(&gcnt[g], 1u);
-                atomicOr(&gmsk[g], 1u << (se[x] & 15));
+                atomicAdd(&gcm[g], 1u);
+                atomicOr(&gcm[g], (1u << (se[x] & 15)) << 16);
             }
             __syncthreads();
             u32 any = 0;
             for (u32 x = tid; x < m; x += NT) {
                 u32 g = sg[x];
-                if (g == x && gcnt[g] > 1 && (gmsk[g] & (gmsk[g] - 1))) any = any > gcnt[g] ? any : gcnt[g];
+                if (g == x && GC_UNRES(gcm[g])) any = any > GC_CNT(gcm[g]) ? any : GC_CNT(gcm[g]);
             }
             if (any) { flag = 1; atomicMax(&smax, any); }
             __syncthreads();
@@ -1232,7 +1236,7 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                 __syncthreads();
                 u32 mine = 0;
                 for (u32 x = tid; x < m; x += NT)
-                    if (sg[x] == x && gcnt[x] > 1 && (gmsk[x] & (gmsk[x] - 1))) mine++;
+                    if (sg[x] == x && GC_UNRES(gcm[x])) mine++;
                 if (mine) atomicAdd(&sub_n, mine);
                 __syncthreads();
                 if (tid == 0) { sub_base = atomicAdd(sub.count, sub_n); sub_i = 0; }
@@ -1240,9 +1244,9 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                 const u32 base = sub_base;
                 if ((u64)base + sub_n <= (u64)sub.cap) {                 // else: the table is full, keep refining here
                     for (u32 x = tid; x < m; x += NT)
-                        if (sg[x] == x && gcnt[x] > 1 && (gmsk[x] & (gmsk[x] - 1))) {
+                        if (sg[x] == x && GC_UNRES(gcm[x])) {
                             const u32 e = base + atomicAdd(&sub_i, 1u);
-                            sub.start[e] = b0 + x; sub.freq[e] = gcnt[x]; sub.j0[e] = j0 + x;
+                            sub.start[e] = b0 + x; sub.freq[e] = GC_CNT(gcm[x]); sub.j0[e] = j0 + x;
                             sub.depth[e] = (u32)(d0 + depth + 1);
                         }
                     active = false;
