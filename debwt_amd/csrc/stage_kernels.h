@@ -931,8 +931,12 @@ struct BlueSub {
 #endif
 #define GC_CNT(v) ((v) & 0xFFFFu)
 #define GC_UNRES(v) (((v) & 0xFFFFu) > 1u && (((v) >> 16) & (((v) >> 16) - 1u)) != 0u)   // several rows, several symbols
+// Waves per SIMD asked of the compiler per class: these kernels wait on SP gathers, and a few spilled registers cost less
+// than the waves they free (measured at 30 Gbp: <=128 rows 7 -> 8 waves 43.6 -> 38.7 ms per launch; 257..512 rows 5 -> 8
+// waves 66.9 -> 51.1 ms, their queued ranges 7 -> 8 waves 77.2 -> 68.9 ms; 513..1024 rows stay at 4: 5 waves with 88
+// bytes of scratch ran 3 % slower).  129..256 rows are held to 5 by their LDS.
 template <int NT, int CAP, int SPLIT>
-__global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, const u64 *__restrict__ bstart,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ? 8 : (CAP <= 256 ? 5 : (CAP <= 512 ? 8 : (CAP <= 1024 ? 4 : 2)))))) void k_blue_refine(u64 *__restrict__ blue, const u64 *__restrict__ bstart,
                                                      const u32 *__restrict__ mi_freq, const u64 *__restrict__ mi_j0,
                                                      u32 Q, u32 lo_excl, const u64 *__restrict__ spn, u64 S,
                                                      u8 *__restrict__ mchar, const u32 *__restrict__ depth0,
@@ -951,7 +955,10 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
     // sample-sort split of a large block (workgroup classes): 64 sampled rows, BINS - 1 splitters (measured at 30 Gbp:
     // 8, 16 or 32 ranges per block all give a blue stage of 0.48-0.50 s; 64 ranges overflow the sub-block table)
     constexpr int BINS = (SPLIT && NT == 256) ? CAP / 32 : 1, SAMPLES = BINS > 1 ? 4 * BINS : 64;
-    __shared__ u64 smp_w[SAMPLES], smp_x[SAMPLES], spl_w[BINS], spl_x[BINS];
+    __shared__ u64 spl_w[BINS], spl_x[BINS];
+    // the sampled windows of the split live in the census words, which are not in use before the first round
+    static_assert(BINS == 1 || (size_t)CAP * sizeof(u32) >= (size_t)SAMPLES * 2 * sizeof(u64), "samples alias the census words");
+    u64 *const smp_w = reinterpret_cast<u64 *>(gcm), *const smp_x = smp_w + SAMPLES;
     __shared__ u32 bin_cnt[BINS], bin_start[BINS], bin_cur[BINS], bin_slot[BINS];
     const u32 tid = threadIdx.x;
     if (Qdev) { u32 qd = *Qdev; Q = qd < Q ? qd : Q; }           // sub-block table: entries written so far (<= its capacity)
@@ -982,7 +989,6 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
                 u64 e = blue[b0 + x];
                 se[x] = e; sg[x] = 0; mask |= 1u << (e & 15);
             } else { se[x] = ~0ull; sg[x] = 0xFFFFu; sw[x] = ~0ull; sx[x] = ~0ull; }
-            gcm[x] = m | (0x3u << 16);                      // round 0: one group, unresolved
         }
         __syncthreads();
         if (mask) atomicOr(&flag, mask);
@@ -1091,6 +1097,10 @@ __global__ __launch_bounds__(NT) void k_blue_refine(u64 *__restrict__ blue, cons
             } else {
                 for (u32 x = tid; x < m; x += NT) sg[x] = 0;   // too skewed (or the table is full): the rounds below
             }
+            __syncthreads();
+        }
+        if (!preloaded && !handed) {                           // round 0: one group (its first row is row 0), unresolved
+            if (tid == 0) gcm[0] = m | (0x3u << 16);
             __syncthreads();
         }
         for (u64 depth = 0; active; depth++) {
