@@ -1375,7 +1375,7 @@ extern "C" int debwt_shard_plan(debwt_ctx *c, const uint64_t *hist4096, uint32_t
 }
 
 // Key exchange or key rescan (include/debwt_hip.h).  Per-GPU milliseconds of what differs between the two, calibrated
-// on 30 Gbp builds in a process group of one (profiles/r02_v22_bench_30G_keys_*.json):
+// on 30 Gbp builds in a process group of one (profiles/r02_v24_bench_30G_keys_*.json):
 //   rescan    a first radix pass that reads the whole text and keeps one key range takes 32.3 ms per 30 Gbp read, the
 //             histogram pass before it about as much                          -> 2.2 ms per Gbp read and key range
 //   exchange  sort stage 2195 ms against 1230 ms: the slice is read once per round, its keys are written grouped by
