@@ -15,7 +15,9 @@ assembly) over that collection.
   N = 1   the one GPU builds the whole BWT: the key space is cut into k-mer-prefix ranges that are sorted one after
           the other over the resident text.
   N > 1   ONE collection, built by N k-mer-prefix shards (strong scaling: the same 30 Gbp at every N): census
-          all-reduce, all_to_all of the 8-byte k-mers to their bucket owners (RCCL over xGMI), local sort and
+          all-gather; the keys of a shard's ranges either arrive by all_to_all of the 8-byte k-mers (RCCL over xGMI,
+          --mode exchange) or are read from the shard's own copy of the text (--mode rescan) -- --mode auto, the
+          default, takes the cheaper one by the library's cost model, which on one node is the second; local sort and
           classification, all-gather of the branching-node facts and of the SP code, all_to_all of the blue entries,
           local blue sort and assembly, final concatenation of the row ranges on rank 0.
 `value` = bases / wall time of a step with the packed text resident in HBM (on every GPU) and the result left in
