@@ -7,7 +7,7 @@ W=${1:-chr1_250M}; R=${2:-3}
 mkdir -p gpurun_out
 python bench.py --gpus 1 --force-sharded --workload $W --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/multi_nccl1.json
 tail -c 1200 gpurun_out/multi_nccl1.json; echo
-for mode in exchange scan; do
+for mode in auto exchange; do
 python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 --master-port 29577 \
     bench.py --gpus $R --backend gloo --mode $mode --workload $W --steps 2 --warmup 1 > gpurun_out/multi_gloo_$mode.json
 tail -c 1500 gpurun_out/multi_gloo_$mode.json; echo
