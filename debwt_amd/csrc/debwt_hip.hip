@@ -1044,7 +1044,7 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
                 wgs += (wk.m + 255u) / 256u;
             }
             const size_t nblk = desc.size();
-            const size_t over_cap = (size_t)(rows / BLUE_LDS_CAP) + 2;
+            const size_t over_cap = (size_t)(rows / LS_QUEUE_CAP) + 2;
             // scratch: w, x, en (u64 per row), bin (u32 per row); per block: splitters, range words, result, descriptor;
             // the batch's oversize ranges
             const size_t per_blk = LS_MAXBINS * 16 + LS_MAXR * 12 + 4 + sizeof(LsBlock);
@@ -1159,7 +1159,7 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
         // kernels take (queued like the tie groups); what a split cannot separate goes through the bitonic network
         if (c->nlarge && (rc = sort_large_blocks(c, sub))) return rc;
         // the queued groups: blocks of their own that start `depth` windows in (<= 128 rows from the 512 class,
-        // <= 512 rows from the 2048 class)
+        // <= 512 rows from the 2048 class and from the split of the large blocks: LS_QUEUE_CAP)
         const u32 gs = std::min<u32>(sub_cap, 1u << 16);
         k_blue_refine<64, 128, 0><<<gs, 64, 0, c->stream>>>(
             c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 0u,
@@ -1170,10 +1170,6 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
         // (257..512 queued rows are one deep tie group as a rule: four waves per block gather its windows four times as wide)
         k_blue_refine<256, BLUE_WAVE_CAP, 0><<<std::min<u32>(gs, 1u << 14), 256, 0, c->stream>>>(
             c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 256u,
-            c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
-        if (c->nlarge)                                             // only the split of large blocks queues more than 512 rows
-            k_blue_refine<256, BLUE_LDS_CAP, 0><<<std::min<u32>(gs, 1u << 12), 256, 0, c->stream>>>(
-            c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, (u32)BLUE_WAVE_CAP,
             c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
     }
     c->stage = ST_BLUE;

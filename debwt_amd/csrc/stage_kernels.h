@@ -1276,6 +1276,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ?
 }
 
 #define BLUE_LDS_CAP 2048
+#ifndef LS_QUEUE_CAP
+#define LS_QUEUE_CAP 512               // largest range the split of a large block queues for the LDS kernels; a larger one is split again
+#endif                                 // (measured on distribution R at 3.1 Gbp: blue stage 102 ms with 2048, 87 with 512, 97 with 256, 104 with 128:
+                                       //  the 2048-row kernel holds two workgroups per CU, the 512-row one eight waves per SIMD)
+static_assert(LS_QUEUE_CAP <= BLUE_WAVE_CAP, "the queue is drained by the kernels of up to BLUE_WAVE_CAP rows");
 
 // Blocks above BLUE_LDS_CAP rows: one level of sample sort in HBM, all pending blocks in the same five launches.
 // Per block: the next 42 SP symbols (two windows, `depth` pairs in) of `ns` evenly spaced rows are sorted by one
@@ -1426,7 +1431,7 @@ __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub s
     u32 my[2] = {0, 0};
     for (int h = 0; h < 2; h++) {
         if (2 * tid + h < nr) ls.start[blockIdx.x * LS_MAXR + 2 * tid + h] = st[h];
-        if (c[h] >= 1 && c[h] <= BLUE_LDS_CAP) my[h] = atomicAdd(&nsub, 1u);
+        if (c[h] >= 1 && c[h] <= LS_QUEUE_CAP) my[h] = atomicAdd(&nsub, 1u);
     }
     __syncthreads();
     if (tid == 0) {
@@ -1440,12 +1445,12 @@ __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub s
     // sub-block starts conservatively at B.depth there, as before)
     const u32 adv_tie = B.pivot ? (tid + 1 < B.nb ? ls_pivot_adv(ls.spl_w[(size_t)blockIdx.x * LS_MAXBINS + tid]) : 0u) : 1u;
     for (int h = 0; h < 2; h++) {
-        if (c[h] >= 1 && c[h] <= BLUE_LDS_CAP && !full) {
+        if (c[h] >= 1 && c[h] <= LS_QUEUE_CAP && !full) {
             const u32 e = base + my[h];
             sub.start[e] = B.b0 + st[h]; sub.freq[e] = c[h]; sub.j0[e] = B.j0 + st[h];
             sub.depth[e] = B.depth + (h && B.pivot ? adv_tie : 0u);
         }
-        if (c[h] > BLUE_LDS_CAP && !full)                                   // h = 1: a range of ties
+        if (c[h] > LS_QUEUE_CAP && !full)                                    // h = 1: a range of ties
             ls.over[atomicAdd(ls.nover, 1u)] = LsOver{blockIdx.x, st[h], c[h], (u32)h, h ? adv_tie : 0u};
     }
 }
