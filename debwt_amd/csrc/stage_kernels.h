@@ -658,7 +658,6 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
             mprev = m;
             const u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
             cand |= (u32)((fwv >> mz_bit(win >> (64 - 2 * K))) & 1ull) << t;
-            spec |= (((sb >> t) & kmask) ? 1u : 0u) << t;
         }
     } else {
 #pragma unroll
@@ -667,8 +666,11 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
         u32 hb = red_hash2(win >> (64 - 2 * K), pb);
         u32 bit = (rbits[hb >> 5] >> (hb & 31)) & 1u;
         cand |= bit << t;
-        spec |= (((sb >> t) & kmask) ? 1u : 0u) << t;
     }
+    }
+    if (sb) {                                                    // a separator within 64 positions: rare, tested apart
+#pragma unroll
+        for (u32 t = 0; t < 32; t++) spec |= (((sb >> t) & kmask) ? 1u : 0u) << t;
     }
     cand &= inrange & ~spec;
     spec &= inrange;
