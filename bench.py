@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Gbp/s of BWT construction on MI355X (BASELINE.json metric), one process per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--k 32]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--k 32]      (N > 1: starts its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (default, every N): BASELINE.json configs[4], the configuration the metric is quoted on -- 10 genomes x
@@ -107,6 +107,32 @@ def cpu_reference(codes, k, threads):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` run directly (no launcher, WORLD_SIZE unset): start the N ranks as CHILD processes
+    of this one -- `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` -- before anything here
+    has touched the GPU (no torch import yet, and never an exec of a process that has), hand rank 0's one JSON line
+    through to stdout (everything else the ranks print goes to stderr) and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in p.stdout:
+        is_line = False
+        if ln.startswith("{"):
+            try:
+                is_line = "metric" in json.loads(ln)
+            except ValueError:
+                pass
+        (sys.stdout if is_line else sys.stderr).write(ln)
+        (sys.stdout if is_line else sys.stderr).flush()
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +149,7 @@ def main():
     ap.add_argument("--tune", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # gloo: ranks may share one GPU (tests)
     ap.add_argument("--force-sharded", action="store_true", help=argparse.SUPPRESS)   # the N>1 code path at N = 1 (tests)
+    ap.add_argument("--launch-probe", action="store_true", help=argparse.SUPPRESS)    # rendezvous only, no GPU (CPU tests)
     ap.add_argument("--mode", choices=["auto", "exchange", "rescan", "scan", "replicas"], default="auto",
                     help="N>1: ONE collection built by N k-mer-prefix shards; SP symbols, facts, blue entries and the "
                          "final rows always travel over RCCL.  'exchange' = the 8-byte keys travel too (all_to_all per "
@@ -130,14 +157,29 @@ def main():
                          "'auto' (default) = the cheaper of the two by the library's cost model (debwt_shard_key_mode); "
                          "'scan' = no bulk exchange at all; 'replicas' = N independent collections (no collective)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
+    from debwt_amd import dist as D
+    rank, local_rank, world = D.env_world()
+    if args.launch_probe:                      # what the CPU suite can check of the N > 1 start: ranks up, one line out
+        D.init(backend="gloo")
+        total = D.sum_over_ranks(1)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "probe": True, "n_gpus": args.gpus, "ranks_joined": int(total)}), flush=True)
+        else:
+            print(f"rank {rank} joined", flush=True)
+        D.finalize()
+        return
 
     import torch
     from debwt_amd import api
-    from debwt_amd import dist as D
     from debwt_amd import synth_native as SN
 
-    rank, local_rank, world = D.env_world()
-    assert world == args.gpus or (world == 1 and args.gpus == 1), "launch one process per GPU"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks (one process per GPU)")
     if args.backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)

@@ -123,10 +123,18 @@ int main(int argc, char **argv) {
             gpus = atoi(argv[i + 1]);
             if (gpus < 1 || gpus > 255) { fprintf(stderr, "--gpus: 1 to 255\n"); return 1; }
         } else if (!strcmp(argv[i], "--devices")) {
-            for (const char *p = argv[i + 1]; *p && ndevs < 255;) {
-                devs[ndevs++] = (int)strtol(p, (char **)&p, 10);
-                if (*p == ',') p++;
+            ndevs = 0;
+            for (const char *p = argv[i + 1]; *p;) {
+                char *end;
+                long v = strtol(p, &end, 10);
+                if (end == p || v < 0 || v > 1023 || ndevs >= 255 || (*end && *end != ',') || (*end == ',' && !end[1])) {
+                    fprintf(stderr, "--devices: a comma-separated list of GPU ordinals, e.g. 0,1,2,3\n");
+                    return 1;
+                }
+                devs[ndevs++] = (int)v;
+                p = *end ? end + 1 : end;
             }
+            if (!ndevs) { fprintf(stderr, "--devices: a comma-separated list of GPU ordinals, e.g. 0,1,2,3\n"); return 1; }
         }
         else if (!strcmp(argv[i], "--keys")) {
             if (!strcmp(argv[i + 1], "exchange")) key_mode = DEBWT_KEYS_EXCHANGE;
@@ -144,8 +152,13 @@ int main(int argc, char **argv) {
     remove(obj);
 
     fprintf(stderr, "run deBWT (MI355X path): sequence file %s, output %s, k-mer length %d\n", source, obj, k);
+    if (ndevs && !gpus) gpus = ndevs;                                       /* --devices alone names the GPUs */
+    if (ndevs && ndevs != gpus) {
+        fprintf(stderr, "--devices names %d GPUs but --gpus asks for %d\n", ndevs, gpus);
+        return 1;
+    }
     if (gpus) return multi_main(source, obj, k, (int)(threads > 256 ? 256 : threads), iupac, iupac_seed, gpus,
-                                ndevs == gpus ? devs : NULL, key_mode);
+                                ndevs ? devs : NULL, key_mode);
     double t0 = now();
     debwt_config cfg = {k, device, 0, 0};
     debwt_ctx *ctx = NULL;

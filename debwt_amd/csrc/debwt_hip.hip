@@ -305,8 +305,11 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
     delete c;
 }
 
+static void join_special(debwt_ctx *c);
+
 extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n, const uint64_t *sep, uint64_t nrec) {
     if (!c || !packed || !sep || nrec == 0 || n < 34) return DEBWT_EINVAL;
+    join_special(c);            // a special-region thread left behind by a failed stage still reads the text of the load before
     if (sep[nrec - 1] != n - 1) return DEBWT_EINVAL;
     uint64_t prev = 0;
     for (uint64_t r = 0; r < nrec; r++) {
@@ -535,6 +538,8 @@ static int sort_begin(debwt_ctx *c) {
         auto t0 = std::chrono::steady_clock::now();
         build_special_tables(c->h_text, n, c->h_sep.data(), c->nrec, c->K, &c->special);
         c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        c->st.special_threads = c->special.threads_used;
+        c->st.special_path = c->special.threads_used > 1 ? 1 : 0;
     });
     // several ranges read off the text: the chunk histograms of every range's first pass from ONE scan of the text (a
     // lane per text word, radix_text_hist_ranges); a single range of a long text takes the same kernel -- it is twice
@@ -1488,9 +1493,12 @@ extern "C" int debwt_shard_partition_keys(debwt_ctx *c, const uint8_t *shard_of_
     RsDigit dg{};
     dg.mode = 1; dg.tab = c->dest_tab.as<u8>(); dg.tshift = tshift;
     hipError_t e = radix_partition_by_shard(c->stream, nullptr, &ts, p1 - p0, (u64 *)d_out, dg, (u32)c->shard_world,
-                                            radix_ws(c), (u64 *)offs, sparse);
+                                            radix_ws(c), (u64 *)offs, sparse, capacity);
+    if (e == hipErrorInvalidValue && offs[c->shard_world] > capacity) {       // refused before the scatter wrote anything
+        c->err = "partition output exceeds the caller's buffer";
+        return DEBWT_EINTERNAL;
+    }
     if (e != hipSuccess) { c->err = hipGetErrorString(e); return DEBWT_EDEVICE; }
-    if (offs[c->shard_world] > capacity) { c->err = "partition output exceeds the caller's buffer"; return DEBWT_EINTERNAL; }
     return DEBWT_OK;
 }
 
@@ -1583,7 +1591,7 @@ extern "C" int debwt_shard_blue_route(debwt_ctx *c, const uint32_t *first_block_
     RsDigit dg{};
     dg.mode = 2; dg.bounds = c->qbounds.as<u32>(); dg.nb = w; dg.tshift = routed_qshift(c);
     hipError_t e = radix_partition_by_shard(c->stream, c->facts_tmp.as<u64>(), nullptr, c->B_rank, (u64 *)d_out, dg, w,
-                                            radix_ws(c), (u64 *)offs);
+                                            radix_ws(c), (u64 *)offs, false, capacity);
     if (e != hipSuccess) { c->err = hipGetErrorString(e); return DEBWT_EDEVICE; }
     return DEBWT_OK;
 }
@@ -1723,6 +1731,11 @@ extern "C" int debwt_fetch_array(debwt_ctx *c, debwt_array which, void *dst, uin
         case DEBWT_ARR_SORTED_KEYS:
         case DEBWT_ARR_DISTINCT_KEYS:
             if (c->ranges.size() != 1) { c->err = "sorted keys are not kept by a multi-range build"; return DEBWT_ESTATE; }
+            // the key buffers are scratch for the later stages (blue-entry sort), and in exchange mode they are the caller's
+            if (which == DEBWT_ARR_SORTED_KEYS && (c->stage > ST_CLASSIFIED || c->exchange)) {
+                c->err = "sorted keys are only kept until the SP stage reuses their buffer (and not in exchange mode)";
+                return DEBWT_ESTATE;
+            }
             if (which == DEBWT_ARR_SORTED_KEYS) { src = c->sk; cnt = c->M; } else { src = c->dk.p; cnt = c->D; }
             break;
         case DEBWT_ARR_RED: src = c->red.p; cnt = c->R; need = ST_CLASSIFIED; break;

@@ -41,19 +41,23 @@ struct DevMem {
     void release() { if (p) { (void)hipSetDevice(dev); (void)hipFree(p); p = nullptr; cap = 0; } }
 };
 
-// all threads call sync(rc); it returns false on every thread as soon as any thread brought an error
+// all threads call sync(rc); it returns false on every thread as soon as any thread brought an error.  The verdict of a
+// barrier is latched by the thread that closes it: a thread that runs ahead and fails before a slow waiter of the
+// barrier before has woken up must not change what that waiter returns (it would leave alone while the others wait for
+// it at the next barrier).
 struct Rendezvous {
     std::mutex m;
     std::condition_variable cv;
     int n = 1, waiting = 0, phase = 0;
     int failed = 0;
+    bool ok_of_phase[2] = {true, true};
     bool sync(int rc) {
         std::unique_lock<std::mutex> lk(m);
         if (rc && !failed) failed = rc;
         const int ph = phase;
-        if (++waiting == n) { waiting = 0; phase++; cv.notify_all(); }
+        if (++waiting == n) { waiting = 0; ok_of_phase[ph & 1] = failed == 0; phase++; cv.notify_all(); }
         else cv.wait(lk, [&] { return phase != ph; });
-        return failed == 0;
+        return ok_of_phase[ph & 1];
     }
 };
 

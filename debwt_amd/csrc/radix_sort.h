@@ -63,7 +63,7 @@ size_t radix_over_bytes(u64 max_keys);
 // tiles before ranking (rs_scatter_sparse_kernel)
 hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const TextKeySrc *text, u64 count, u64 *dst,
                                     const RsDigit &dg, u32 nshards, const RadixWorkspace &ws, u64 *offs_host,
-                                    bool sparse = false);
+                                    bool sparse, u64 capacity);
 
 // Sorts `n` keys ascending on their low `key_bits` bits.  a: input; b: scratch of n words.
 // Returns the buffer (a or b) that holds the result.  All work is enqueued on `stream`.

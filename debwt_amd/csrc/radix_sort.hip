@@ -1464,7 +1464,8 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
 // One bucketing pass by destination shard: `count` source items (text positions [text->pos0, +count) when `text`
 // is given, else the keys in `src`) -> `dst` grouped by shard; offs_host[0..nshards] receives the group offsets.
 hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const TextKeySrc *text, u64 count, u64 *dst,
-                                    const RsDigit &dg, u32 nshards, const RadixWorkspace &ws, u64 *offs_host, bool sparse) {
+                                    const RsDigit &dg, u32 nshards, const RadixWorkspace &ws, u64 *offs_host, bool sparse,
+                                    u64 capacity) {
     TextKeySrc none{};
     u32 nchunks; u64 chunk;
     rs_plan(count, &nchunks, &chunk);
@@ -1477,9 +1478,7 @@ hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const Te
     }
     rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
     rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
-    if (text && sparse) rs_scatter_sparse_kernel<0, 1><<<nchunks, SC_NT, 0, stream>>>(*text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
-    else if (text) rs_scatter_kernel<1, 1, 0><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
-    else rs_scatter_kernel<0, 1, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    // the group totals are known before anything is written: a buffer that cannot hold them is refused here, not overrun
     u32 tot[RS_RADIX];
     hipError_t e = hipMemcpyAsync(tot, digit_tot, sizeof tot, hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
@@ -1487,5 +1486,10 @@ hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const Te
     // digit_tot holds exclusive offsets; the last group ends at the number of valid items
     for (u32 i = 0; i < nshards; i++) offs_host[i] = tot[i];
     offs_host[nshards] = nshards < RS_RADIX ? tot[nshards] : 0;   // first empty digit starts where the data ends
+    if (offs_host[nshards] > capacity) return hipErrorInvalidValue;
+    if (text && sparse) rs_scatter_sparse_kernel<0, 1><<<nchunks, SC_NT, 0, stream>>>(*text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    else if (text) rs_scatter_kernel<1, 1, 0><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    else rs_scatter_kernel<0, 1, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, count, chunk, dg, ws.counts, digit_tot, nchunks);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     return hipGetLastError();
 }

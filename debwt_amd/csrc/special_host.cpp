@@ -105,6 +105,7 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
     struct Item { uint64_t key, pos, rec, next; };
     std::vector<Item> items(NS);
     const unsigned nt = special_threads(NS);
+    out->threads_used = nt;
     const uint64_t nchunks = nt > 1 ? (uint64_t)nt * 4 : 1;
     auto cut = [&](uint64_t total, uint64_t c) { return total / nchunks * c + std::min<uint64_t>(c, total % nchunks); };
     parallel_chunks(nt, nchunks, [&](uint64_t c) {

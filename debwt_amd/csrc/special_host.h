@@ -17,6 +17,7 @@ struct SpecialTables {
     // (node<<2|1) of the node instance immediately followed by the separator
     std::vector<uint64_t> head_keys;
     std::vector<uint64_t> tail_facts;
+    unsigned threads_used = 1;      // host threads the module ran on
 };
 
 // words: reference-format packed text (>= ceil((n+32)/32)+1 words readable); sep: separator

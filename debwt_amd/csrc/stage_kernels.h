@@ -842,7 +842,8 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const ulonglong2 *__r
 // block order), k_blue_strip turns them into blue entries (pred | spIndex << 4).  A sharded build routes the same
 // words (global block ids) to the shard that owns the block, where k_blue_place puts them into the block through a
 // cursor per owned block.
-__global__ void k_blue_strip(const u64 *__restrict__ src, u64 *__restrict__ dst, u64 n, int qshift) {
+// (src may be dst: every thread rewrites its own word)
+__global__ void k_blue_strip(const u64 *src, u64 *dst, u64 n, int qshift) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 e = src[i];

@@ -193,7 +193,8 @@ class Workspace:
     build allocates nothing and the library's own buffers never compete with a caching allocator's leftovers."""
 
     def __init__(self, d, device=None, mode="auto"):
-        assert mode in MODES
+        if mode not in MODES:
+            raise ValueError(f"mode {mode!r}: one of {MODES}")
         self.d, self.mode = d, mode
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.buf = {}
@@ -293,7 +294,8 @@ def build_sharded(d, ws=None, mode=None, device=None):
             offs = np.zeros(world + 1, dtype=np.uint64)
             _chk(d, L.debwt_shard_partition_keys(d._h, tab.ctypes.data_as(u8p), ctypes.c_void_p(xa.data_ptr()),
                                                  xa.numel(), offs.ctypes.data_as(u64p)))
-            assert [int(offs[i + 1] - offs[i]) for i in range(world)] == send, "partition differs from the census"
+            if [int(offs[i + 1] - offs[i]) for i in range(world)] != send:
+                raise RuntimeError("key partition differs from the census")
             xb = ws.get("xb", nrv + 64, torch.int64)
             t0 = time.perf_counter()
             _all_to_all(xb, xa, recv, send)
@@ -333,7 +335,8 @@ def build_sharded(d, ws=None, mode=None, device=None):
         allsp, got_sp = _all_gather_var(ws, "sp", mysp, s_loc.value, lens)
         sync()
         info["facts_sp_gather_ms"] += (time.perf_counter() - t0) * 1e3
-        assert got_sp == sp_total
+        if got_sp != sp_total:
+            raise RuntimeError(f"gathered {got_sp} SP symbols, the slices announced {sp_total}")
         _chk(d, L.debwt_shard_sp_import(d._h, ctypes.c_void_p(allsp.data_ptr()), sp_total))
 
         # 5. blue entries of my slice -> the owners of their blocks
@@ -413,7 +416,8 @@ def _concat_on_rank0(d, ws, dst=0):
                                 base.ctypes.data_as(u64p), rws.ctypes.data_as(u64p), n, ctypes.c_void_p(out.data_ptr())))
     hrows = np.sort(np.concatenate([lists[r, 1:1 + int(allr[r, 2])] for r in range(world)])).astype(np.uint64)
     dollars = [int(lists[r, 0]) for r in range(world) if lists[r, 0] >= 0]
-    assert len(dollars) == 1, "exactly one shard holds the '$' row"
+    if len(dollars) != 1:
+        raise RuntimeError(f"{len(dollars)} shards report the '$' row: exactly one holds it")
     return out[:(n + 31) // 32], hrows, dollars[0]
 
 

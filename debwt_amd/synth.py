@@ -179,6 +179,32 @@ def pan_chromosomes(genome_len, genomes, chroms, seed=SEED_P, snp_rate=1e-3, rep
     return out
 
 
+def read_set(records, min_len, max_len, genome_len, seed=SEED_P, snap=8, dup_every=16):
+    """Many short records (the input the special-region module exists for, SURVEY 8f-1: contig-level assemblies, read
+    sets): `records` substrings of one base genome with repeat families, lengths min_len..max_len (> 32), starts
+    hash-defined; start and end positions are snapped to multiples of `snap`, so many records share their last or first
+    bases with other records -- equal windows across '#' that continue differently (special branches,
+    src/collect#$.c:534-598) and long ties among the special suffixes; every `dup_every`-th record repeats an earlier
+    one exactly."""
+    assert min_len > 32 + 2 * snap and max_len >= min_len and genome_len > 2 * max_len
+    g = base_genome(genome_len, seed)
+    i = np.arange(records, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h1 = splitmix64(np.uint64(_mix(seed, 0xAEAD5)) + i * np.uint64(0x9E3779B97F4A7C15))
+        h2 = splitmix64(h1 ^ np.uint64(0x5851F42D4C957F2D))
+    ln = (np.uint64(min_len) + h2 % np.uint64(max_len - min_len + 1)).astype(np.int64)
+    st = (h1 % np.uint64(genome_len - max_len)).astype(np.int64)
+    st = st // snap * snap
+    en = np.minimum((st + ln) // snap * snap, genome_len)
+    out = []
+    for r in range(records):
+        if dup_every and r % dup_every == dup_every - 1:
+            out.append(out[int(h2[r] >> np.uint64(32)) % r].copy())
+        else:
+            out.append(g[int(st[r]):int(en[r])].copy())
+    return out
+
+
 def codes_to_ascii(codes):
     return np.frombuffer(b"ACGT", dtype=np.uint8)[np.asarray(codes, dtype=np.uint8)].tobytes()
 

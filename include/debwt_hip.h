@@ -62,6 +62,9 @@ typedef struct {
     uint32_t radix_pass_launches;
     float radix_pass_ms;
     uint64_t radix_pass_keys;   /* keys moved per launch */
+    /* how the special-region tables of the last run were built (collect, src/collect#$.c:118-157,348-602):
+     * special_path 0 = one host thread, 1 = host threads, 2 = device; special_threads = host threads used */
+    uint32_t special_path, special_threads;
 } debwt_stats;
 
 int debwt_create(const debwt_config *cfg, debwt_ctx **out);

@@ -41,7 +41,8 @@ def build_ref():
 def lib():
     global _LIB
     if _LIB is None:
-        L = ctypes.CDLL(build())
+        # DEBWT_ORACLE_LIB: another build of the same source (the ASan + UBSan one of tests/sanitize/Makefile)
+        L = ctypes.CDLL(os.environ.get("DEBWT_ORACLE_LIB") or build())
         u8p, u64p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint64)
         L.orc_make_text.restype = ctypes.c_uint64
         L.orc_make_text.argtypes = [ctypes.c_char_p, u64p, ctypes.c_uint64, u8p]

@@ -105,12 +105,19 @@ def run_ref(driver, recs, k, lower=False):
 
 
 def main():
+    """No argument: regenerate everything.  `--only NAME[,NAME...]`: (re)generate those cases and merge them into the
+    committed manifest (the other entries stay as they are)."""
     driver = O.build_ref()
     if not driver:
         sys.exit("needs /root/reference (build container only)")
     manifest = []
+    only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 and sys.argv[1] == "--only" else None
 
     def emit(name, recs, ks, source, lower=False):
+        if only is not None and name not in only:
+            return
+        if callable(recs):
+            recs = recs()
         n = sum(len(r) for r in recs) + len(recs)
         if source["kind"] == "fasta":
             fasta.write_fasta(os.path.join(HERE, name + ".fa"), recs, lower=lower)
@@ -143,6 +150,20 @@ def main():
          {"kind": "synth", "fn": "chromosomes", "args": [1_000_000, 5]})
     emit("uniform_300k", [synth.uniform_codes(300_000)], (32,),
          {"kind": "synth", "fn": "uniform_codes", "args": [300_000], "wrap": True})
+    # BASELINE.json configs[0]: the E. coli-sized single record bench.py calls ecoli_4.6M
+    emit("ecoli_4.6M", lambda: synth.pan_chromosomes(4_600_000, 1, 1), (32,),
+         {"kind": "synth", "fn": "pan_chromosomes", "args": [4_600_000, 1, 1]})
+    # many records: N*K special suffixes well above the 2^14 at which the special-region module of the
+    # build goes to host threads / the device; the reference's insert() is O(N) per record (src/INandOut.c:91-108),
+    # hence N <= 2*10^4 here
+    emit("contigs_2000", lambda: synth.read_set(2000, 3000, 8000, 4_000_000), (32,),
+         {"kind": "synth", "fn": "read_set", "args": [2000, 3000, 8000, 4_000_000]})
+    emit("reads_20000", lambda: synth.read_set(20000, 60, 400, 1_000_000), (32, 20),
+         {"kind": "synth", "fn": "read_set", "args": [20000, 60, 400, 1_000_000]})
+    if only is not None:
+        old = json.load(open(os.path.join(HERE, "manifest.json")))
+        new = {(e["name"], e["k"]) for e in manifest}
+        manifest = [e for e in old if (e["name"], e["k"]) not in new] + manifest
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
     print("wrote", len(manifest), "entries")
 

@@ -1,0 +1,146 @@
+// host_sanitize.cpp -- the host-side C++ of the product (FASTA ingest, special-region module, synthetic-text generator)
+// built WITHOUT HIP under AddressSanitizer + UndefinedBehaviorSanitizer and driven over the inputs the CPU tests use
+// ("build runs ASan/UBSan on its CPU restatement"; the reference's own hazards it must not repeat are
+// listed at /root/reference/src/getKmer.c:51-52 and src/generateSP.c:351-369).  CPU only -- never run on the GPU box.
+// Build + run: make -C tests/sanitize   (log -> profiles/r03_sanitizers.txt)
+#include "../../debwt_amd/csrc/fasta_host.h"
+#include "../../debwt_amd/csrc/special_host.h"
+#include "../../include/debwt_synth.h"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); failures++; } } while (0)
+
+static uint64_t rng_state = 0x5EEDBA5Eull;
+static uint64_t rnd() { uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+
+static std::string fasta_of(const std::vector<std::string> &recs, size_t width, bool crlf, bool lower) {
+    std::string s;
+    for (size_t r = 0; r < recs.size(); r++) {
+        s += ">rec" + std::to_string(r) + " some description\n";
+        for (size_t i = 0; i < recs[r].size(); i += width) {
+            std::string ln = recs[r].substr(i, width);
+            if (lower) for (auto &c : ln) c = (char)tolower(c);
+            s += ln; s += crlf ? "\r\n" : "\n";
+        }
+    }
+    return s;
+}
+
+static uint64_t digest_tables(const SpecialTables &t) {
+    uint64_t h = 7;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
+    for (auto v : t.pos) mix(v);
+    for (auto v : t.key) mix(v);
+    for (auto v : t.chr) mix(v);
+    for (auto v : t.branch) mix(v);
+    for (auto v : t.head_keys) mix(v);
+    for (auto v : t.tail_facts) mix(v);
+    return h;
+}
+
+int main() {
+    // ---- FASTA ingest: line widths, CRLF, lower case, 1..8 threads, gzip, IUPAC replacement, the error paths ----------
+    std::vector<std::string> recs;
+    const char *acgt = "ACGT";
+    for (int r = 0; r < 300; r++) {
+        size_t len = 33 + rnd() % 3000;
+        std::string s(len, 'A');
+        for (auto &c : s) c = acgt[rnd() & 3];
+        if (r % 7 == 0) s.replace(s.size() - 33, 33, std::string(33, 'T'));       // records ending in T...T
+        if (r % 11 == 0 && r) s = recs[r - 1];                                    // duplicates
+        recs.push_back(s);
+    }
+    PackedText ref{};
+    char err[256];
+    {
+        std::string fa = fasta_of(recs, 60, false, false);
+        CHECK(pack_fasta_buffer(fa.data(), fa.size(), 1, &ref, err, sizeof err) == 0);
+        CHECK(ref.nrec == recs.size());
+    }
+    for (size_t width : {1ul, 7ul, 60ul, 61ul, 100000ul})
+        for (int threads : {1, 2, 3, 8})
+            for (int variant = 0; variant < 3; variant++) {
+                std::string fa = fasta_of(recs, width, variant == 1, variant == 2);
+                PackedText p{};
+                CHECK(pack_fasta_buffer(fa.data(), fa.size(), threads, &p, err, sizeof err) == 0);
+                CHECK(p.n == ref.n && p.nrec == ref.nrec && p.nwords == ref.nwords);
+                CHECK(p.n == ref.n && !memcmp(p.words, ref.words, ref.nwords * 8) && !memcmp(p.sep, ref.sep, ref.nrec * 8));
+                free_packed_text(&p);
+            }
+    {   // gzip through a file
+        std::string fa = fasta_of(recs, 70, false, false);
+        const char *path = "/tmp/debwt_sanitize.fa.gz";
+        gzFile g = gzopen(path, "wb");
+        CHECK(g && gzwrite(g, fa.data(), (unsigned)fa.size()) == (int)fa.size());
+        gzclose(g);
+        PackedText p{};
+        CHECK(pack_fasta_file(path, 4, &p, err, sizeof err) == 0);
+        CHECK(p.n == ref.n && !memcmp(p.words, ref.words, ref.nwords * 8));
+        free_packed_text(&p);
+        remove(path);
+        CHECK(pack_fasta_file("/nonexistent/x.fa", 2, &p, err, sizeof err) != 0);
+    }
+    {   // IUPAC letters: refused by default, replaced deterministically (independent of threads) with the option
+        std::vector<std::string> r2 = recs;
+        const char *iupac = "NRYKMSWBDHV";
+        for (auto &s : r2) for (size_t i = 5; i < s.size(); i += 97) s[i] = iupac[rnd() % 11];
+        std::string fa = fasta_of(r2, 80, false, false);
+        PackedText p{}, q{};
+        CHECK(pack_fasta_buffer(fa.data(), fa.size(), 2, &p, err, sizeof err) != 0);
+        CHECK(pack_fasta_buffer(fa.data(), fa.size(), 1, &p, err, sizeof err, IngestOpts{INGEST_IUPAC_RANDOM, 42}) == 0);
+        CHECK(pack_fasta_buffer(fa.data(), fa.size(), 7, &q, err, sizeof err, IngestOpts{INGEST_IUPAC_RANDOM, 42}) == 0);
+        CHECK(p.n == q.n && !memcmp(p.words, q.words, p.nwords * 8));
+        free_packed_text(&p); free_packed_text(&q);
+    }
+    for (const char *bad : {"ACGT\n", ">a\nACGTACGT\n", ">a\nACGTXACGTACGTACGTACGTACGTACGTACGTACGTACGT\n", "@r\nACGT\n+\nIIII\n", "", ">only header\n"}) {
+        PackedText p{};
+        CHECK(pack_fasta_buffer(bad, strlen(bad), 2, &p, err, sizeof err) != 0);
+    }
+
+    // ---- special-region module on the packed text: one thread against many, K = 11 .. 31 -------------------------------
+    for (int K : {11, 15, 19, 31}) {
+        uint64_t d1 = 0, d8 = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            setenv("DEBWT_SPECIAL_PAR_MIN", pass ? "1" : "4611686018427387904", 1);
+            setenv("DEBWT_SPECIAL_THREADS", pass ? "8" : "1", 1);
+            SpecialTables t;
+            build_special_tables(ref.words, ref.n, ref.sep, ref.nrec, K, &t);
+            CHECK(t.pos.size() == ref.nrec * (uint64_t)K && t.head_keys.size() == ref.nrec);
+            CHECK(t.threads_used == (pass ? 8u : 1u));
+            (pass ? d8 : d1) = digest_tables(t);
+        }
+        CHECK(d1 == d8);
+    }
+    free_packed_text(&ref);
+
+    // ---- synthetic-text generator: words and codes of a small pan-genome, chunked against whole ------------------------
+    {
+        uint64_t lens[3] = {40000, 35000, 25000};
+        debwt_synth_spec sp{};
+        sp.seed = 0x5EEDBA5Eull; sp.genome_len = 100000; sp.genomes = 3; sp.nchrom = 3; sp.chrom_len = lens;
+        sp.snp_rate = 1e-3; sp.repeat_coverage = 0.25; sp.lowcx_fraction = 0.03; sp.alu_copies = 50; sp.alu_divergence = 0.12;
+        debwt_synth *s = nullptr;
+        CHECK(debwt_synth_open(&sp, 4, &s) == 0 && s);
+        const uint64_t nw = debwt_synth_nwords(s);
+        std::vector<uint64_t> whole(nw), parts(nw), sep(debwt_synth_nrec(s));
+        uint64_t census[4], c2[4];
+        CHECK(debwt_synth_words(s, 0, nw, 4, whole.data(), census) == 0);
+        for (uint64_t a = 0; a < nw; a += 1000) CHECK(debwt_synth_words(s, a, std::min(nw, a + 1000), 2, parts.data() + a, c2) == 0);
+        CHECK(whole == parts);
+        CHECK(debwt_synth_sep(s, sep.data()) == 0 && sep.back() == debwt_synth_n(s) - 1);
+        std::vector<uint8_t> codes(100000);
+        CHECK(debwt_synth_codes(s, 1, 0, 100000, codes.data()) == 0);
+        debwt_synth_close(s);
+    }
+    printf("host_sanitize: %d failures\n", failures);
+    return failures ? 1 : 0;
+}

@@ -30,6 +30,13 @@ def test_cli_argument_errors(tmp_path):
     assert r.returncode == 1 and "thread number" in r.stderr
     r = subprocess.run([CLI, "-o", "/nonexistent_dir/o", str(fa)], capture_output=True, text=True)
     assert r.returncode == 1 and "cannot create" in r.stderr
+    # --devices: a list that is not numeric, ends in a comma, or names another number of GPUs than --gpus is refused,
+    # never silently dropped
+    for devs, gpus, msg in (("0,x", "2", "comma-separated"), ("zero", "1", "comma-separated"), ("0,", "1", "comma-separated"),
+                            ("0,0,0", "2", "names 3 GPUs")):
+        r = subprocess.run([CLI, "-o", str(tmp_path / "o"), "--gpus", gpus, "--devices", devs, str(fa)],
+                           capture_output=True, text=True)
+        assert r.returncode == 1 and msg in r.stderr, (devs, r.stderr)
 
 
 @pytest.mark.gpu

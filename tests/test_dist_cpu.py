@@ -142,3 +142,22 @@ def test_sharded_host_logic_over_gloo(tmp_path):
         assert res[0]["rounds"] >= 3                                               # several exchange rounds
         assert sum(x["keys"] for x in res) == sum(x["sent"] for x in res)           # every key reached exactly one owner
         assert sum(x["sum"] for x in res) == sum(x["sent_sum"] for x in res)
+
+
+def test_bench_starts_its_own_ranks_when_run_directly():
+    """`python bench.py --gpus N` with no launcher (the shape of the driver's N = 1 command) starts N child ranks,
+    hands rank 0's one JSON line through on stdout and returns the launcher's exit code (--launch-probe: rendezvous
+    only, no GPU)."""
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-probe"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                     # exactly one line on stdout; the ranks' chatter is on stderr
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_joined"] == 2 and "rank 1 joined" in r.stderr
+    # a launcher that started the wrong number of ranks is an error message and a non-zero exit, not an assert
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-check"],
+                       env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "one process per GPU" in r.stderr

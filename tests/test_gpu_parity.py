@@ -85,6 +85,71 @@ def test_hip_kmer_count_matches_reference_kmerinfo(api, entry):
     d.close()
 
 
+@pytest.mark.parametrize("entry", [e for e in MANIFEST if e["records"] >= 2000], ids=golden_id)
+def test_many_record_goldens_take_the_parallel_special_region_path(api, entry):
+    """collections of thousands of records put N*(k-1) >= 2^14 suffixes through the special-region module's
+    parallel form (host threads or the device) -- checked against the reference's own output for 2,000 contigs and
+    20,000 reads (tests/golden: made by the reference's stage functions, -t 1), and again with the module forced onto
+    one host thread: same bytes."""
+    import os
+    recs = golden_records(entry)
+    assert entry["records"] * (entry["k"] - 1) >= 1 << 14
+    outs = []
+    for force_serial in (False, True):
+        if force_serial:
+            os.environ["DEBWT_SPECIAL_PAR_MIN"] = str(1 << 62)
+            os.environ["DEBWT_SPECIAL_DEVICE_MIN"] = str(1 << 62)
+        try:
+            d, (words, hrows, drow), st = _run(api, recs, entry["k"])
+        finally:
+            os.environ.pop("DEBWT_SPECIAL_PAR_MIN", None)
+            os.environ.pop("DEBWT_SPECIAL_DEVICE_MIN", None)
+        assert (st["special_path"] == 0) == force_serial, st
+        assert force_serial or st["special_path"] == 2 or st["special_threads"] > 1, st
+        sha = entry["sha256"]
+        assert _sha(words) == sha["bwt"] and _sha(hrows) == sha["hash"]
+        assert _sha(np.array([drow], dtype=np.uint64)) == sha["dollar"]
+        assert st["special_branch_num"] == entry["counters"]["specialBranchNum"]
+        outs.append(words)
+        d.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_hundred_thousand_records_equal_oracle(api, oracle):
+    """10^5 reads (beyond what the reference's O(N)-per-record insert, src/INandOut.c:91-108, finishes in test time):
+    3.1e6 special suffixes through the parallel special-region path against the oracle, whose special-region code is
+    pinned by the 2,000- and 20,000-record goldens."""
+    from debwt_amd import synth
+    recs = synth.read_set(100_000, 60, 300, 3_000_000, seed=0xBEEF5)
+    ow, oh, od, ost = oracle.build_bwt(oracle.sym_from_codes(recs), 32)
+    d, (words, hrows, drow), st = _run(api, recs, 32)
+    assert st["special_path"] == 2 or st["special_threads"] > 1, st
+    assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od
+    assert st["special_branch_num"] == ost["special_branch_num"] and st["nrec"] == 100_000
+    assert d.verify_device()["inverse_bwt_ok"]
+    d.close()
+
+
+def test_sorted_keys_are_refused_once_their_buffer_is_reused(api):
+    """DEBWT_ARR_SORTED_KEYS names a buffer the SP stage reuses as scratch: after that stage the fetch is an error,
+    not stale bytes."""
+    from debwt_amd import synth
+    d = api.DeBWT(k=32)
+    d.load_records(synth.pan_genome(50_000, 2))
+    d.kmer_sort_rle()
+    sk = d.fetch_array(api.ARR_SORTED_KEYS)
+    d.classify()
+    assert np.array_equal(d.fetch_array(api.ARR_SORTED_KEYS), sk)
+    d.sp_generate()
+    with pytest.raises(RuntimeError):
+        d.fetch_array(api.ARR_SORTED_KEYS)
+    d.build()
+    with pytest.raises(RuntimeError):
+        d.fetch_array(api.ARR_SORTED_KEYS)
+    assert len(d.fetch_array(api.ARR_DISTINCT_KEYS)) == d.stats()["distinct_keys"]
+    d.close()
+
+
 def _adversarial(rng):
     nrec = int(rng.integers(1, 7))
     base = rng.integers(0, 4, size=int(rng.integers(60, 400))).astype(np.uint8)
@@ -411,7 +476,7 @@ def test_multi_range_build_matches_reference_golden(api, entry):
     """The same golden vectors with the key space cut into many prefix ranges (cap = 4096 instances)."""
     recs = golden_records(entry)
     d = api.DeBWT(k=entry["k"])
-    d.set_range_cap(4096)
+    d.set_range_cap(4096 if entry["n"] < 2_000_000 else entry["n"] // 40)     # the Mbp-sized goldens: ~40 ranges
     d.load_records(recs)
     d.build()
     words, hrows, drow = d.fetch()

@@ -172,3 +172,41 @@ def test_multi_gpu_host_from_one_process(api, oracle, devices, case, k, cap, tun
         assert (ms["key_bytes_in"] > 0) == (want == 0 and len(devices) > 1)
     assert m.verify_device()["ok"] == 1
     m.close()
+
+
+def _run_bench_direct(extra, timeout=900):
+    """`python bench.py --gpus N ...` exactly as the driver types it for N = 1: no launcher in front."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_started_by_bench_itself_gloo():
+    """bench.py --gpus 2 run DIRECTLY starts its two ranks as child processes (they share this box's one GPU, so the
+    collectives go over gloo), builds ONE chr1-sized collection as two k-mer-prefix shards and prints one line whose
+    result passed the census and the device inverse BWT."""
+    j = _run_bench_direct(["--gpus", "2", "--backend", "gloo", "--workload", "chr1_250M", "--steps", "1", "--warmup", "1",
+                           "--no-cpu-baseline"])
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["check"]["census_equals_text"] and j["check"]["inverse_bwt_ok"], j["check"]
+    assert "chr1_250M" in j["config"]["workload"] and j["config"]["bases_per_gpu"] * 2 <= j["config"]["bases"]
+
+
+def test_bench_two_ranks_started_by_bench_itself_rccl():
+    """The same over RCCL when the box has two GPUs (the driver's 8-GPU node; skipped on a one-GPU box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: two RCCL ranks need two devices")
+    for mode in ("exchange", "rescan"):
+        j = _run_bench_direct(["--gpus", "2", "--workload", "chr1_250M", "--steps", "1", "--warmup", "1",
+                               "--no-cpu-baseline", "--mode", mode])
+        assert j["n_gpus"] == 2 and j["check"]["census_equals_text"] and j["check"]["inverse_bwt_ok"], j
