@@ -23,7 +23,11 @@ assembly) over that collection.
 `value` = bases / wall time of a step with the packed text resident in HBM (on every GPU) and the result left in
 HBM (rank 0), barrier + device synchronisation on both sides, slowest rank.  Extra keys:
   host_to_host  -- N = 1: the same build from the page-locked host text to the BWT and its '#'/'$' rows back in
-                   page-locked host memory (SURVEY 8d's region: load + build + fetch);
+                   page-locked host memory (SURVEY 8d's region: load + build + fetch), MEAN over as many consecutive
+                   steps as `steps`;
+  link_probe    -- N > 1: all_to_all rate per peer pair measured on this node before the first build, fed to the
+                   key-path cost model (debwt_shard_key_mode) in place of its assumed link rate;
+  key_modes_ms  -- N > 1, --mode auto: ms per build of the chosen key path (the timed steps) AND of the other one;
   first_build_s -- the cold first build (allocates the workspace);
   check         -- outside the timed region: symbol census of the result against the text's (device kernel), '#' rows
                    ascending, and the inverse BWT on the device (one LF walk per text segment, debwt_verify_device);
@@ -32,7 +36,9 @@ HBM (rank 0), barrier + device synchronisation on both sides, slowest rank.  Ext
                    launch of the first key range on the stream it runs on, against the 8 TB/s HBM peak;
   cpu_baseline  -- the reference's own stage functions (oracle/_ref, compiled from /root/reference/src in the build
                    container) on this box's host cores on a bounded prefix of record 0 (rank 0, N = 1 only);
-  cpu_port      -- the single-threaded CPU oracle on a prefix of the same record.
+  cpu_port      -- the single-threaded CPU oracle on a prefix of the same record;
+  cpu_baseline_at_configs -- the reference on the whole ecoli_4.6M collection (BASELINE configs[0]; --cpu-configs: also
+                   chr1_250M, configs[1]).
 """
 import argparse
 import json
@@ -143,7 +149,12 @@ def main():
     ap.add_argument("--sort-algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--h2h-reps", type=int, default=2, help="host-to-host repetitions (N = 1); 0 = skip")
+    ap.add_argument("--h2h-reps", type=int, default=-1,
+                    help="host-to-host steps (N = 1; load + build + fetch, mean over them); default = --steps, 0 = skip")
+    ap.add_argument("--cpu-configs", action="store_true",
+                    help="also time the reference on the whole chr1_250M collection (BASELINE configs[1]; minutes of CPU)")
+    ap.add_argument("--no-other-mode", action="store_true",
+                    help="N>1 with --mode auto: do not also time the key path the cost model did not choose")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bases of record 0 given to the reference")
     ap.add_argument("--port-sample", type=int, default=100_000_000, help="bases of record 0 given to the oracle port")
     ap.add_argument("--tune", type=int, default=0, help=argparse.SUPPRESS)
@@ -223,6 +234,8 @@ def main():
 
     acc = {"pass_ms": 0.0, "pass_launches": 0, "stage": {}, "timed": False, "xfer": {}, "info": {}}
     shard_ws = SH.Workspace(d, device, mode=args.mode) if sharded else None
+    # N > 1: what the links of THIS node sustain, measured before the first build and fed to the key-path cost model
+    link_probe = SH.measure_link(device, mib_per_peer=1024 if args.backend == "nccl" else 16) if sharded and world > 1 else None
 
     def step():
         if sharded:
@@ -269,14 +282,37 @@ def main():
                      "hash_rows": int(len(hrows)), "dollar_row": int(drow)}
             if hasattr(d, "verify_device"):
                 check.update(d.verify_device())
+    # N > 1, --mode auto: the key path the cost model did NOT choose, timed the same way over a few steps, so that a
+    # scaling run answers "exchange or rescan" by measurement (collective: every rank runs it)
+    key_modes = None
+    if sharded and world > 1 and args.mode == "auto" and not args.no_other_mode:
+        chosen = acc["info"].get("keys", "rescan")
+        other = "exchange" if chosen == "rescan" else "rescan"
+        key_modes = {chosen: round(dt * 1e3 / args.steps, 3)}
+        try:
+            ws2 = SH.Workspace(d, device, mode=other)
+            ws2.buf = shard_ws.buf                            # the same exchange buffers
+            acc["timed"] = False
+            k2 = max(1, min(3, args.steps))
+            dt2 = D.timed_steps(lambda: SH.build_sharded(d, ws2), steps=k2, warmup=1, device_sync=torch.cuda.synchronize,
+                                tensor_device=tdev)
+            key_modes[other] = round(dt2 * 1e3 / k2, 3)
+            key_modes["note"] = (f"ms per build; '{chosen}' is the cost model's choice and the timed steps of `value`, "
+                                 f"'{other}' was timed over {k2} steps after one warm-up")
+        except Exception as e:                                # noqa: BLE001 -- extra information, never the result
+            key_modes[other] = f"failed: {e}"
     h2h = None
-    if world == 1 and args.h2h_reps > 0:
+    h2h_reps = args.steps if args.h2h_reps < 0 else args.h2h_reps
+    if world == 1 and not sharded and h2h_reps > 0:
+        # SURVEY 8d's region: page-locked host text -> debwt_load_text -> debwt_build -> debwt_fetch_bwt into page-locked
+        # host memory; MEAN over h2h_reps consecutive steps bracketed by device synchronisation, like the timed steps above
         out_words = SN.PinnedArray((n + 31) // 32)
         out_hash = SN.PinnedArray(max(nrec - 1, 1))
         out_dollar = SN.PinnedArray(1)
-        ts = []
-        for _ in range(args.h2h_reps):
-            torch.cuda.synchronize()
+        parts = np.zeros(3)
+        torch.cuda.synchronize()
+        t_begin = time.perf_counter()
+        for _ in range(h2h_reps):
             t0 = time.perf_counter()
             d.load_packed(text.a, n, sep)
             t1 = time.perf_counter()
@@ -284,12 +320,15 @@ def main():
             t2 = time.perf_counter()
             d.fetch_into(out_words.a, out_hash.a, out_dollar.a)
             t3 = time.perf_counter()
-            ts.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
-        best = min(ts)
-        h2h = {"value": round(n / best[0] / 1e9, 4), "unit": "Gbp/s", "seconds": round(best[0], 4),
-               "load_s": round(best[1], 4), "build_s": round(best[2], 4), "fetch_s": round(best[3], 4),
-               "note": "page-locked host text -> BWT + '#'/'$' rows in page-locked host memory (SURVEY 8d); a fresh load "
-                       "also re-plans the key ranges (prefix census of the text)"}
+            parts += (t1 - t0, t2 - t1, t3 - t2)
+        torch.cuda.synchronize()
+        mean_s = (time.perf_counter() - t_begin) / h2h_reps
+        parts /= h2h_reps
+        h2h = {"value": round(n / mean_s / 1e9, 4), "unit": "Gbp/s", "seconds": round(mean_s, 4), "steps": h2h_reps,
+               "load_s": round(parts[0], 4), "build_s": round(parts[1], 4), "fetch_s": round(parts[2], 4),
+               "note": "MEAN over `steps` consecutive steps of: page-locked host text -> HBM, build, BWT + '#'/'$' rows -> "
+                       "page-locked host memory (SURVEY 8d's region; PCIe both ways inside).  A fresh load also re-plans the "
+                       "key ranges (prefix census of the text).  `value` above is the same build with the text resident in HBM"}
         out_words.free(); out_hash.free(); out_dollar.free()
 
     if rank == 0:
@@ -298,13 +337,15 @@ def main():
         keys = st["radix_pass_keys"]
         mean_pass_ms = pass_ms / max(pass_launches, 1)
         achieved = 16.0 * keys / (mean_pass_ms * 1e-3) / 1e9 if mean_pass_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and args.k == 32 and world == 1:
             try:
                 j = json.load(open(pmc))
                 if j.get("workload") == args.workload:      # the PMC passes were run on this workload
                     traffic = j.get("rs_scatter_bytes_per_launch")
+                    traffic_source = ("profiles/pmc_latest.json: the builder's rocprofv3 --pmc passes on this workload "
+                                      f"({j.get('source', 'scripts/pmc_30g.sh')}), NOT a counter of this run")
             except Exception:
                 traffic = None
         if sharded:
@@ -324,7 +365,7 @@ def main():
                        "parallelism": par},
             "roofline": {"bound": "hbm", "kernel": "rs_scatter_kernel<0,0,1> (one 8-bit radix pass over the keys of a key range)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_launch": 16 * keys, "mean_launch_ms": round(mean_pass_ms, 4),
                          "launches_timed": pass_launches},
             "stages_ms": {k_: round(v, 3) for k_, v in stage.items()},
@@ -338,12 +379,22 @@ def main():
         if sharded:
             line["exchange"] = {k_: round(v, 3) for k_, v in acc["xfer"].items()}
             line["exchange"].update(acc["info"])
+            line["link_probe"] = link_probe
+            line["key_modes_ms"] = key_modes
         if args.gpus == 1 and not args.no_cpu_baseline:
             threads = SN.default_threads()
             ref = cpu_reference(syn.codes(0, 0, min(args.cpu_sample, int(syn._lens[0]))), args.k, threads)
             port = cpu_port(syn.codes(0, 0, min(args.port_sample, int(syn._lens[0]))), args.k)
             line["cpu_baseline"] = ref if ref else port
             line["cpu_port"] = port
+            # the reference on WHOLE BASELINE configurations (configs[0] always; configs[1] = minutes of CPU,
+            # on request -- profiles/ holds the run): same stage functions, same thread count
+            at = {}
+            for wl in ["ecoli_4.6M"] + (["chr1_250M"] if args.cpu_configs else []):
+                s2 = SN.Synth.named(wl)
+                at[wl] = cpu_reference(s2.codes(0, 0, int(s2._lens[0])), args.k, threads)
+                s2.close()
+            line["cpu_baseline_at_configs"] = at
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

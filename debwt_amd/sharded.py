@@ -120,6 +120,67 @@ P2P_MAX = int(os.environ.get("DEBWT_P2P_MAX_BYTES", str(1 << 29)))
 LINK_GBYTES_PER_S = float(os.environ.get("DEBWT_LINK_GBYTES_PER_S", "0"))
 
 
+def measure_link(device, mib_per_peer=1024, reps=2):
+    """What a key exchange would run at on THIS node, measured instead of assumed (the cost model's link rate,
+    debwt_shard_key_mode): an all_to_all of `mib_per_peer` MiB to every peer -- cut into P2P_MAX calls exactly like the
+    exchanges of a build -- timed after one warm-up; the sustained one-direction rate per peer pair becomes
+    LINK_GBYTES_PER_S unless DEBWT_LINK_GBYTES_PER_S fixes it.  Also re-probes, between real peers, the RCCL message
+    limit found in a group of one (a single message above 1 GiB arrives with its second half zeroed): one 1.25 GiB
+    message per peer, checked at the receiver.  Collective: every rank calls it."""
+    global LINK_GBYTES_PER_S
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world < 2:
+        return None
+    dev = device if _on_device() else torch.device("cpu")
+    per = (mib_per_peer << 20) // 8
+    src = torch.empty(per * world, dtype=torch.int64, device=device)
+    dst = torch.empty(per * world, dtype=torch.int64, device=device)
+    src.fill_(rank + 1)
+    counts = [per] * world
+    times = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        t0 = time.perf_counter()
+        _all_to_all(dst, src, counts, counts)
+        torch.cuda.synchronize(device)
+        times.append(time.perf_counter() - t0)
+    ok = all(int(dst[r * per]) == r + 1 and int(dst[(r + 1) * per - 1]) == r + 1 for r in range(world))
+    best = min(times[1:])
+    t = torch.tensor([best], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    best = float(t.item())
+    per_peer = per * 8 / best / 1e9                                   # one direction, one peer pair
+    res = {"all_to_all_mib_per_peer": mib_per_peer, "seconds": round(best, 4), "gbytes_per_s_per_peer": round(per_peer, 2),
+           "gbytes_per_s_out_of_one_gpu": round(per_peer * (world - 1), 2), "content_ok": bool(ok),
+           "calls_of_at_most_bytes": P2P_MAX}
+    # one message of 1.25 GiB per peer in ONE call (the exchanges never do this: they stay below P2P_MAX)
+    if _on_device() and os.environ.get("DEBWT_SKIP_BIG_MESSAGE_PROBE") is None:
+        try:
+            big = (5 << 28) // 8
+            a = torch.empty(big * world, dtype=torch.int64, device=device)
+            b = torch.zeros(big * world, dtype=torch.int64, device=device)
+            a.fill_(7)
+            dist.all_to_all([b[r * big:(r + 1) * big] for r in range(world)], [a[r * big:(r + 1) * big] for r in range(world)])
+            torch.cuda.synchronize(device)
+            peer = (rank + 1) % world
+            intact = bool((b[peer * big + big // 2:(peer + 1) * big] == 7).all().item())
+            v = torch.tensor([1 if intact else 0], dtype=torch.int64, device=device)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            res["message_above_1GiB_intact_between_peers"] = bool(v.item())
+            del a, b
+        except Exception as e:          # noqa: BLE001 -- a probe: report, do not fail the build
+            res["message_above_1GiB_intact_between_peers"] = f"probe failed: {e}"
+    del src, dst
+    torch.cuda.empty_cache()
+    if not os.environ.get("DEBWT_LINK_GBYTES_PER_S") and _on_device():
+        LINK_GBYTES_PER_S = per_peer
+        res["fed_to_cost_model"] = True
+    else:
+        res["fed_to_cost_model"] = False
+    return res
+
+
 def _global_max(value):
     return int(_all_gather_small([int(value)]).max())
 
