@@ -65,7 +65,7 @@ SYMBOLS = [
     "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_verify_device", "debwt_multi_create", "debwt_multi_destroy", "debwt_multi_last_error",
     "debwt_multi_load_text", "debwt_multi_load_fasta", "debwt_multi_build", "debwt_multi_fetch_bwt", "debwt_multi_get_stats",
     "debwt_multi_verify", "debwt_multi_shard", "debwt_pinned_alloc", "debwt_pinned_free", "debwt_shard_key_mode",
-    "debwt_multi_set_key_mode",
+    "debwt_multi_set_key_mode", "debwt_special_compare",
 ]
 
 
@@ -187,6 +187,8 @@ def lib():
                                         ctypes.POINTER(DebwtPackedText), ctypes.c_char_p, ctypes.c_size_t]
     L.debwt_load_fasta_opts.restype = ctypes.c_int
     L.debwt_load_fasta_opts.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64]
+    L.debwt_special_compare.restype = ctypes.c_int
+    L.debwt_special_compare.argtypes = [vp, u64p]
     L.debwt_special_digest.restype = ctypes.c_int
     L.debwt_special_digest.argtypes = [u64p, ctypes.c_uint64, u64p, ctypes.c_uint64, ctypes.c_int, u64p]
     L.debwt_multi_create.restype = ctypes.c_int

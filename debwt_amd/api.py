@@ -171,6 +171,13 @@ class DeBWT:
         return {"inverse_bwt_ok": bool(r["ok"]), "inverse_bwt": {k: (round(v, 2) if isinstance(v, float) else v)
                                                                   for k, v in r.items() if k != "ok"}}
 
+    def special_compare(self):
+        """Special-region tables of the loaded text, device module against host module: mismatching elements of
+        (suffix order, keys, BWT symbols, special branches, head nodes, tail nodes) -- all zero when they agree."""
+        mm = np.zeros(6, dtype=np.uint64)
+        self._chk(self._L.debwt_special_compare(self._h, _p64(mm)))
+        return [int(x) for x in mm]
+
     def stats(self):
         st = _lib.DebwtStats()
         self._chk(self._L.debwt_get_stats(self._h, ctypes.byref(st)))

@@ -21,6 +21,7 @@
 #include "special_host.h"
 #include "fasta_host.h"
 #include "stage_kernels.h"
+#include "special_kernels.h"
 #include "verify_kernels.h"
 
 namespace {
@@ -54,6 +55,9 @@ struct debwt_ctx {
     DevBuf rs_rle, text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
         hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist, dest_tab, qbounds, qcursor, qlist, qwave;
+    DevBuf sx, sppos, sprec, tail_d;   // special-region module on the device: scratch arena, positions / records of the sorted items, tail facts
+    bool special_dev = false;   // the tables of this build were made on the device (spkey / spchr / branch / head_keys / tail_d)
+    u64 nbranch = 0;            // special branches (specialBranchNum)
     u32 *h_over = nullptr;      // pinned mirror of rs_over
     u64 *sk = nullptr;          // sorted keys (keysA or keysB)
     u32 *h_scalars = nullptr;   // pinned read-back area
@@ -245,6 +249,7 @@ static std::vector<DevBuf *> all_buffers(debwt_ctx *c) {
             &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
             &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew,
             &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
+            &c->sx, &c->sppos, &c->sprec, &c->tail_d,
             &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0,
             &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf, &c->vidx, &c->vtmp, &c->qlist, &c->qwave};
 }
@@ -511,6 +516,146 @@ static void join_special(debwt_ctx *c) {
     if (c->special_running) { c->special_thread.join(); c->special_running = false; }
 }
 
+// ---- special-region module on the device (special_kernels.h) --------------------------------------------
+
+static int bits_for(u64 v) { int b = 1; while (b < 64 && (v >> b)) b++; return b; }     // bits that hold 0..v
+
+// Collections of many records build their special-region tables on the device: from 2^14 special suffixes on
+// (DEBWT_SPECIAL_DEVICE_MIN overrides; tests force either path), as long as the payload fields of its sorts hold the
+// record ranks and item places (2^27 records, 2^32 special suffixes -- beyond that the host threads take over).
+static bool special_wants_device(const debwt_ctx *c) {
+    const char *e = getenv("DEBWT_SPECIAL_DEVICE_MIN");
+    const u64 dev_min = e ? strtoull(e, nullptr, 10) : (1ull << 14);
+    if (c->NS < dev_min) return false;
+    return c->nrec < (1ull << 27) && c->NS < (1ull << 32) && 5 + bits_for(c->nrec) + bits_for(c->NS - 1) <= 64;
+}
+
+static int special_device_build(debwt_ctx *c) {
+    const u64 N = c->nrec, NS = c->NS, n = c->n;
+    const int K = c->K;
+    int rc;
+    const auto t_begin = std::chrono::steady_clock::now();
+    // one scratch arena, carved: u64 sort buffers of NS words, per-record and per-item side arrays
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
+    const size_t oX = take(NS * 8 + 64), oY = take(NS * 8 + 64);
+    const size_t o_ord = take(N * 4), o_gid = take(N * 4), o_actA = take(N * 4), o_actB = take(N * 4), o_val = take(N * 8);
+    const size_t o_recs = take(N * 4), o_vals = take(N * 8), o_gids = take(N * 4), o_ordv = take(N * 4);
+    const size_t o_head = take((N + 1) * 4), o_stay = take(N), o_rank = take(N * 4);
+    const size_t o_id1 = take(NS * 4), o_id2 = take(NS * 4), o_grp = take(NS * 4), o_gflag = take(NS), o_bnd = take(64);
+    ENSURE(c, c->sx, off);
+    ENSURE(c, c->sppos, NS * 8 + 64);
+    ENSURE(c, c->sprec, NS * 4 + 64);
+    ENSURE(c, c->tail_d, N * 8 + 64);
+    ENSURE(c, c->rs_skew, (NS / 2048 + 2) * 4);
+    u8 *base = c->sx.as<u8>();
+    u64 *X = (u64 *)(base + oX), *Y = (u64 *)(base + oY);
+    u32 *ord = (u32 *)(base + o_ord), *gid = (u32 *)(base + o_gid), *act = (u32 *)(base + o_actA), *act2 = (u32 *)(base + o_actB);
+    u64 *valbuf = (u64 *)(base + o_val), *val_s = (u64 *)(base + o_vals);
+    u32 *rec_s = (u32 *)(base + o_recs), *gid_s = (u32 *)(base + o_gids), *ordv = (u32 *)(base + o_ordv);
+    u32 *headpos = (u32 *)(base + o_head), *rank = (u32 *)(base + o_rank);
+    u8 *stay = base + o_stay;
+    u32 *id1 = (u32 *)(base + o_id1), *id2 = (u32 *)(base + o_id2), *grp = (u32 *)(base + o_grp);
+    u8 *gflag = base + o_gflag;
+    const SxText T{c->text.as<u64>(), c->sepbits.as<u64>(), c->sep.as<u64>(), n, N, K};
+    auto grid = [](u64 m) { return grid_for(m, 256); };
+
+    // 1. ranks of the record starts: refinement rounds on 21-symbol windows inside the tie groups
+    k_sx_init<<<grid(N), 256, 0, c->stream>>>(ord, gid, act, N);
+    const char *env_rounds = getenv("DEBWT_SPECIAL_MAX_ROUNDS");
+    const u64 max_rounds = env_rounds ? strtoull(env_rounds, nullptr, 10) : 64ull;
+    u64 na = N > 1 ? N : 0;
+    bool one_group = true;
+    for (u64 w = 0; na; w++) {
+        if (w >= max_rounds) {
+            // records identical for max_rounds * 21 symbols and more: the few groups left are ordered on the host
+            std::vector<u32> h_ord(N), h_gid(N), h_act(na);
+            HIPCHK(c, hipMemcpyAsync(h_ord.data(), ord, N * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(h_gid.data(), gid, N * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(h_act.data(), act, na * 4, hipMemcpyDeviceToHost, c->stream));
+            if ((rc = sync_check(c))) return rc;
+            special_order_record_starts(c->h_text, n, c->h_sep.data(), N, h_ord.data(), h_gid.data(), h_act.data(), na);
+            HIPCHK(c, hipMemcpyAsync(ord, h_ord.data(), N * 4, hipMemcpyHostToDevice, c->stream));
+            if ((rc = sync_check(c))) return rc;
+            break;
+        }
+        const int bA = bits_for(na - 1);
+        k_sx_round_keys<<<grid(na), 256, 0, c->stream>>>(T, ord, act, na, w, bA, valbuf, X);
+        // three stable passes, least significant first: low 32 bits of the window, its high 31 bits, the tie group; the
+        // payload of a pass is the place in the order of the pass before (ida / idb / idc: the element at every place)
+        u64 *r = nullptr;
+        if ((rc = sort_keys(c, X, Y, na, 32 + bA, &r, false))) return rc;
+        k_it_ids<<<grid(na), 256, 0, c->stream>>>(r, nullptr, na, bA, id1);
+        k_sx_pass_hi<<<grid(na), 256, 0, c->stream>>>(id1, valbuf, na, bA, X);
+        if ((rc = sort_keys(c, X, Y, na, 31 + bA, &r, false))) return rc;
+        k_it_ids<<<grid(na), 256, 0, c->stream>>>(r, id1, na, bA, id2);
+        u32 *idc = id2;
+        if (!one_group) {
+            k_sx_pass_gid<<<grid(na), 256, 0, c->stream>>>(id2, gid, act, na, bA, X);
+            if ((rc = sort_keys(c, X, Y, na, bits_for(N - 1) + bA, &r, false))) return rc;
+            k_it_ids<<<grid(na), 256, 0, c->stream>>>(r, id2, na, bA, id1);
+            idc = id1;
+        }
+        k_sx_gather<<<grid(na), 256, 0, c->stream>>>(idc, valbuf, ord, gid, act, na, rec_s, val_s, gid_s);
+        SxHeadF fh{gid_s, val_s, ordv, headpos};
+        if ((rc = cp_count(c, fh, na, cp_area(c, 0), 20))) return rc;
+        if ((rc = cp_emit(c, fh, na, cp_area(c, 0)))) return rc;
+        k_sx_sentinel<<<1, 1, 0, c->stream>>>(headpos, cp_area(c, 0) + CP_MAXCHUNKS, (u32)na);
+        k_sx_apply<<<grid(na), 256, 0, c->stream>>>(rec_s, ordv, headpos, act, na, ord, gid, stay);
+        SxStayF fs{stay, act, act2};
+        if ((rc = cp_count(c, fs, na, cp_area(c, 1), 21))) return rc;
+        if ((rc = cp_emit(c, fs, na, cp_area(c, 1)))) return rc;
+        if ((rc = sync_check(c))) return rc;
+        na = c->h_scalars[21];
+        std::swap(act, act2);
+        one_group = false;
+    }
+    k_sx_rank_of<<<grid(N), 256, 0, c->stream>>>(ord, N, rank);
+
+    // 2. the N*K special suffixes by (key, later separator first, follower rank): three stable passes, least significant first
+    const int bR = bits_for(N), bP = bits_for(NS - 1);
+    u64 *r = nullptr;
+    (void)o_bnd;
+    k_it_pass1<<<grid(NS), 256, 0, c->stream>>>(rank, N, K, NS, bR, bP, X);
+    if ((rc = sort_keys(c, X, Y, NS, 5 + bR + bP, &r, false))) return rc;
+    k_it_ids<<<grid(NS), 256, 0, c->stream>>>(r, nullptr, NS, bP, id1);
+    k_it_pass_key<<<grid(NS), 256, 0, c->stream>>>(T, id1, NS, 0, bP, X);
+    if ((rc = sort_keys(c, X, Y, NS, 31 + bP, &r, false))) return rc;
+    k_it_ids<<<grid(NS), 256, 0, c->stream>>>(r, id1, NS, bP, id2);
+    k_it_pass_key<<<grid(NS), 256, 0, c->stream>>>(T, id2, NS, 1, bP, X);
+    if ((rc = sort_keys(c, X, Y, NS, 31 + bP, &r, false))) return rc;
+    k_it_ids<<<grid(NS), 256, 0, c->stream>>>(r, id2, NS, bP, id1);
+    k_it_out<<<grid(NS), 256, 0, c->stream>>>(T, id1, NS, c->spkey.as<u64>(), c->spchr.as<u8>(), c->sppos.as<u64>(),
+                                              c->sprec.as<u32>());
+
+    // 3. special branches; head and tail nodes
+    SxBranchF fb{T, c->sppos.as<u64>(), c->sprec.as<u32>(), grp};
+    if ((rc = cp_count(c, fb, NS, cp_area(c, 0), 20))) return rc;
+    if ((rc = cp_emit(c, fb, NS, cp_area(c, 0)))) return rc;
+    HIPCHK(c, hipMemsetAsync(gflag, 0, NS, c->stream));
+    k_br_diff<<<grid(NS), 256, 0, c->stream>>>(T, c->sppos.as<u64>(), grp, NS, gflag);
+    SxBranchEmitF fe{gflag, grp, c->sppos.as<u64>(), nullptr};
+    if ((rc = cp_count(c, fe, NS, cp_area(c, 1), 21))) return rc;
+    if ((rc = sync_check(c))) return rc;
+    c->nbranch = c->h_scalars[21];
+    ENSURE(c, c->branch, c->nbranch * 8 + 64);
+    if (c->nbranch) {
+        fe.branch = X;
+        if ((rc = cp_emit(c, fe, NS, cp_area(c, 1)))) return rc;
+        if ((rc = sort_keys(c, X, Y, c->nbranch, bits_for(n), &r, false))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->branch.p, r, c->nbranch * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    k_heads_tails<<<grid(N), 256, 0, c->stream>>>(T, X, c->tail_d.as<u64>());
+    if ((rc = sort_keys(c, X, Y, N, 2 * K + 2, &r, false))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->head_keys.p, r, N * 8, hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = sync_check(c))) return rc;
+    c->special_dev = true;
+    c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    c->st.special_path = 2;
+    c->st.special_threads = 0;
+    return DEBWT_OK;
+}
+
 // plans the ranges, sizes the range workspace, starts the host special-region module
 static int sort_begin(debwt_ctx *c) {
     const u64 n = c->n;
@@ -531,8 +676,13 @@ static int sort_begin(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     // the keys (node << 2 | pred) are read off the text inside the first radix pass: no unsorted key array
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    // host special-region module beside the GPU's key sort (src/collect#$.c:118-157,348-602)
+    // special-region module (src/collect#$.c:118-157,348-602): on the device for collections of many records, else on the
+    // host beside the GPU's key sort
     join_special(c);
+    c->special_dev = false;
+    if (special_wants_device(c)) {
+        if ((rc = special_device_build(c))) return rc;
+    } else {
     c->special_running = true;
     c->special_thread = std::thread([c, n]() {
         auto t0 = std::chrono::steady_clock::now();
@@ -541,6 +691,7 @@ static int sort_begin(debwt_ctx *c) {
         c->st.special_threads = c->special.threads_used;
         c->st.special_path = c->special.threads_used > 1 ? 1 : 0;
     });
+    }
     // several ranges read off the text: the chunk histograms of every range's first pass from ONE scan of the text (a
     // lane per text word, radix_text_hist_ranges); a single range of a long text takes the same kernel -- it is twice
     // as fast as the histogram pass of the sort itself (a shard of 8 reads the whole text for its one range)
@@ -592,9 +743,10 @@ static int sort_range(debwt_ctx *c, size_t i, u64 *imported) {
         if ((rc = cp_count(c, f, r.M, cp_area(c, 0), 0))) return rc;
         if ((rc = cp_emit(c, f, r.M, cp_area(c, 0)))) return rc;
     }
-    if (i == 0) {
+    if (i == 0 && !c->special_dev) {
         join_special(c);
         const SpecialTables &sp = c->special;
+        c->nbranch = sp.branch.size();
         ENSURE(c, c->branch, sp.branch.size() * 8 + 64);
         HIPCHK(c, hipMemcpyAsync(c->head_keys.p, sp.head_keys.data(), c->nrec * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->spkey.p, sp.key.data(), c->NS * 8, hipMemcpyHostToDevice, c->stream));
@@ -603,16 +755,22 @@ static int sort_range(debwt_ctx *c, size_t i, u64 *imported) {
             HIPCHK(c, hipMemcpyAsync(c->branch.p, sp.branch.data(), sp.branch.size() * 8, hipMemcpyHostToDevice, c->stream));
     }
     // special suffixes whose key lies in this range, and their rows among the context's instances
+    u64 *d_bounds = nullptr;
     {
         const std::vector<uint64_t> &key = c->special.key;          // ascending (suffix order implies key order)
         u64 s0 = 0, s1 = c->NS;
-        if (c->shard_world > 1 || P > 1) {
+        if ((c->shard_world > 1 || P > 1) && c->special_dev) {
+            d_bounds = reinterpret_cast<u64 *>(c->sx.as<u8>() + c->sx.cap - 64);      // spare words at the end of the arena
+            k_sp_bounds<<<1, 64, 0, c->stream>>>(c->spkey.as<u64>(), c->NS, r.key_lo >> 2, r.key_hi >> 2, d_bounds);
+            HIPCHK(c, hipMemcpyAsync(&c->h_scalars[24], d_bounds, 16, hipMemcpyDeviceToHost, c->stream));
+        } else if (c->shard_world > 1 || P > 1) {
             s0 = std::lower_bound(key.begin(), key.end(), r.key_lo >> 2) - key.begin();
             s1 = r.key_hi ? (u64)(std::lower_bound(key.begin(), key.end(), r.key_hi >> 2) - key.begin()) : c->NS;
         }
         r.s0 = s0; r.s1 = s1;
     }
     if ((rc = sync_check(c))) return rc;
+    if (d_bounds) memcpy(&r.s0, &c->h_scalars[24], 8), memcpy(&r.s1, &c->h_scalars[26], 8);
     c->D = c->h_scalars[0];
     c->Dsum += c->D;
     if (r.s1 > r.s0)
@@ -635,7 +793,7 @@ static int sort_end(debwt_ctx *c) {
         HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     }
     c->st.distinct_keys = c->Dsum;
-    c->st.special_branch_num = c->special.branch.size();
+    c->st.special_branch_num = c->nbranch;
     c->stage = ST_SORTED;
     return DEBWT_OK;
 }
@@ -761,7 +919,8 @@ static int classify_global(debwt_ctx *c, const u64 *d_facts, u64 nfacts, u64 qba
     ENSURE(c, c->red_q, nf * 4 + 64);
     u64 *all = c->facts_all.as<u64>();
     if (nfacts) HIPCHK(c, hipMemcpyAsync(all, d_facts, nfacts * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(all + nfacts, c->special.tail_facts.data(), nrec * 8, hipMemcpyHostToDevice, c->stream));
+    if (c->special_dev) HIPCHK(c, hipMemcpyAsync(all + nfacts, c->tail_d.p, nrec * 8, hipMemcpyDeviceToDevice, c->stream));
+    else HIPCHK(c, hipMemcpyAsync(all + nfacts, c->special.tail_facts.data(), nrec * 8, hipMemcpyHostToDevice, c->stream));
     u64 *sorted_facts = nullptr;
     if ((rc = sort_keys(c, all, c->facts_tmp.as<u64>(), nf, 2 * c->cfg.k, &sorted_facts, false))) return rc;
     RedUniqueF fr{sorted_facts, nf, c->red.as<u64>()};
@@ -883,12 +1042,12 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
     if (ng && c->mzfilter)
         k_sp_flags<1><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
-            c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
+            c->branch.as<u64>(), c->nbranch, c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
             sp_block_ids(c));
     else if (ng)
         k_sp_flags<0><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
-            c->branch.as<u64>(), (u64)c->special.branch.size(), c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
+            c->branch.as<u64>(), c->nbranch, c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
             sp_block_ids(c));
     SpCountF fc{c->momask.as<u32>() + g0, c->mimask.as<u32>() + g0};
     if ((rc = cp_count2(c, fc, ng, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
@@ -1868,6 +2027,53 @@ extern "C" int debwt_special_digest(const uint64_t *packed, uint64_t n, const ui
     for (uint64_t v : t.head_keys) d[3] = mix(d[3], v);
     for (uint64_t v : t.tail_facts) d[3] = mix(d[3], v);
     for (int i = 0; i < 4; i++) digest[i] = d[i];
+    return DEBWT_OK;
+}
+
+// The special-region tables of the loaded text built twice -- on the device (special_kernels.h) and by the host module
+// (special_host.cpp) -- and compared element by element: mismatch[0..5] = suffix order, keys, BWT symbols, special
+// branches, head nodes, tail nodes (a table of different length counts as all of it).
+extern "C" int debwt_special_compare(debwt_ctx *c, uint64_t mismatch[6]) {
+    if (!c || !mismatch) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    join_special(c);
+    if (c->nrec >= (1ull << 27) || c->NS >= (1ull << 32)) return DEBWT_ERANGE;
+    int rc = special_device_build(c);
+    c->special_dev = false;                                   // a build that follows chooses its own path
+    if (rc) return rc;
+    SpecialTables t;
+    build_special_tables(c->h_text, c->n, c->h_sep.data(), c->nrec, c->K, &t);
+    const u64 NS = c->NS, N = c->nrec;
+    std::vector<u64> pos(NS), key(NS), br(c->nbranch), hk(N), tf(N);
+    std::vector<u8> chr(NS);
+    HIPCHK(c, hipMemcpy(pos.data(), c->sppos.p, NS * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(key.data(), c->spkey.p, NS * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(chr.data(), c->spchr.p, NS, hipMemcpyDeviceToHost));
+    if (c->nbranch) HIPCHK(c, hipMemcpy(br.data(), c->branch.p, c->nbranch * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hk.data(), c->head_keys.p, N * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(tf.data(), c->tail_d.p, N * 8, hipMemcpyDeviceToHost));
+    auto diff = [](const auto &a, const auto &b) {
+        if (a.size() != b.size()) return (uint64_t)std::max(a.size(), b.size());
+        uint64_t d = 0;
+        for (size_t i = 0; i < a.size(); i++) d += a[i] != b[i];
+        return d;
+    };
+    if (getenv("DEBWT_SPECIAL_DEBUG")) {
+        int shown = 0;
+        for (u64 s_ = 0; s_ < NS && shown < 12; s_++)
+            if (pos[s_] != t.pos[s_]) {
+                auto recof = [&](u64 p) { return (u64)(std::lower_bound(c->h_sep.begin(), c->h_sep.end(), p) - c->h_sep.begin()); };
+                const u64 rd = recof(pos[s_]), rh = recof(t.pos[s_]);
+                fprintf(stderr, "special mismatch at %llu: device pos %llu (rec %llu d %llu) host pos %llu (rec %llu d %llu) key %llx / %llx\n",
+                        (unsigned long long)s_, (unsigned long long)pos[s_], (unsigned long long)rd, (unsigned long long)(c->h_sep[rd] - pos[s_]),
+                        (unsigned long long)t.pos[s_], (unsigned long long)rh, (unsigned long long)(c->h_sep[rh] - t.pos[s_]),
+                        (unsigned long long)key[s_], (unsigned long long)t.key[s_]);
+                shown++;
+            }
+    }
+    mismatch[0] = diff(pos, t.pos); mismatch[1] = diff(key, t.key); mismatch[2] = diff(chr, t.chr);
+    mismatch[3] = diff(br, t.branch); mismatch[4] = diff(hk, t.head_keys); mismatch[5] = diff(tf, t.tail_facts);
     return DEBWT_OK;
 }
 

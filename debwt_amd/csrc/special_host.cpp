@@ -256,3 +256,24 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
     std::sort(out->head_keys.begin(), out->head_keys.end());
     lap("heads and tails");
 }
+
+void special_order_record_starts(const uint64_t *words, uint64_t n, const uint64_t *sep, uint64_t nrec, uint32_t *ord,
+                                 const uint32_t *gid, const uint32_t *act, uint64_t na) {
+    Text T{words, n, sep, nrec};
+    std::vector<uint64_t> starts;                       // first element of every group in act
+    for (uint64_t i = 0; i < na; i++)
+        if (i == 0 || gid[act[i]] != gid[act[i - 1]]) starts.push_back(i);
+    starts.push_back(na);
+    const uint64_t ngroups = starts.size() - 1;
+    const unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    parallel_chunks(ngroups > 1 ? nt : 1, ngroups, [&](uint64_t g) {
+        std::vector<uint32_t> recs(starts[g + 1] - starts[g]);
+        for (size_t x = 0; x < recs.size(); x++) recs[x] = ord[act[starts[g] + x]];
+        std::sort(recs.begin(), recs.end(), [&](uint32_t a, uint32_t b) {
+            if (a == b) return false;
+            const uint64_t pa = a ? sep[a - 1] + 1 : 0, pb = b ? sep[b - 1] + 1 : 0;
+            return T.less(pa, a, pb, b);
+        });
+        for (size_t x = 0; x < recs.size(); x++) ord[act[starts[g] + x]] = recs[x];
+    });
+}

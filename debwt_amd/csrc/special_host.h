@@ -24,3 +24,10 @@ struct SpecialTables {
 // positions ascending, sep[nrec-1] == n-1.  K = k-1.
 void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep, uint64_t nrec, int K,
                           SpecialTables *out);
+
+// Inside every tie group of record starts -- act[0..na): ascending places of `ord`, a group = the run of places with
+// equal gid -- sort the records ord[place] by the true suffix order of their first positions.  The device module
+// (special_kernels.h) hands over the few groups that are still tied after its last window round (records that are
+// identical for thousands of symbols).
+void special_order_record_starts(const uint64_t *words, uint64_t n, const uint64_t *sep, uint64_t nrec, uint32_t *ord,
+                                 const uint32_t *gid, const uint32_t *act, uint64_t na);

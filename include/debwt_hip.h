@@ -308,6 +308,11 @@ int debwt_radix_sort_u64(debwt_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint
  * Lets tests compare the threaded module with its single-threaded run (DEBWT_SPECIAL_THREADS / DEBWT_SPECIAL_PAR_MIN). */
 int debwt_special_digest(const uint64_t *packed, uint64_t n, const uint64_t *sep, uint64_t nrec, int k, uint64_t digest[4]);
 
+/* Needs a GPU and a loaded text: builds the same tables on the device (the path collections of many records take,
+ * SURVEY 8f-1) and by the host module, and counts the elements that differ: mismatch[0..5] = suffix order of the
+ * special suffixes, their keys, their BWT symbols, the special branches, the head nodes, the tail nodes. */
+int debwt_special_compare(debwt_ctx *ctx, uint64_t mismatch[6]);
+
 /* Verification tool standing in for the dead LFsearch path (src/LFsearch.c:14-48): inverse BWT
  * by LF walk on the host from a fetched result; writes the n symbols (0..5).  Returns 0 when the
  * walk closes. */
