@@ -542,7 +542,7 @@ static int special_device_build(debwt_ctx *c) {
     const size_t o_ord = take(N * 4), o_gid = take(N * 4), o_actA = take(N * 4), o_actB = take(N * 4), o_val = take(N * 8);
     const size_t o_recs = take(N * 4), o_vals = take(N * 8), o_gids = take(N * 4), o_ordv = take(N * 4);
     const size_t o_head = take((N + 1) * 4), o_stay = take(N), o_rank = take(N * 4);
-    const size_t o_id1 = take(NS * 4), o_id2 = take(NS * 4), o_grp = take(NS * 4), o_gflag = take(NS), o_bnd = take(64);
+    const size_t o_grp = take(NS * 4), o_gflag = take(NS), o_bnd = take(64);
     ENSURE(c, c->sx, off);
     ENSURE(c, c->sppos, NS * 8 + 64);
     ENSURE(c, c->sprec, NS * 4 + 64);
@@ -555,10 +555,18 @@ static int special_device_build(debwt_ctx *c) {
     u32 *rec_s = (u32 *)(base + o_recs), *gid_s = (u32 *)(base + o_gids), *ordv = (u32 *)(base + o_ordv);
     u32 *headpos = (u32 *)(base + o_head), *rank = (u32 *)(base + o_rank);
     u8 *stay = base + o_stay;
-    u32 *id1 = (u32 *)(base + o_id1), *id2 = (u32 *)(base + o_id2), *grp = (u32 *)(base + o_grp);
+    u32 *grp = (u32 *)(base + o_grp);
     u8 *gflag = base + o_gflag;
     const SxText T{c->text.as<u64>(), c->sepbits.as<u64>(), c->sep.as<u64>(), n, N, K};
     auto grid = [](u64 m) { return grid_for(m, 256); };
+    auto other = [&](u64 *p_) { return p_ == X ? Y : X; };
+    // stable 8-bit passes over the bits [lo, hi) of `count` words in a (scratch b); the buffer that holds the result
+    auto lsd = [&](u64 *a, u64 *b, u64 count, int lo, int hi) -> u64 * {
+        hipError_t e = hipSuccess;
+        u64 *res = radix_sort_bits(c->stream, a, b, count, lo, hi, radix_ws(c), &e);
+        if (e != hipSuccess) { c->err = std::string("special-region sort: ") + hipGetErrorString(e); return nullptr; }
+        return res;
+    };
 
     // 1. ranks of the record starts: refinement rounds on 21-symbol windows inside the tie groups
     k_sx_init<<<grid(N), 256, 0, c->stream>>>(ord, gid, act, N);
@@ -581,22 +589,18 @@ static int special_device_build(debwt_ctx *c) {
         }
         const int bA = bits_for(na - 1);
         k_sx_round_keys<<<grid(na), 256, 0, c->stream>>>(T, ord, act, na, w, bA, valbuf, X);
-        // three stable passes, least significant first: low 32 bits of the window, its high 31 bits, the tie group; the
-        // payload of a pass is the place in the order of the pass before (ida / idb / idc: the element at every place)
-        u64 *r = nullptr;
-        if ((rc = sort_keys(c, X, Y, na, 32 + bA, &r, false))) return rc;
-        k_it_ids<<<grid(na), 256, 0, c->stream>>>(r, nullptr, na, bA, id1);
-        k_sx_pass_hi<<<grid(na), 256, 0, c->stream>>>(id1, valbuf, na, bA, X);
-        if ((rc = sort_keys(c, X, Y, na, 31 + bA, &r, false))) return rc;
-        k_it_ids<<<grid(na), 256, 0, c->stream>>>(r, id1, na, bA, id2);
-        u32 *idc = id2;
+        // three stable sorts, least significant field first: low 32 bits of the window, its high 31 bits, the tie group
+        u64 *r = lsd(X, Y, na, bA, bA + 32);
+        if (!r) return DEBWT_EDEVICE;
+        u64 *o = other(r);
+        k_sx_rekey<<<grid(na), 256, 0, c->stream>>>(r, valbuf, gid, act, na, bA, 0, o);
+        if (!(r = lsd(o, other(o), na, bA, bA + 31))) return DEBWT_EDEVICE;
         if (!one_group) {
-            k_sx_pass_gid<<<grid(na), 256, 0, c->stream>>>(id2, gid, act, na, bA, X);
-            if ((rc = sort_keys(c, X, Y, na, bits_for(N - 1) + bA, &r, false))) return rc;
-            k_it_ids<<<grid(na), 256, 0, c->stream>>>(r, id2, na, bA, id1);
-            idc = id1;
+            o = other(r);
+            k_sx_rekey<<<grid(na), 256, 0, c->stream>>>(r, valbuf, gid, act, na, bA, 1, o);
+            if (!(r = lsd(o, other(o), na, bA, bA + bits_for(N - 1)))) return DEBWT_EDEVICE;
         }
-        k_sx_gather<<<grid(na), 256, 0, c->stream>>>(idc, valbuf, ord, gid, act, na, rec_s, val_s, gid_s);
+        k_sx_gather<<<grid(na), 256, 0, c->stream>>>(r, bA, valbuf, ord, gid, act, na, rec_s, val_s, gid_s);
         SxHeadF fh{gid_s, val_s, ordv, headpos};
         if ((rc = cp_count(c, fh, na, cp_area(c, 0), 20))) return rc;
         if ((rc = cp_emit(c, fh, na, cp_area(c, 0)))) return rc;
@@ -617,15 +621,13 @@ static int special_device_build(debwt_ctx *c) {
     u64 *r = nullptr;
     (void)o_bnd;
     k_it_pass1<<<grid(NS), 256, 0, c->stream>>>(rank, N, K, NS, bR, bP, X);
-    if ((rc = sort_keys(c, X, Y, NS, 5 + bR + bP, &r, false))) return rc;
-    k_it_ids<<<grid(NS), 256, 0, c->stream>>>(r, nullptr, NS, bP, id1);
-    k_it_pass_key<<<grid(NS), 256, 0, c->stream>>>(T, id1, NS, 0, bP, X);
-    if ((rc = sort_keys(c, X, Y, NS, 31 + bP, &r, false))) return rc;
-    k_it_ids<<<grid(NS), 256, 0, c->stream>>>(r, id1, NS, bP, id2);
-    k_it_pass_key<<<grid(NS), 256, 0, c->stream>>>(T, id2, NS, 1, bP, X);
-    if ((rc = sort_keys(c, X, Y, NS, 31 + bP, &r, false))) return rc;
-    k_it_ids<<<grid(NS), 256, 0, c->stream>>>(r, id2, NS, bP, id1);
-    k_it_out<<<grid(NS), 256, 0, c->stream>>>(T, id1, NS, c->spkey.as<u64>(), c->spchr.as<u8>(), c->sppos.as<u64>(),
+    if (!(r = lsd(X, Y, NS, bP, bP + 5 + bR))) return DEBWT_EDEVICE;
+    for (int hi = 0; hi < 2; hi++) {
+        u64 *o = other(r);
+        k_it_rekey<<<grid(NS), 256, 0, c->stream>>>(T, r, NS, hi, bP, o);
+        if (!(r = lsd(o, other(o), NS, bP, bP + 31))) return DEBWT_EDEVICE;
+    }
+    k_it_out<<<grid(NS), 256, 0, c->stream>>>(T, r, bP, NS, c->spkey.as<u64>(), c->spchr.as<u8>(), c->sppos.as<u64>(),
                                               c->sprec.as<u32>());
 
     // 3. special branches; head and tail nodes
@@ -642,11 +644,11 @@ static int special_device_build(debwt_ctx *c) {
     if (c->nbranch) {
         fe.branch = X;
         if ((rc = cp_emit(c, fe, NS, cp_area(c, 1)))) return rc;
-        if ((rc = sort_keys(c, X, Y, c->nbranch, bits_for(n), &r, false))) return rc;
+        if (!(r = lsd(X, Y, c->nbranch, 0, bits_for(n)))) return DEBWT_EDEVICE;
         HIPCHK(c, hipMemcpyAsync(c->branch.p, r, c->nbranch * 8, hipMemcpyDeviceToDevice, c->stream));
     }
     k_heads_tails<<<grid(N), 256, 0, c->stream>>>(T, X, c->tail_d.as<u64>());
-    if ((rc = sort_keys(c, X, Y, N, 2 * K + 2, &r, false))) return rc;
+    if (!(r = lsd(X, Y, N, 0, 2 * K + 2))) return DEBWT_EDEVICE;
     HIPCHK(c, hipMemcpyAsync(c->head_keys.p, r, N * 8, hipMemcpyDeviceToDevice, c->stream));
     if ((rc = sync_check(c))) return rc;
     c->special_dev = true;

@@ -12,11 +12,13 @@
 //    rounds on 21-symbol windows of the text in 3-bit codes (A0 C1 G2 T3 #4 $5 -- plain integer order is the
 //    reference's A<C<G<T<#<$ with '#' equal to '#' and the comparison running on past it): round w sorts the still
 //    tied record starts by their w-th window inside their tie group; a group that is a single record is done.  The
-//    sorts are the 64-bit radix sort of the key path with the element's index in the low bits as payload.
+//    sorts are the stable 8-bit radix passes of the key path (radix_sort_bits) over the field bits, with the element's
+//    index below them as payload.
 // 2. Special suffixes.  Item (record r, offset d) gets the sort key (T-padded node key, K-1-d, rank of record r+1's
 //    start) -- a separator ranks above every base and the padding is the largest base, so among equal keys the suffix
 //    that reaches its separator later is the smaller one, and '$' ranks above '#' (the last record's follower rank is
-//    the largest) -- sorted by three stable LSD passes (31 + 31 + (5 + rank) bits, payload = place in the pass before).
+//    the largest) -- sorted by three stable LSD sorts, least significant field first ((5 + rank) + 31 + 31 bits); the
+//    item id sits below the field as payload and is not sorted on: the passes are stable.
 // 3. Special branches: runs of equal K-windows (same offset and kind of separator) whose symbols K ahead differ, by a
 //    head-flag scan over the sorted items; head / tail nodes per record.
 #pragma once
@@ -66,27 +68,22 @@ __global__ void k_sx_round_keys(SxText T, const u32 *__restrict__ ord, const u32
     valbuf[a] = val;
     keyA[a] = ((val & 0xFFFFFFFFull) << bA) | a;
 }
-// second sort key = high 31 bits of the window | place in the order of the first sort (ida: element at that place)
-__global__ void k_sx_pass_hi(const u32 *__restrict__ ida, const u64 *__restrict__ valbuf, u64 na, int bA,
-                             u64 *__restrict__ keyB) {
+// second / third sort key of a round, in the order the pass before left (the passes are stable and sort the key bits
+// above the payload only, so the payload -- the active element -- rides along): high 31 bits of the window, tie group
+__global__ void k_sx_rekey(const u64 *__restrict__ src, const u64 *__restrict__ valbuf, const u32 *__restrict__ gid,
+                           const u32 *__restrict__ act, u64 na, int bA, int which, u64 *__restrict__ dst) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= na) return;
-    keyB[i] = ((valbuf[ida[i]] >> 32) << bA) | i;
+    const u64 a = src[i] & ((1ull << bA) - 1ull);
+    dst[i] = ((which ? (u64)gid[act[a]] : (valbuf[a] >> 32)) << bA) | a;
 }
-// third sort key = tie group | place in the order of the second sort
-__global__ void k_sx_pass_gid(const u32 *__restrict__ idb, const u32 *__restrict__ gid, const u32 *__restrict__ act,
-                              u64 na, int bA, u64 *__restrict__ keyC) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= na) return;
-    keyC[i] = ((u64)gid[act[idb[i]]] << bA) | i;
-}
-// records, windows and groups in the order (group, window); idc: active element at every place of that order
-__global__ void k_sx_gather(const u32 *__restrict__ idc, const u64 *__restrict__ valbuf, const u32 *__restrict__ ord,
-                            const u32 *__restrict__ gid, const u32 *__restrict__ act, u64 na, u32 *__restrict__ rec_s,
-                            u64 *__restrict__ val_s, u32 *__restrict__ gid_s) {
+// records, windows and groups in the order (group, window)
+__global__ void k_sx_gather(const u64 *__restrict__ sorted, int bA, const u64 *__restrict__ valbuf,
+                            const u32 *__restrict__ ord, const u32 *__restrict__ gid, const u32 *__restrict__ act, u64 na,
+                            u32 *__restrict__ rec_s, u64 *__restrict__ val_s, u32 *__restrict__ gid_s) {
     const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= na) return;
-    const u64 a = idc[f];
+    const u64 a = sorted[f] & ((1ull << bA) - 1ull);
     const u32 p = act[a];
     rec_s[f] = ord[p]; val_s[f] = valbuf[a]; gid_s[f] = gid[p];
 }
@@ -136,26 +133,20 @@ __global__ void k_it_pass1(const u32 *__restrict__ rank, u64 N, int K, u64 NS, i
     const u64 follower = r + 1 < N ? (u64)rank[r + 1] : N;     // '$' ranks above every '#'
     key[i] = (((e << bR) | follower) << bP) | i;
 }
-__global__ void k_it_ids(const u64 *__restrict__ sorted, const u32 *__restrict__ id_prev, u64 NS, int bP,
-                         u32 *__restrict__ id) {
+// the next pass's key bits above the item id, in the order the pass before left: low / high 31 bits of the padded key
+__global__ void k_it_rekey(SxText T, const u64 *__restrict__ src, u64 NS, int hi, int bP, u64 *__restrict__ dst) {
     const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= NS) return;
-    const u64 v = sorted[q] & ((1ull << bP) - 1ull);
-    id[q] = id_prev ? id_prev[v] : (u32)v;
-}
-__global__ void k_it_pass_key(SxText T, const u32 *__restrict__ id, u64 NS, int hi, int bP, u64 *__restrict__ key) {
-    const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= NS) return;
-    const u64 i = id[q], r = i / (u64)T.K;
+    const u64 i = src[q] & ((1ull << bP) - 1ull), r = i / (u64)T.K;
     const int d = T.K - 1 - (int)(i - r * (u64)T.K);
     const u64 k62 = T.item_key(r, d);
-    key[q] = ((hi ? (k62 >> 31) : (k62 & 0x7FFFFFFFull)) << bP) | q;
+    dst[q] = ((hi ? (k62 >> 31) : (k62 & 0x7FFFFFFFull)) << bP) | i;
 }
-__global__ void k_it_out(SxText T, const u32 *__restrict__ id, u64 NS, u64 *__restrict__ spkey, u8 *__restrict__ spchr,
-                         u64 *__restrict__ sppos, u32 *__restrict__ sprec) {
+__global__ void k_it_out(SxText T, const u64 *__restrict__ sorted, int bP, u64 NS, u64 *__restrict__ spkey,
+                         u8 *__restrict__ spchr, u64 *__restrict__ sppos, u32 *__restrict__ sprec) {
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= NS) return;
-    const u64 i = id[s], r = i / (u64)T.K;
+    const u64 i = sorted[s] & ((1ull << bP) - 1ull), r = i / (u64)T.K;
     const int d = T.K - 1 - (int)(i - r * (u64)T.K);
     const u64 p = T.sep[r] - (u64)d;
     spkey[s] = T.item_key(r, d);

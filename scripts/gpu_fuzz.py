@@ -39,6 +39,8 @@ for c in range(cases):
     k = int(rng.choice([12, 13, 16, 20, 24, 27, 31, 32]))
     tune = int(rng.choice([0, 0, 0, 32, 48, 128, 160, 256, 2048, 4096, 4096 + 32, 4096 + 6, 8192, 8192 + 128]))
     cap = int(rng.choice([0, 0, 4096, 20000, 300000]))
+    if rng.integers(0, 3) == 0: os.environ["DEBWT_SPECIAL_DEVICE_MIN"] = "0"      # special-region module on the device at any size
+    else: os.environ.pop("DEBWT_SPECIAL_DEVICE_MIN", None)
     sym = O.sym_from_codes(recs)
     ow, oh, od, ost = O.build_bwt(sym, k)
     d = api.DeBWT(k=k, tune=tune)

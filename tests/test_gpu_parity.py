@@ -130,6 +130,59 @@ def test_hundred_thousand_records_equal_oracle(api, oracle):
     d.close()
 
 
+@pytest.mark.parametrize("case", ["adversarial", "reads", "contigs_dup", "reads_20000", "single_record"])
+@pytest.mark.parametrize("max_rounds", [None, 2])
+def test_special_region_tables_device_equals_host(api, case, max_rounds, monkeypatch):
+    """the special-region tables (suffix order of the N*K special suffixes, their keys and BWT symbols, the
+    special branches, head and tail nodes: src/collect#$.c:118-157,428-455,468-598) built by the device module against
+    the host module, element by element (debwt_special_compare); max_rounds = 2 sends every tie group of record starts
+    that is still tied after 42 symbols to the host comparison (the path of records identical for thousands of symbols)."""
+    from debwt_amd import synth
+    if max_rounds is not None:
+        monkeypatch.setenv("DEBWT_SPECIAL_MAX_ROUNDS", str(max_rounds))
+    rng = np.random.default_rng(4242)
+    if case == "adversarial":
+        sets = [(_adversarial(rng), int(rng.choice([12, 16, 20, 27, 32]))) for _ in range(25)]
+    elif case == "reads":
+        sets = [(synth.read_set(int(rng.integers(2, 600)), 50, int(rng.integers(60, 300)), 20_000, seed=int(rng.integers(1, 1 << 30)),
+                                snap=int(rng.choice([1, 4, 8])), dup_every=int(rng.choice([0, 3, 16]))), int(rng.choice([12, 21, 32])))
+                for _ in range(15)]
+    elif case == "contigs_dup":       # exact duplicates of 3-8 kb: tied for hundreds of windows
+        sets = [(synth.read_set(2000, 3000, 8000, 4_000_000), 32), (synth.read_set(300, 3000, 8000, 400_000, dup_every=2), 20)]
+    elif case == "reads_20000":
+        sets = [(synth.read_set(20000, 60, 400, 1_000_000), 32), (synth.read_set(20000, 60, 400, 1_000_000), 16)]
+    else:
+        sets = [([synth.uniform_codes(5000)], 32), (synth.pan_genome(3000, 2), 12)]
+    for recs, k in sets:
+        d = api.DeBWT(k=k)
+        d.load_records(recs)
+        assert d.special_compare() == [0, 0, 0, 0, 0, 0], (case, k, len(recs))
+        d.close()
+
+
+def test_device_special_region_module_forced_on_small_inputs_equals_oracle(api, oracle, monkeypatch):
+    """The device module at any size (DEBWT_SPECIAL_DEVICE_MIN=0) inside full builds, single and multi-range, against
+    the oracle: adversarial collections (duplicates, prefix-duplicates, shared ends, homopolymer ends) and read sets."""
+    from debwt_amd import synth
+    monkeypatch.setenv("DEBWT_SPECIAL_DEVICE_MIN", "0")
+    rng = np.random.default_rng(777)
+    for c in range(60):
+        recs = _adversarial(rng) if c % 2 else synth.read_set(int(rng.integers(2, 300)), 50, 200, 10_000,
+                                                              seed=int(rng.integers(1, 1 << 30)), snap=4, dup_every=5)
+        k = int(rng.choice([12, 16, 21, 32]))
+        ow, oh, od, ost = oracle.build_bwt(oracle.sym_from_codes(recs), k)
+        d = api.DeBWT(k=k)
+        if c % 3 == 0:
+            d.set_range_cap(4096)
+        d.load_records(recs)
+        d.build()
+        w, h, dr = d.fetch()
+        st = d.stats()
+        assert st["special_path"] == 2 and st["special_branch_num"] == ost["special_branch_num"]
+        assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od, (c, k)
+        d.close()
+
+
 def test_sorted_keys_are_refused_once_their_buffer_is_reused(api):
     """DEBWT_ARR_SORTED_KEYS names a buffer the SP stage reuses as scratch: after that stage the fetch is an error,
     not stale bytes."""
