@@ -104,6 +104,7 @@ struct debwt_ctx {
     u64 S_local = 0, B_slice = 0, sp_off = 0;
     int hbits = 10, pbits = 13;
     bool mzfilter = false;      // the prefilter is indexed by the nodes' minimizers (pbits = log2 of its 64-bit words)
+    bool mztable = false;       // ... and so is the node table (k_build_hash)
     bool abs32 = true;          // fill cursors hold absolute blue slots
 
     hipEvent_t ev[8]{};         // stage boundaries
@@ -985,6 +986,7 @@ static int sp_prepare(debwt_ctx *c) {
     // The plain bitmap is kept for small node tables (below 2^20 slots: a few Mbp); from there on the minimizer filter
     // wins (250 Mbp: SP stage 3.16 ms against 3.41 ms).  cfg.reserved bit 12 forces it for any size (tests).
     c->mzfilter = c->K >= 24 && !(c->cfg.reserved & 2048) && (hbits >= 20 || (c->cfg.reserved & 4096));
+    c->mztable = c->mzfilter && (c->cfg.reserved & 16384);        // cfg.reserved bit 14: node table addressed by minimizer (A/B, tests)
     int pb;
     if (c->mzfilter) {
         pb = 10;
@@ -1011,7 +1013,7 @@ static int sp_prepare(debwt_ctx *c) {
         k_build_hash<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->red_q.as<u32>(),
                                                                 c->blk_start.as<u64>(), c->abs32 ? 1 : 0, (u32)c->qbase,
                                                                 (u32)c->Q, hbits, c->htab.as<HSlot>(), c->mzfilter ? 0 : pb,
-                                                                c->rbits.as<u32>());
+                                                                c->rbits.as<u32>(), c->mztable ? c->K : 0);
         if (c->mzfilter)
             k_build_mzfilter<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->K, pb, c->rbits.as<u64>());
     }
@@ -1041,7 +1043,12 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
     if (g1 - g0 > (1ull << 27) - 2) { c->err = "text slice of the SP stage exceeds 2^32 positions"; return DEBWT_ERANGE; }
     c->g0 = g0; c->g1 = g1;
     const u64 ng = g1 - g0;
-    if (ng && c->mzfilter)
+    if (ng && c->mzfilter && c->mztable)
+        k_sp_flags<2><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+            c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
+            c->branch.as<u64>(), c->nbranch, c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
+            sp_block_ids(c));
+    else if (ng && c->mzfilter)
         k_sp_flags<1><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
             c->branch.as<u64>(), c->nbranch, c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
@@ -1119,11 +1126,11 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
             if (c->abs32)
                 k_blue_fill<1><<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
                     c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, c->blk_start.as<u64>(),
-                    (u32)c->qbase, c->blue.as<u64>());
+                    (u32)c->qbase, c->blue.as<u64>(), c->mztable ? c->K : 0);
             else
                 k_blue_fill<0><<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
                     c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, c->blk_start.as<u64>(),
-                    (u32)c->qbase, c->blue.as<u64>());
+                    (u32)c->qbase, c->blue.as<u64>(), c->mztable ? c->K : 0);
         }
         S += c->S_local; Bseen += c->B_slice;
     }

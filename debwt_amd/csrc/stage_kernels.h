@@ -511,18 +511,61 @@ struct __attribute__((aligned(16))) HSlot {
 __device__ __forceinline__ u32 red_hash(u64 node, int bits) { return (u32)((node * 0x9E3779B97F4A7C15ull) >> (64 - bits)); }
 __device__ __forceinline__ u32 red_hash2(u64 node, int bits) { return (u32)((node * 0xC2B2AE3D27D4EB4Full) >> (64 - bits)); }
 
+// Node table addressed by minimizer (mzK > 0; cfg.reserved bit 14, NOT the default: measured at 30 Gbp it fetches 24 % fewer
+// lines per slice -- 561 M read requests against 735 M -- but the SP flags pass takes 434 ms per build against 424 ms,
+// DESIGN.md section 8).  Consecutive text positions
+// hold nodes that overlap in all but one symbol and mostly share their minimizer, and in repeat families nearly every
+// position is a branching node: with the table hashed by node every one of them is a random 128-byte line (PMC at
+// 30 Gbp: 40 bytes fetched per text position).  Addressed by MINIMIZER, the nodes of neighbouring positions are
+// neighbours in the table: a minimizer owns a window of 32 slots (512 bytes), and a node sits in the pair of slots
+// that belongs to the OFFSET of the minimizer inside the node (0 .. K-16: 16 pairs) -- the next text position has the
+// same minimizer one symbol further left, i.e. the pair before.  One 32-byte load per candidate, no search, and a
+// stretch of positions walks its window line by line.  A node whose pair is taken (several branching nodes with the same
+// minimizer at the same offset, windows of different minimizers that collide) goes to its node hash with ordinary
+// linear probing; slots are never freed, so a lookup that finds an empty slot in the pair knows the node is in neither
+// place.
+#define MZ_W 16
+__device__ __forceinline__ u32 mz_hash(u32 x) { x *= 0x9E3779B1u; x ^= x >> 15; return x * 0x85EBCA6Bu; }
+__device__ __forceinline__ u32 mz_word(u32 m, int fbits) { return (m * 0xC2B2AE3Du) >> (32 - fbits); }
+__device__ __forceinline__ u32 mz_bit(u64 node) { return (u32)((node * 0xC2B2AE3D27D4EB4Full) >> 58); }
+// first slot of the pair of (minimizer m at offset o of the node)
+__device__ __forceinline__ u32 mz_pair(u32 m, u32 o, int hbits) { return (((m * 0x27D4EB2Fu) >> (32 - (hbits - 5))) << 5) + 2u * o; }
+// minimizer of a node and its offset (the first 16-mer with the smallest hash)
+__device__ __forceinline__ u32 mz_of_node(u64 node, int K, u32 *off) {
+    const u64 win = node << (64 - 2 * K);
+    const int nw = K - MZ_W + 1;
+    u32 m = 0xFFFFFFFFu, o = 0;
+    for (int j = 0; j < nw; j++) {
+        const u32 h = mz_hash((u32)(win >> (32 - 2 * j)));
+        if (h < m) { m = h; o = (u32)j; }
+    }
+    *off = o;
+    return m;
+}
+
 __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__restrict__ red_q,
                              const u64 *__restrict__ blk_start, int abs32, u32 qbase, u32 Qlocal, int hbits,
-                             HSlot *__restrict__ htab, int pb, u32 *__restrict__ rbits) {
+                             HSlot *__restrict__ htab, int pb, u32 *__restrict__ rbits, int mzK) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const u64 v = red[r], node = v >> 2;
     const u32 mask = (1u << hbits) - 1u;
-    u32 h = red_hash(node, hbits);
-    for (;;) {
-        u64 old = atomicCAS(&htab[h].key, 0ull, v);
-        if (old == 0ull) break;
-        h = (h + 1) & mask;
+    u32 h = 0;
+    bool placed = false;
+    if (mzK) {
+        u32 o;
+        const u32 m = mz_of_node(node, mzK, &o);
+        h = mz_pair(m, o, hbits);
+        placed = atomicCAS(&htab[h].key, 0ull, v) == 0ull;
+        if (!placed) placed = atomicCAS(&htab[++h].key, 0ull, v) == 0ull;
+    }
+    if (!placed) {
+        h = red_hash(node, hbits);
+        for (;;) {
+            u64 old = atomicCAS(&htab[h].key, 0ull, v);
+            if (old == 0ull) break;
+            h = (h + 1) & mask;
+        }
     }
     // fill cursor of a multi-in node (redPoint analogue, src/INandOut.c:413): the next free blue slot of its block
     // when all blue slots of the context fit 32 bits (abs32), else the entries placed so far (the block's first
@@ -546,26 +589,27 @@ __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__re
 // a minimizer share the word (red nodes cluster around the same loci), the words are sized for ~2 red nodes each; a
 // minimizer that very many red nodes share (a homopolymer's) saturates its word and merely sends its positions to the
 // node table, as every position went before.  Used for K >= 24 (a node then has >= 9 candidate 16-mers).
-#define MZ_W 16
-__device__ __forceinline__ u32 mz_hash(u32 x) { x *= 0x9E3779B1u; x ^= x >> 15; return x * 0x85EBCA6Bu; }
-__device__ __forceinline__ u32 mz_word(u32 m, int fbits) { return (m * 0xC2B2AE3Du) >> (32 - fbits); }
-__device__ __forceinline__ u32 mz_bit(u64 node) { return (u32)((node * 0xC2B2AE3D27D4EB4Full) >> 58); }
 __global__ void k_build_mzfilter(const u64 *__restrict__ red, u64 R, int K, int fbits, u64 *__restrict__ fw) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
-    const u64 node = red[r] >> 2, win = node << (64 - 2 * K);
-    const int nw = K - MZ_W + 1;
-    u32 m = 0xFFFFFFFFu;
-    for (int j = 0; j < nw; j++) {
-        const u32 h = mz_hash((u32)(win >> (32 - 2 * j)));
-        m = h < m ? h : m;
-    }
-    atomicOr(&fw[mz_word(m, fbits)], 1ull << mz_bit(node));
+    const u64 node = red[r] >> 2;
+    u32 o;
+    atomicOr(&fw[mz_word(mz_of_node(node, K, &o), fbits)], 1ull << mz_bit(node));
 }
 
-// returns the slot (or 0xFFFFFFFF) and the flags of `node`
-__device__ __forceinline__ u32 red_lookup(const HSlot *__restrict__ htab, int hbits, u64 node, u32 *flags) {
+// returns the slot (or 0xFFFFFFFF) and the flags of `node`; mzK > 0: the table is addressed by minimizer (k_build_hash)
+__device__ __forceinline__ u32 red_lookup(const HSlot *__restrict__ htab, int hbits, u64 node, u32 *flags, int mzK = 0) {
     const u32 mask = (1u << hbits) - 1u;
+    if (mzK) {
+        u32 o;
+        const u32 m = mz_of_node(node, mzK, &o);
+        const u32 a = mz_pair(m, o, hbits);
+        for (u32 h = a; h < a + 2u; h++) {
+            const u64 v = htab[h].key;
+            if (v == 0ull) { *flags = 0; return 0xFFFFFFFFu; }
+            if ((v >> 2) == node) { *flags = (u32)(v & 3); return h; }
+        }
+    }
     u32 h = red_hash(node, hbits);
     for (;;) {
         u64 v = htab[h].key;
@@ -585,6 +629,15 @@ __device__ __forceinline__ u32 red_lookup_q(const HSlot *__restrict__ htab, int 
         if ((v.x >> 2) == node) { *q = (u32)(v.y >> 32); return (u32)(v.x & 3); }
         h = (h + 1) & mask;
     }
+}
+// minimizer-addressed table: a = first slot of the node's pair (mz_pair)
+__device__ __forceinline__ u32 red_lookup_q_mz(const HSlot *__restrict__ htab, int hbits, u64 node, u32 a, u32 *q) {
+    const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(&htab[a]);
+    const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(&htab[a + 1u]);
+    if ((v0.x >> 2) == node && v0.x) { *q = (u32)(v0.y >> 32); return (u32)(v0.x & 3); }
+    if ((v1.x >> 2) == node && v1.x) { *q = (u32)(v1.y >> 32); return (u32)(v1.x & 3); }
+    if (v0.x == 0ull || v1.x == 0ull) return 0u;
+    return red_lookup_q(htab, hbits, node, q);
 }
 
 // rows of the special suffixes: rank among the node instances + own rank (src/INandOut.c:419-439)
@@ -650,14 +703,21 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
         u64 fwv = 0;
 #pragma unroll
         for (u32 t = 0; t < 32; t++) {
-            u32 m = H[t];
+            u32 m = H[t], o = 0;
 #pragma unroll
             for (int d = 1; d < 16; d++)
-                if (d < nw) m = H[t + d] < m ? H[t + d] : m;
+                if (d < nw) {
+                    const bool lt = H[t + d] < m;
+                    m = lt ? H[t + d] : m;
+                    if (MZ == 2) o = lt ? (u32)d : o;
+                }
             if (t == 0 || m != mprev) fwv = fw[mz_word(m, pb)];
             mprev = m;
             const u64 win = t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0;
-            cand |= (u32)((fwv >> mz_bit(win >> (64 - 2 * K))) & 1ull) << t;
+            const u32 bit = (u32)((fwv >> mz_bit(win >> (64 - 2 * K))) & 1ull);
+            // the node table is addressed by (minimizer, its offset in the node) too: the candidate's pair of slots
+            if (MZ == 2 && bit) lq[threadIdx.x * 32 + t] = mz_pair(m, o, hbits);
+            cand |= bit << t;
         }
     } else {
 #pragma unroll
@@ -675,6 +735,46 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict_
     cand &= inrange & ~spec;
     spec &= inrange;
     // phase 2: only the candidates pay for the table search
+    if (MZ == 2) {
+        // minimizer-addressed table (cfg.reserved bit 14): SP_BATCH candidates are addressed and their pairs of slots
+        // requested before the first answer is used (their lines are mostly in L2: what is left is the round trip)
+        constexpr int SP_BATCH = 4;
+        while (cand) {
+            u32 tt[SP_BATCH], ad[SP_BATCH];
+            u64 nd[SP_BATCH];
+            ulonglong2 v0[SP_BATCH], v1[SP_BATCH];
+            bool have[SP_BATCH];
+#pragma unroll
+            for (int b = 0; b < SP_BATCH; b++) {
+                have[b] = cand != 0u;
+                const u32 t = have[b] ? (u32)__ffs(cand) - 1u : 0u;
+                cand &= cand - 1u;                              // 0 stays 0
+                tt[b] = t;
+                nd[b] = (t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0) >> (64 - 2 * K);
+                ad[b] = lq[threadIdx.x * 32 + t];
+            }
+#pragma unroll
+            for (int b = 0; b < SP_BATCH; b++) {
+                v0[b] = v1[b] = make_ulonglong2(0ull, 0ull);
+                if (have[b]) {
+                    v0[b] = *reinterpret_cast<const ulonglong2 *>(&htab[ad[b]]);
+                    v1[b] = *reinterpret_cast<const ulonglong2 *>(&htab[ad[b] + 1u]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < SP_BATCH; b++) {
+                if (!have[b]) continue;
+                u32 fl = 0, q = 0;
+                // the pair of (minimizer, offset): a match, an empty slot (the node is in neither place), or on to the node hash
+                if (v0[b].x && (v0[b].x >> 2) == nd[b]) { fl = (u32)(v0[b].x & 3ull); q = (u32)(v0[b].y >> 32); }
+                else if (v1[b].x && (v1[b].x >> 2) == nd[b]) { fl = (u32)(v1[b].x & 3ull); q = (u32)(v1[b].y >> 32); }
+                else if (v0[b].x && v1[b].x) fl = red_lookup_q(htab, hbits, nd[b], &q);
+                mo |= (fl & 1u) << tt[b];
+                mi |= ((fl >> 1) & 1u) << tt[b];
+                if (ids.list && (fl & 2u)) lq[threadIdx.x * 32 + tt[b]] = q;
+            }
+        }
+    }
     while (cand) {
         u32 t = (u32)__ffs(cand) - 1u;
         cand &= cand - 1u;
@@ -818,12 +918,12 @@ template <int ABS32>
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const ulonglong2 *__restrict__ mi_list, u64 B,
                                                             HSlot *__restrict__ htab, int hbits,
                                                             const u64 *__restrict__ blk_start, u32 qbase,
-                                                            u64 *__restrict__ blue) {
+                                                            u64 *__restrict__ blue, int mzK) {
     u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     ulonglong2 it = mi_list[b];
     u32 fl;
-    u32 h = red_lookup(htab, hbits, it.x, &fl);
+    u32 h = red_lookup(htab, hbits, it.x, &fl, mzK);
     if (h == 0xFFFFFFFFu) return;
     if (ABS32) {
         if (htab[h].cur == HCURSOR_SKIP) return;                            // block owned by another shard

@@ -637,8 +637,9 @@ def test_shard_world_limit(api):
 @pytest.mark.parametrize("entry", [e for e in MANIFEST if e["k"] >= 24], ids=golden_id)
 def test_minimizer_prefilter_matches_reference_golden(api, entry):
     """The SP stage's prefilter indexed by minimizers (the form large texts use; tune bit 12 forces it at any size), with
-    the filter at its default size and cut to 1/4 (saturated words send more positions to the node table)."""
-    for tune in (4096, 4096 + 6):
+    the filter at its default size and cut to 1/4 (saturated words send more positions to the node table); the node
+    table hashed by node (the default) and addressed by (minimizer, offset) pairs (bit 14)."""
+    for tune in (4096, 4096 + 6, 4096 + 16384):
         d = api.DeBWT(k=entry["k"], tune=tune)
         d.load_records(golden_records(entry))
         d.build()
