@@ -973,13 +973,7 @@ __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ ke
             // are empty, so the two lists never meet): several workgroups share its run-length encoding
             if ((e - x0) / RLW_H >= RLU_LONG) unfit[gridDim.x - 1u - atomicAdd(nunfit + 2, 1u)] = blockIdx.x;
         }
-        u32 bad = 0;
-        for (u64 i = s + lane; i + 1 < e && !bad; i += 64) bad = keys[i] > keys[i + 1] ? 1u : 0u;
-        if (__ballot(bad != 0) == 0ull) return;
-        u64 t0 = s / RL_H, t1 = (e - 1) / RL_H;
-        if (t0 > 0) t0--;
-        for (u64 t = t0 + lane; t <= t1; t += 64) mark[t] = 1;
-        return;
+        return;                               // rs_local_unfit_kernel takes the stretch from the list (and tests its order there)
     }
     const u32 cnt = (u32)(e - s);
     // LDS operations of one wave execute in order: no barrier between the writes and the reads of its own tile

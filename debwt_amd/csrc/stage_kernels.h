@@ -663,8 +663,11 @@ struct SpBlockIds {
 
 // pass 1: one lane = 32 consecutive positions = one text word (coalesced 8-byte loads); per position the
 // node is a shift of the 128-bit (w0,w1) pair; flags go out as two 32-bit masks per group
+#ifndef SP_FLAGS_WAVES
+#define SP_FLAGS_WAVES 4
+#endif
 template <int MZ>
-__global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_flags(const u64 *__restrict__ text, const u64 *__restrict__ sepbits,
+__global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_FLAGS_WAVES))) void k_sp_flags(const u64 *__restrict__ text, const u64 *__restrict__ sepbits,
                                                            u64 n, int K, const HSlot *__restrict__ htab, int hbits,
                                                            const u32 *__restrict__ rbits, int pb,
                                                            const u64 *__restrict__ branch, u64 nbranch,

@@ -124,9 +124,9 @@ def measure_link(device, mib_per_peer=1024, reps=2):
     """What a key exchange would run at on THIS node, measured instead of assumed (the cost model's link rate,
     debwt_shard_key_mode): an all_to_all of `mib_per_peer` MiB to every peer -- cut into P2P_MAX calls exactly like the
     exchanges of a build -- timed after one warm-up; the sustained one-direction rate per peer pair becomes
-    LINK_GBYTES_PER_S unless DEBWT_LINK_GBYTES_PER_S fixes it.  Also re-probes, between real peers, the RCCL message
-    limit found in a group of one (a single message above 1 GiB arrives with its second half zeroed): one 1.25 GiB
-    message per peer, checked at the receiver.  Collective: every rank calls it."""
+    LINK_GBYTES_PER_S unless DEBWT_LINK_GBYTES_PER_S fixes it.  With DEBWT_BIG_MESSAGE_PROBE=1 it also re-probes, between
+    real peers, the RCCL message limit found in a group of one (a single message above 1 GiB arrives with its second half
+    zeroed): one 1.25 GiB message per peer, checked at the receiver.  Collective: every rank calls it."""
     global LINK_GBYTES_PER_S
     world, rank = dist.get_world_size(), dist.get_rank()
     if world < 2:
@@ -154,8 +154,9 @@ def measure_link(device, mib_per_peer=1024, reps=2):
     res = {"all_to_all_mib_per_peer": mib_per_peer, "seconds": round(best, 4), "gbytes_per_s_per_peer": round(per_peer, 2),
            "gbytes_per_s_out_of_one_gpu": round(per_peer * (world - 1), 2), "content_ok": bool(ok),
            "calls_of_at_most_bytes": P2P_MAX}
-    # one message of 1.25 GiB per peer in ONE call (the exchanges never do this: they stay below P2P_MAX)
-    if _on_device() and os.environ.get("DEBWT_SKIP_BIG_MESSAGE_PROBE") is None:
+    # one message of 1.25 GiB per peer in ONE call (the exchanges never do this: they stay below P2P_MAX).  Opt-in
+    # (DEBWT_BIG_MESSAGE_PROBE=1): a library that mishandles such a message must not be able to take a bench run down
+    if _on_device() and os.environ.get("DEBWT_BIG_MESSAGE_PROBE") == "1":
         try:
             big = (5 << 28) // 8
             a = torch.empty(big * world, dtype=torch.int64, device=device)

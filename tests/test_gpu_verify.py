@@ -174,7 +174,7 @@ def test_multi_gpu_host_from_one_process(api, oracle, devices, case, k, cap, tun
     m.close()
 
 
-def _run_bench_direct(extra, timeout=900):
+def _run_bench_direct(extra, timeout=900, env_extra=None):
     """`python bench.py --gpus N ...` exactly as the driver types it for N = 1: no launcher in front."""
     import json
     import os
@@ -182,6 +182,7 @@ def _run_bench_direct(extra, timeout=900):
     import sys
     from conftest import ROOT
     env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True,
                        text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -199,6 +200,9 @@ def test_bench_two_ranks_started_by_bench_itself_gloo():
     assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "strong" and j["value"] > 0
     assert j["check"]["census_equals_text"] and j["check"]["inverse_bwt_ok"], j["check"]
     assert "chr1_250M" in j["config"]["workload"] and j["config"]["bases_per_gpu"] * 2 <= j["config"]["bases"]
+    # the link probe ran and both key paths were timed (--mode auto times the one the cost model did not choose as well)
+    assert j["link_probe"]["content_ok"] and set(j["key_modes_ms"]) >= {"exchange", "rescan"}, (j["link_probe"], j["key_modes_ms"])
+    assert all(isinstance(j["key_modes_ms"][m], float) for m in ("exchange", "rescan")), j["key_modes_ms"]
 
 
 def test_bench_two_ranks_started_by_bench_itself_rccl():
@@ -208,5 +212,6 @@ def test_bench_two_ranks_started_by_bench_itself_rccl():
         pytest.skip("one GPU on this box: two RCCL ranks need two devices")
     for mode in ("exchange", "rescan"):
         j = _run_bench_direct(["--gpus", "2", "--workload", "chr1_250M", "--steps", "1", "--warmup", "1",
-                               "--no-cpu-baseline", "--mode", mode])
+                               "--no-cpu-baseline", "--mode", mode], env_extra={"DEBWT_BIG_MESSAGE_PROBE": "1"})
         assert j["n_gpus"] == 2 and j["check"]["census_equals_text"] and j["check"]["inverse_bwt_ok"], j
+        assert j["link_probe"]["content_ok"] and j["link_probe"]["gbytes_per_s_per_peer"] > 0, j["link_probe"]
