@@ -1,4 +1,4 @@
-// fasta_host.cpp -- multi-threaded FASTA -> 2-bit packed text.
+// fasta_host.cpp -- multi-threaded FASTA (and FASTQ) -> 2-bit packed text.
 //
 // Replaces the reference's single-threaded ingest (kseq.h + zlib, one base at a time into `reference`,
 // src/collect#$.c:34-90): the file is mapped (or inflated, when gzip), cut into one chunk per thread at arbitrary
@@ -288,12 +288,75 @@ int fail(char *err, size_t errlen, const std::string &msg) {
     return -1;
 }
 
+// FASTQ, which the reference's reader accepts as well (klib kseq_read, src/kseq.h:177-201: '@' header, sequence lines up
+// to the line that starts with '+', then quality characters until there are as many as bases, quality of another length
+// = error): the records are rewritten as header-less FASTA (">\n" + the sequence lines) into `out`, which the chunked
+// FASTA parser then takes.  One serial walk over the lines (memchr speed): a quality line may start with '@' or '>', so
+// record starts cannot be recognised from the middle of the file.  Returns the FASTA length, or -1 with a message.
+long fastq_to_fasta(const char *buf, size_t len, char *out, char *err, size_t errlen) {
+    size_t i = 0, o = 0;
+    uint64_t rec = 0;
+    auto line_end = [&](size_t from) {                       // index of the newline that ends the line at `from`, or len
+        const void *nl = memchr(buf + from, '\n', len - from);
+        return nl ? (size_t)((const char *)nl - buf) : len;
+    };
+    auto payload = [&](size_t from, size_t to) {             // characters of [from, to) that are not white space
+        size_t c = 0;
+        for (size_t j = from; j < to; j++) c += !(buf[j] == '\r' || buf[j] == ' ' || buf[j] == '\t');
+        return c;
+    };
+    while (i < len) {
+        if (buf[i] == '\n' || buf[i] == '\r') { i++; continue; }               // blank lines between records
+        if (buf[i] != '@') {
+            char m[120];
+            snprintf(m, sizeof m, "FASTQ record %llu does not start with '@' (byte %zu)", (unsigned long long)rec + 1, i);
+            fail(err, errlen, m);
+            return -1;
+        }
+        i = std::min(len, line_end(i) + 1);                                     // header line: the name is not used
+        out[o++] = '>'; out[o++] = '\n';
+        size_t bases = 0;
+        while (i < len && buf[i] != '+') {                                      // sequence lines
+            const size_t e = line_end(i);
+            bases += payload(i, e);
+            memcpy(out + o, buf + i, e - i); o += e - i;
+            out[o++] = '\n';
+            i = std::min(len, e + 1);
+        }
+        if (i >= len) { fail(err, errlen, "FASTQ input ends inside a record (no '+' line)"); return -1; }
+        i = std::min(len, line_end(i) + 1);                                     // the '+' line
+        size_t qual = 0;
+        while (i < len && qual < bases) {                                       // quality lines
+            const size_t e = line_end(i);
+            qual += payload(i, e);
+            i = std::min(len, e + 1);
+        }
+        if (qual != bases) {
+            char m[160];
+            snprintf(m, sizeof m, "FASTQ record %llu: %zu quality characters for %zu bases (truncated file?)",
+                     (unsigned long long)rec + 1, qual, bases);
+            fail(err, errlen, m);
+            return -1;
+        }
+        rec++;
+    }
+    return (long)o;
+}
+
 }  // namespace
 
 int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out, char *err, size_t errlen, IngestOpts opts) {
     if (threads < 1) threads = 1;
     if (len == 0) return fail(err, errlen, "empty input");
-    if (buf[0] == '@') return fail(err, errlen, "FASTQ input is not supported (FASTA expected)");
+    if (buf[0] == '@') {
+        // header, sequence and '+' lines never grow: 2 bytes for every header of >= 2 (">\n" for "@\n")
+        char *fa = (char *)malloc(len + 2);
+        if (!fa) return fail(err, errlen, "out of memory");
+        const long fl = fastq_to_fasta(buf, len, fa, err, errlen);
+        const int rc = fl < 0 ? -1 : (fl == 0 ? fail(err, errlen, "no FASTQ record") : pack_fasta_buffer(fa, (size_t)fl, threads, out, err, errlen, opts));
+        free(fa);
+        return rc;
+    }
     size_t nch = std::min<size_t>((size_t)threads, std::max<size_t>(1, len >> 16));
     std::vector<Chunk> ch(nch);
     for (size_t t = 0; t < nch; t++) {

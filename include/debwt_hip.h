@@ -85,8 +85,10 @@ int debwt_load_ascii(debwt_ctx *ctx, const char *seq, const uint64_t *reclen, ui
 
 /* FASTA ingest (replaces the reference's single-threaded kseq.h + zlib reader, src/collect#$.c:34-90): the file is
  * mapped (gzip: inflated), parsed and packed by `threads` host threads (the reference's -t) into the text format
- * above.  Characters other than ACGTacgt and white space, sequence before the first header, FASTQ input and records of
- * 32 bases or fewer (src/collect#$.c:41-45) are errors.  debwt_pack_fasta is host-only (no GPU needed);
+ * above.  FASTQ (first byte '@') is read as the reference's reader reads it (src/kseq.h:177-201: sequence lines up to the
+ * '+' line, as many quality characters as bases; the qualities are dropped).  Characters other than ACGTacgt and white
+ * space, sequence before the first header, a quality string of another length than its sequence and records of 32 bases
+ * or fewer (src/collect#$.c:41-45) are errors.  debwt_pack_fasta is host-only (no GPU needed);
  * debwt_load_fasta = debwt_pack_fasta + debwt_load_text with the packed copy owned by ctx. */
 typedef struct {
     uint64_t *words;      /* ((n + 63) >> 5) + 2 words */

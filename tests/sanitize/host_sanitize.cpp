@@ -101,7 +101,29 @@ int main() {
         CHECK(p.n == q.n && !memcmp(p.words, q.words, p.nwords * 8));
         free_packed_text(&p); free_packed_text(&q);
     }
-    for (const char *bad : {"ACGT\n", ">a\nACGTACGT\n", ">a\nACGTXACGTACGTACGTACGTACGTACGTACGTACGTACGT\n", "@r\nACGT\n+\nIIII\n", "", ">only header\n"}) {
+    {   // FASTQ (src/kseq.h:177-201): multi-line sequence and quality, quality lines that start with '@', '>' or '+'
+        std::string fq;
+        for (size_t r = 0; r < recs.size(); r++) {
+            fq += "@read" + std::to_string(r) + "\n";
+            for (size_t i = 0; i < recs[r].size(); i += 61) fq += recs[r].substr(i, 61) + "\n";
+            fq += r % 2 ? "+read\n" : "+\n";
+            std::string q(recs[r].size(), 'I');
+            q[0] = "@>+"[r % 3];
+            for (size_t i = 0; i < q.size(); i += 61) fq += q.substr(i, 61) + (r % 5 ? "\n" : "\r\n");
+        }
+        for (int threads : {1, 3, 8}) {
+            PackedText p{};
+            CHECK(pack_fasta_buffer(fq.data(), fq.size(), threads, &p, err, sizeof err) == 0);
+            CHECK(p.n == ref.n && p.nrec == ref.nrec && !memcmp(p.words, ref.words, ref.nwords * 8));
+            free_packed_text(&p);
+        }
+        PackedText p{};
+        std::string cut = fq.substr(0, fq.size() - 5);                                     // quality string cut short
+        CHECK(pack_fasta_buffer(cut.data(), cut.size(), 2, &p, err, sizeof err) != 0);
+        cut = fq.substr(0, fq.find('+'));                                                  // no '+' line
+        CHECK(pack_fasta_buffer(cut.data(), cut.size(), 2, &p, err, sizeof err) != 0);
+    }
+    for (const char *bad : {"ACGT\n", ">a\nACGTACGT\n", ">a\nACGTXACGTACGTACGTACGTACGTACGTACGTACGTACGT\n", "@r\nACGT\n+\nIIII\n", "@\n", "@r\nACGT", "", ">only header\n"}) {
         PackedText p{};
         CHECK(pack_fasta_buffer(bad, strlen(bad), 2, &p, err, sizeof err) != 0);
     }

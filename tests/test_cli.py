@@ -71,6 +71,31 @@ def test_cli_gzip_input(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_fastq_input_equals_reference_files(tmp_path):
+    """FASTQ, which the reference's reader takes too (src/kseq.h:177-201): the 20,000-read golden collection written as
+    a gzipped FASTQ (qualities with '@' / '>' line starts) gives the reference's OUT, OUT.# and OUT.$ -- and, being 20,000
+    records, goes through the special-region module on the device."""
+    import gzip
+    import hashlib
+    from conftest import golden_records
+    assert _have_cli()
+    entry = next(e for e in golden_manifest() if e["name"] == "reads_20000" and e["k"] == 32)
+    recs = golden_records(entry)
+    fq = tmp_path / "reads.fq.gz"
+    asc = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with gzip.open(fq, "wb", compresslevel=1) as g:
+        for i, r in enumerate(recs):
+            q = bytearray(b"I" * len(r))
+            q[0] = b"@>+I"[i % 4]
+            g.write(b"@r%d\n" % i + asc[r].tobytes() + b"\n+\n" + bytes(q) + b"\n")
+    out = str(tmp_path / "OUT")
+    r = subprocess.run([CLI, "-o", out, "-t", "4", str(fq)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for ext, key in (("", "bwt"), (".#", "hash"), (".$", "dollar")):
+        assert hashlib.sha256(open(out + ext, "rb").read()).hexdigest() == entry["sha256"][key], ext
+
+
+@pytest.mark.gpu
 def test_cli_iupac_option(tmp_path):
     """A FASTA with N runs: refused as the reference's reader refuses it, accepted with --iupac, and then the BWT is the
     BWT of the text the ingest produced (same seed through the API)."""

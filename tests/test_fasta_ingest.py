@@ -79,7 +79,10 @@ def test_pack_fasta_headers_longer_than_a_chunk(tmp_path):
     (b">a\nACGTNACGT" + b"A" * 40 + b"\n", "not one of ACGTacgt"),
     (b"ACGT\n>a\n" + b"A" * 40 + b"\n", "before the first header"),
     (b">a\n" + b"A" * 32 + b"\n", "Length <= 32"),
-    (b"@r\nACGT\n+\nIIII\n", "FASTQ"),
+    (b"@r\nACGT\n+\nIIII\n", "Length <= 32"),                                       # FASTQ is read; 4 bases are too few
+    (b"@r\n" + b"A" * 40 + b"\n+\n" + b"I" * 39 + b"\n", "quality characters"),      # truncated quality string
+    (b"@r\n" + b"A" * 40 + b"\n", "no '+' line"),
+    (b"@r\n" + b"A" * 40 + b"\n+\n" + b"I" * 40 + b"\nACGT\n", "does not start with '@'"),
     (b"", "empty"),
 ])
 def test_pack_fasta_errors(tmp_path, content, msg):
@@ -195,3 +198,59 @@ def test_pack_fasta_line_widths_around_the_vector_block(tmp_path, recs, width, n
     _write(p, sub, width=width)
     for threads in (1, 5):
         _check(p, sub, threads)
+
+
+def _write_fastq(path, recs, width=0, crlf=False, gz=False, lower=False, nasty_quals=True, blank=False):
+    """FASTQ as the reference's reader takes it (src/kseq.h:177-201): '@' header, sequence on one or several lines, a
+    '+' line (with or without the name repeated), as many quality characters as bases -- quality lines may start with
+    '@' or '>' (both are legal quality characters)."""
+    eol = b"\r\n" if crlf else b"\n"
+    op = gzip.open if gz else open
+    rng = np.random.default_rng(9)
+    with op(path, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b"@read%d/1 length=%d" % (i, len(r)) + eol)
+            s = bytes(ASC[c] for c in r)
+            if lower and i % 2:
+                s = s.lower()
+            w = width or len(s)
+            for a in range(0, len(s), w):
+                f.write(s[a:a + w] + eol)
+            f.write((b"+read%d/1" % i if i % 2 else b"+") + eol)
+            q = bytes(rng.integers(33, 74, size=len(s)).astype(np.uint8))
+            if nasty_quals:
+                q = (b"@" if i % 3 == 0 else b">" if i % 3 == 1 else b"+") + q[1:]
+            for a in range(0, len(q), w):
+                f.write(q[a:a + w] + eol)
+            if blank and i % 5 == 0:
+                f.write(eol)
+
+
+@pytest.mark.parametrize("threads", [1, 4, 16])
+@pytest.mark.parametrize("shape", ["plain", "multiline", "crlf", "gz", "lower", "blank"])
+def test_pack_fastq_matches_numpy_packer(tmp_path, threads, shape):
+    """FASTQ input (reads: the collections the special-region module on the device exists for): same packed text as the
+    numpy packer gives for the sequences, qualities dropped."""
+    rng = np.random.default_rng(12)
+    recs = [rng.integers(0, 4, size=int(rng.integers(33, 400))).astype(np.uint8) for _ in range(3000)]
+    p = str(tmp_path / ("r.fq.gz" if shape == "gz" else "r.fq"))
+    kw = {"plain": {}, "multiline": {"width": 37}, "crlf": {"crlf": True, "width": 50}, "gz": {"gz": True},
+          "lower": {"lower": True}, "blank": {"blank": True}}[shape]
+    _write_fastq(p, recs, **kw)
+    _check(p, recs, threads)
+
+
+def test_pack_fastq_with_ambiguity_letters(tmp_path):
+    rng = np.random.default_rng(13)
+    recs = [rng.integers(0, 4, size=150).astype(np.uint8) for _ in range(50)]
+    p = str(tmp_path / "n.fq")
+    _write_fastq(p, recs)
+    data = bytearray(open(p, "rb").read())
+    pos = data.index(b"\n") + 10                       # an N inside the first read
+    data[pos] = ord("N")
+    open(p, "wb").write(bytes(data))
+    with pytest.raises(api.DebwtError):
+        api.pack_fasta(p, 2)
+    a = api.pack_fasta(p, 1, iupac_seed=5)
+    b = api.pack_fasta(p, 8, iupac_seed=5)
+    assert a[1] == b[1] and np.array_equal(a[0], b[0])
