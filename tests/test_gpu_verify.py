@@ -148,6 +148,7 @@ def test_config3_config4_collections_on_one_gpu(api, workload):
 
 @pytest.mark.parametrize("devices,case,k,cap,tune", [([0, 0], "pan", 32, 0, 0), ([0, 0, 0], "chrom", 24, 150_000, 0),
                                                      ([0] * 8, "many", 32, 0, 0), ([0] * 5, "pan", 20, 60_000, 0),
+                                                     ([0, 0, 0], "reads", 32, 0, 0), ([0, 0], "reads", 24, 40_000, 0),
                                                      ([0], "pan", 32, 0, 0), ([0, 0, 0], "pan", 32, 0, 32)])
 def test_multi_gpu_host_from_one_process(api, oracle, devices, case, k, cap, tune, monkeypatch):
     """debwt_multi_build: one host thread per shard, exchanges as device-to-device copies -- here with all shards on
@@ -155,6 +156,7 @@ def test_multi_gpu_host_from_one_process(api, oracle, devices, case, k, cap, tun
     exchange rounds per shard where a range cap is set, against the oracle; then the device inverse BWT."""
     from debwt_amd import synth
     recs = {"pan": lambda: synth.pan_genome(300_000, 3), "many": lambda: synth.pan_genome(20_000, 9, seed=5),
+            "reads": lambda: synth.read_set(3000, 60, 300, 200_000, seed=11),      # special-region module on the device in every shard
             "chrom": lambda: synth.chromosomes(2_000_000, 4)}[case]()
     ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), k)
     m = api.MultiDeBWT(devices, k=k, tune=tune)               # tune 32: blue entries placed through block cursors

@@ -58,6 +58,8 @@ WORKER = textwrap.dedent("""
         recs = synth.pan_genome(300_000, 3)
     elif case == "many":
         recs = synth.pan_genome(20_000, 9, seed=5)
+    elif case == "reads":                                 # 3000 records: the special-region module runs on the device
+        recs = synth.read_set(3000, 60, 300, 200_000, seed=11)
     else:
         recs = synth.chromosomes(2_000_000, 4)
     n = sum(len(r) for r in recs) + len(recs)
@@ -80,7 +82,8 @@ WORKER = textwrap.dedent("""
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["scan", "exchange", "rescan", "auto"])
 @pytest.mark.parametrize("world,case,k,cap", [(2, "pan", 32, 0), (3, "pan", 20, 0), (2, "many", 32, 0), (4, "chrom", 32, 0),
-                                              (2, "pan", 32, 100_000), (3, "chrom", 24, 150_000), (4, "many", 32, 8192)])
+                                              (2, "pan", 32, 100_000), (3, "chrom", 24, 150_000), (4, "many", 32, 8192),
+                                              (3, "reads", 32, 0), (2, "reads", 20, 50_000)])
 def test_sharded_build_equals_oracle(tmp_path, oracle, world, case, k, mode, cap):
     from debwt_amd import synth
     script = tmp_path / "worker.py"
@@ -95,6 +98,7 @@ def test_sharded_build_equals_oracle(tmp_path, oracle, world, case, k, mode, cap
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     recs = {"pan": lambda: synth.pan_genome(300_000, 3), "many": lambda: synth.pan_genome(20_000, 9, seed=5),
+            "reads": lambda: synth.read_set(3000, 60, 300, 200_000, seed=11),
             "chrom": lambda: synth.chromosomes(2_000_000, 4)}[case]()
     ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), k)
     z = np.load(out)
