@@ -132,6 +132,8 @@ def measure_link(device, mib_per_peer=1024, reps=2):
     if world < 2:
         return None
     dev = device if _on_device() else torch.device("cpu")
+    on_gpu = torch.device(device).type == "cuda"                # gloo tests may run it on host tensors
+    sync = (lambda: torch.cuda.synchronize(device)) if on_gpu else (lambda: None)
     per = (mib_per_peer << 20) // 8
     src = torch.empty(per * world, dtype=torch.int64, device=device)
     dst = torch.empty(per * world, dtype=torch.int64, device=device)
@@ -139,11 +141,11 @@ def measure_link(device, mib_per_peer=1024, reps=2):
     counts = [per] * world
     times = []
     for _ in range(reps + 1):
-        torch.cuda.synchronize(device)
+        sync()
         dist.barrier()
         t0 = time.perf_counter()
         _all_to_all(dst, src, counts, counts)
-        torch.cuda.synchronize(device)
+        sync()
         times.append(time.perf_counter() - t0)
     ok = all(int(dst[r * per]) == r + 1 and int(dst[(r + 1) * per - 1]) == r + 1 for r in range(world))
     best = min(times[1:])
@@ -173,7 +175,8 @@ def measure_link(device, mib_per_peer=1024, reps=2):
         except Exception as e:          # noqa: BLE001 -- a probe: report, do not fail the build
             res["message_above_1GiB_intact_between_peers"] = f"probe failed: {e}"
     del src, dst
-    torch.cuda.empty_cache()
+    if on_gpu:
+        torch.cuda.empty_cache()
     if not os.environ.get("DEBWT_LINK_GBYTES_PER_S") and _on_device():
         LINK_GBYTES_PER_S = per_peer
         res["fed_to_cost_model"] = True

@@ -121,6 +121,9 @@ SHARD_WORKER = textwrap.dedent("""
     counts = [int(x) for x in SH._all_gather_small([sp.numel()])[:, 0]]
     cat, tot = SH._all_gather_var(ws, "sp", sp, sp.numel(), counts)
     assert tot == sum(counts) and (cat[:tot].numpy() == np.concatenate([np.full(7 * (r + 1), r) for r in range(world)])).all()
+    # the link probe of bench.py (N > 1): an all_to_all of 1 MiB per peer in calls of P2P_MAX bytes, content checked
+    lp = SH.measure_link(torch.device("cpu"), mib_per_peer=1, reps=1)
+    assert lp["content_ok"] and lp["gbytes_per_s_per_peer"] > 0 and lp["fed_to_cost_model"] is False, lp
     open(os.path.join(sys.argv[1], f"shard{rank}.json"), "w").write(json.dumps(
         {"rank": rank, "rounds": rounds, "keys": int(len(mine)), "sum": int(mine.sum()), "sent": int(len(keys)), "sent_sum": int(keys.sum())}))
     D.finalize()
