@@ -113,6 +113,13 @@ def cpu_reference(codes, k, threads):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def emit_line(line):
+    """The one JSON line, object and newline in a single write (print() issues two: another process on the same pipe can
+    get in between)."""
+    sys.stdout.flush()
+    os.write(1, (json.dumps(line) + "\n").encode())
+
+
 def launch_ranks(n_ranks):
     """`python bench.py --gpus N` run directly (no launcher, WORLD_SIZE unset): start the N ranks as CHILD processes
     of this one -- `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` -- before anything here
@@ -128,14 +135,24 @@ def launch_ranks(n_ranks):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for ln in p.stdout:
-        is_line = False
-        if ln.startswith("{"):
+        # the ranks share one pipe: another rank's output (gloo prints its connection messages to stdout in pieces) may
+        # stand in front of rank 0's object or between it and its newline: take the object from where it starts to where it ends
+        at = ln.find('{"metric"')
+        obj, end = None, 0
+        if at >= 0:
             try:
-                is_line = "metric" in json.loads(ln)
+                obj, end = json.JSONDecoder().raw_decode(ln[at:])
             except ValueError:
-                pass
-        (sys.stdout if is_line else sys.stderr).write(ln)
-        (sys.stdout if is_line else sys.stderr).flush()
+                obj = None
+        if obj is not None:
+            rest = ln[:at] + ln[at + end:]
+            sys.stdout.write(ln[at:at + end] + "\n")
+            sys.stdout.flush()
+            if rest.strip():
+                sys.stderr.write(rest if rest.endswith("\n") else rest + "\n")
+        else:
+            sys.stderr.write(ln)
+        sys.stderr.flush()
     return p.wait()
 
 
@@ -153,6 +170,7 @@ def main():
                     help="host-to-host steps (N = 1; load + build + fetch, mean over them); default = --steps, 0 = skip")
     ap.add_argument("--cpu-configs", action="store_true",
                     help="also time the reference on the whole chr1_250M collection (BASELINE configs[1]; minutes of CPU)")
+    ap.add_argument("--other-mode-timeout", type=float, default=180.0, help=argparse.SUPPRESS)
     ap.add_argument("--no-other-mode", action="store_true",
                     help="N>1 with --mode auto: do not also time the key path the cost model did not choose")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bases of record 0 given to the reference")
@@ -179,7 +197,7 @@ def main():
         D.init(backend="gloo")
         total = D.sum_over_ranks(1)
         if rank == 0:
-            print(json.dumps({"metric": METRIC, "probe": True, "n_gpus": args.gpus, "ranks_joined": int(total)}), flush=True)
+            emit_line({"metric": METRIC, "probe": True, "n_gpus": args.gpus, "ranks_joined": int(total)})
         else:
             print(f"rank {rank} joined", flush=True)
         D.finalize()
@@ -282,25 +300,6 @@ def main():
                      "hash_rows": int(len(hrows)), "dollar_row": int(drow)}
             if hasattr(d, "verify_device"):
                 check.update(d.verify_device())
-    # N > 1, --mode auto: the key path the cost model did NOT choose, timed the same way over a few steps, so that a
-    # scaling run answers "exchange or rescan" by measurement (collective: every rank runs it)
-    key_modes = None
-    if sharded and world > 1 and args.mode == "auto" and not args.no_other_mode:
-        chosen = acc["info"].get("keys", "rescan")
-        other = "exchange" if chosen == "rescan" else "rescan"
-        key_modes = {chosen: round(dt * 1e3 / args.steps, 3)}
-        try:
-            ws2 = SH.Workspace(d, device, mode=other)
-            ws2.buf = shard_ws.buf                            # the same exchange buffers
-            acc["timed"] = False
-            k2 = max(1, min(3, args.steps))
-            dt2 = D.timed_steps(lambda: SH.build_sharded(d, ws2), steps=k2, warmup=1, device_sync=torch.cuda.synchronize,
-                                tensor_device=tdev)
-            key_modes[other] = round(dt2 * 1e3 / k2, 3)
-            key_modes["note"] = (f"ms per build; '{chosen}' is the cost model's choice and the timed steps of `value`, "
-                                 f"'{other}' was timed over {k2} steps after one warm-up")
-        except Exception as e:                                # noqa: BLE001 -- extra information, never the result
-            key_modes[other] = f"failed: {e}"
     h2h = None
     h2h_reps = args.steps if args.h2h_reps < 0 else args.h2h_reps
     if world == 1 and not sharded and h2h_reps > 0:
@@ -331,6 +330,7 @@ def main():
                        "key ranges (prefix census of the text).  `value` above is the same build with the text resident in HBM"}
         out_words.free(); out_hash.free(); out_dollar.free()
 
+    line = None
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
         value = total_bases / (dt / args.steps) / 1e9
@@ -380,7 +380,7 @@ def main():
             line["exchange"] = {k_: round(v, 3) for k_, v in acc["xfer"].items()}
             line["exchange"].update(acc["info"])
             line["link_probe"] = link_probe
-            line["key_modes_ms"] = key_modes
+            line["key_modes_ms"] = None
         if args.gpus == 1 and not args.no_cpu_baseline:
             threads = SN.default_threads()
             ref = cpu_reference(syn.codes(0, 0, min(args.cpu_sample, int(syn._lens[0]))), args.k, threads)
@@ -397,7 +397,46 @@ def main():
             line["cpu_baseline_at_configs"] = at
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+
+    # N > 1, --mode auto: the key path the cost model did NOT choose, timed the same way over a few steps, so that a
+    # scaling run answers "exchange or rescan" by measurement (collective: every rank runs it).  It is extra information
+    # and must not be able to cost the run its result: rank 0 holds the finished line, and a watchdog on every rank ends
+    # the process with exit code 0 -- rank 0 printing the line first -- when the extra builds have not come back in time
+    # (a collective that hangs, a rank that failed alone and left the others waiting).
+    if sharded and world > 1 and args.mode == "auto" and not args.no_other_mode:
+        import threading
+        chosen = acc["info"].get("keys", "rescan")
+        other = "exchange" if chosen == "rescan" else "rescan"
+        key_modes = {chosen: round(dt * 1e3 / args.steps, 3)}
+        state = {"why": f"not back within {args.other_mode_timeout} s"}
+
+        def bail():
+            if rank == 0:
+                key_modes[other] = f"dropped: {state['why']}"
+                line["key_modes_ms"] = key_modes
+                emit_line(line)
+            os._exit(0)
+
+        timer = threading.Timer(args.other_mode_timeout, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            ws2 = SH.Workspace(d, device, mode=other)
+            ws2.buf = shard_ws.buf                            # the same exchange buffers
+            k2 = max(1, min(3, args.steps))
+            dt2 = D.timed_steps(lambda: SH.build_sharded(d, ws2), steps=k2, warmup=1, device_sync=torch.cuda.synchronize,
+                                tensor_device=tdev)
+            key_modes[other] = round(dt2 * 1e3 / k2, 3)
+            key_modes["note"] = (f"ms per build; '{chosen}' is the cost model's choice and the timed steps of `value`, "
+                                 f"'{other}' was timed over {k2} steps after one warm-up")
+            timer.cancel()
+        except Exception as e:                                # noqa: BLE001
+            state["why"] = f"rank {rank} failed: {e}"
+            threading.Event().wait()                          # the other ranks wait in a collective: the watchdogs end the run
+        if rank == 0:
+            line["key_modes_ms"] = key_modes
+    if rank == 0:
+        emit_line(line)
     d.close()
     text.free()
     D.finalize()

@@ -207,6 +207,16 @@ def test_bench_two_ranks_started_by_bench_itself_gloo():
     assert all(isinstance(j["key_modes_ms"][m], float) for m in ("exchange", "rescan")), j["key_modes_ms"]
 
 
+def test_bench_extra_key_mode_cannot_cost_the_result():
+    """The second key path of --mode auto is extra information: when it does not come back in time (here: a watchdog of
+    a millisecond) every rank leaves with exit code 0 and rank 0 has printed the finished line first."""
+    j = _run_bench_direct(["--gpus", "2", "--backend", "gloo", "--workload", "ecoli_4.6M", "--steps", "1", "--warmup", "1",
+                           "--no-cpu-baseline", "--other-mode-timeout", "0.001"])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["check"]["inverse_bwt_ok"], j
+    dropped = [v for v in j["key_modes_ms"].values() if isinstance(v, str) and v.startswith("dropped")]
+    assert len(dropped) == 1, j["key_modes_ms"]
+
+
 def test_bench_two_ranks_started_by_bench_itself_rccl():
     """The same over RCCL when the box has two GPUs (the driver's 8-GPU node; skipped on a one-GPU box)."""
     import torch
