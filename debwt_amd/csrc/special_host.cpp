@@ -154,9 +154,9 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
     }
     lap("sort by key");
     // runs of equal keys: true suffix order inside each (independent of each other)
-    std::vector<uint64_t> runs;                      // starts of the runs of length > 1
+    std::vector<std::pair<uint64_t, uint64_t>> runs;       // [start, end) of the runs of length > 1
     {
-        std::vector<std::vector<uint64_t>> part(nchunks);       // a chunk lists the runs that START inside it
+        std::vector<std::vector<std::pair<uint64_t, uint64_t>>> part(nchunks);   // a chunk lists the runs that START inside it
         parallel_chunks(nt, nchunks, [&](uint64_t c) {
             uint64_t i = cut(NS, c);
             const uint64_t end = cut(NS, c + 1);
@@ -164,7 +164,7 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
             while (i < end) {
                 uint64_t j = i + 1;
                 while (j < NS && items[j].key == items[i].key) j++;
-                if (j - i > 1) part[c].push_back(i);
+                if (j - i > 1) part[c].push_back({i, j});
                 i = j;
             }
         });
@@ -178,14 +178,14 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
         if (same_offset && !enda && !endb && a.next != b.next) return a.next < b.next;
         return a.pos != b.pos && T.less(a.pos, a.rec, b.pos, b.rec);
     };
-    auto run_end = [&](uint64_t i) { uint64_t j = i + 1; while (j < NS && items[j].key == items[i].key) j++; return j; };
     // long runs first, each on all threads (pieces sorted, then merged pairwise): the suffixes a base or two before
-    // their separator share their key with a large part of the collection
+    // their separator share their key with a large part of the collection.  (The run ends were found before any thread
+    // moves an item: looking for them while other runs are being sorted would read items another thread is swapping.)
     constexpr uint64_t LONG_RUN = 1u << 15;
-    std::vector<uint64_t> short_runs;
-    for (uint64_t i : runs) {
-        const uint64_t j = run_end(i), len = j - i;
-        if (nt == 1 || len < LONG_RUN) { short_runs.push_back(i); continue; }
+    std::vector<std::pair<uint64_t, uint64_t>> short_runs;
+    for (const auto &run : runs) {
+        const uint64_t i = run.first, len = run.second - run.first;
+        if (nt == 1 || len < LONG_RUN) { short_runs.push_back(run); continue; }
         const uint64_t pieces = std::min<uint64_t>((uint64_t)nt * 2, len / 4096);
         auto pcut = [&](uint64_t c) { return i + len / pieces * c + std::min<uint64_t>(c, len % pieces); };
         parallel_chunks(nt, pieces, [&](uint64_t c) { std::sort(items.begin() + pcut(c), items.begin() + pcut(c + 1), by_suffix); });
@@ -201,7 +201,7 @@ void build_special_tables(const uint64_t *words, uint64_t n, const uint64_t *sep
     parallel_chunks(nt, short_runs.empty() ? 0 : rchunks, [&](uint64_t c) {
         const uint64_t r0 = short_runs.size() / rchunks * c + std::min<uint64_t>(c, short_runs.size() % rchunks);
         const uint64_t r1 = short_runs.size() / rchunks * (c + 1) + std::min<uint64_t>(c + 1, short_runs.size() % rchunks);
-        for (uint64_t r = r0; r < r1; r++) std::sort(items.begin() + short_runs[r], items.begin() + run_end(short_runs[r]), by_suffix);
+        for (uint64_t r = r0; r < r1; r++) std::sort(items.begin() + short_runs[r].first, items.begin() + short_runs[r].second, by_suffix);
     });
     lap("tie runs");
     std::vector<uint64_t> order(NS), orec(NS);

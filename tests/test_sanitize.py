@@ -20,5 +20,11 @@ def test_host_code_is_clean_under_asan_ubsan():
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and "0 failures" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
     assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr
+    # ThreadSanitizer over the threaded host code (it found the one race this code had: run ends looked for while other
+    # runs were being sorted, special_host.cpp)
+    r = subprocess.run(["make", "-C", SAN, "host_sanitize_tsan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([os.path.join(SAN, "host_sanitize_tsan")], cwd=SAN, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 failures" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
     r = subprocess.run(["sh", "cli_args.sh"], cwd=SAN, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "cli_args: ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
