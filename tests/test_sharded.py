@@ -86,6 +86,8 @@ WORKER = textwrap.dedent("""
                                               (3, "reads", 32, 0), (2, "reads", 20, 50_000)])
 def test_sharded_build_equals_oracle(tmp_path, oracle, world, case, k, mode, cap):
     from debwt_amd import synth
+    if case == "reads" and mode in ("scan", "auto"):
+        pytest.skip("the many-record collection runs in the two key modes only (suite time)")
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / "res.npz")
