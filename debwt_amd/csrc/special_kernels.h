@@ -125,31 +125,35 @@ __global__ void k_sx_rank_of(const u32 *__restrict__ ord, u64 N, u32 *__restrict
 // ---- 2. the special suffixes in suffix order ------------------------------------------------------------------------
 // item i = record i / K, offset d = K-1 - i % K (the order the reference enumerates them, src/collect#$.c:118-131)
 
-__global__ void k_it_pass1(const u32 *__restrict__ rank, u64 N, int K, u64 NS, int bR, int bP, u64 *__restrict__ key) {
+// first sort key of every item, and its padded key once for all passes: in enumeration order the separator positions and
+// the text windows are read in sequence; the passes then fetch one word per item instead of three scattered ones
+__global__ void k_it_pass1(SxText T, const u32 *__restrict__ rank, u64 NS, int bR, int bP, u64 *__restrict__ key,
+                           u64 *__restrict__ ikey) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NS) return;
-    const u64 r = i / (u64)K;
-    const u64 e = i - r * (u64)K;                              // K-1-d: a later separator first
-    const u64 follower = r + 1 < N ? (u64)rank[r + 1] : N;     // '$' ranks above every '#'
+    const u64 r = i / (u64)T.K;
+    const u64 e = i - r * (u64)T.K;                            // K-1-d: a later separator first
+    const u64 follower = r + 1 < T.nrec ? (u64)rank[r + 1] : T.nrec;     // '$' ranks above every '#'
     key[i] = (((e << bR) | follower) << bP) | i;
+    ikey[i] = T.item_key(r, T.K - 1 - (int)e);
 }
 // the next pass's key bits above the item id, in the order the pass before left: low / high 31 bits of the padded key
-__global__ void k_it_rekey(SxText T, const u64 *__restrict__ src, u64 NS, int hi, int bP, u64 *__restrict__ dst) {
+__global__ void k_it_rekey(const u64 *__restrict__ ikey, const u64 *__restrict__ src, u64 NS, int hi, int bP,
+                           u64 *__restrict__ dst) {
     const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= NS) return;
-    const u64 i = src[q] & ((1ull << bP) - 1ull), r = i / (u64)T.K;
-    const int d = T.K - 1 - (int)(i - r * (u64)T.K);
-    const u64 k62 = T.item_key(r, d);
+    const u64 i = src[q] & ((1ull << bP) - 1ull);
+    const u64 k62 = ikey[i];
     dst[q] = ((hi ? (k62 >> 31) : (k62 & 0x7FFFFFFFull)) << bP) | i;
 }
-__global__ void k_it_out(SxText T, const u64 *__restrict__ sorted, int bP, u64 NS, u64 *__restrict__ spkey,
-                         u8 *__restrict__ spchr, u64 *__restrict__ sppos, u32 *__restrict__ sprec) {
+__global__ void k_it_out(SxText T, const u64 *__restrict__ ikey, const u64 *__restrict__ sorted, int bP, u64 NS,
+                         u64 *__restrict__ spkey, u8 *__restrict__ spchr, u64 *__restrict__ sppos, u32 *__restrict__ sprec) {
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= NS) return;
     const u64 i = sorted[s] & ((1ull << bP) - 1ull), r = i / (u64)T.K;
     const int d = T.K - 1 - (int)(i - r * (u64)T.K);
     const u64 p = T.sep[r] - (u64)d;
-    spkey[s] = T.item_key(r, d);
+    spkey[s] = ikey[i];
     spchr[s] = (u8)text_symbol(T.text, p - 1);                // always a base: records are longer than K
     sppos[s] = p;
     sprec[s] = (u32)r;
@@ -159,8 +163,9 @@ __global__ void k_it_out(SxText T, const u64 *__restrict__ sorted, int bP, u64 N
 
 // equal K-windows with the separator of the same kind at the same offset (src/collect#$.c:603-634)
 struct SxBranchF {
-    SxText T; const u64 *sppos; const u32 *sprec; u32 *grp;
+    SxText T; const u64 *sppos; const u32 *sprec; const u64 *spkey; u8 *head; u32 *grp;
     __device__ bool same(u64 a, u64 b) const {
+        if (spkey[a] != spkey[b]) return false;                // equal windows have equal padded keys (read in sequence)
         const u64 pa = sppos[a], pb = sppos[b];
         const u64 ra = sprec[a], rb = sprec[b];
         const u64 da = T.sep[ra] - pa, db = T.sep[rb] - pb;
@@ -169,8 +174,8 @@ struct SxBranchF {
         const u64 keep = (~0ull << (64 - 2 * T.K)) & ~slot;
         return ((text_window(T.text, pa) ^ text_window(T.text, pb)) & keep) == 0;
     }
-    __device__ u32 count(u64 s) const { return (s == 0 || !same(s - 1, s)) ? 1u : 0u; }
-    __device__ u32 recount(u64 s) const { return count(s); }
+    __device__ u32 count(u64 s) const { const u32 h = (s == 0 || !same(s - 1, s)) ? 1u : 0u; head[s] = (u8)h; return h; }
+    __device__ u32 recount(u64 s) const { return head[s]; }
     __device__ void emit(u64 s, u32 off, u32 c) const { grp[s] = off + c - 1u; }
 };
 // a group whose members do not all continue with the same symbol K ahead is a branch (src/collect#$.c:540-593)
