@@ -55,6 +55,8 @@ struct debwt_ctx {
     DevBuf rs_rle, text, sepbits, sep, keysA, keysB, rs_counts, cp_counts, dk, dstart, mchar, head_keys, facts, facts_tmp,
         red, red_q, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
         hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist, dest_tab, qbounds, qcursor, qlist, qwave;
+    DevBuf brbits;              // the special branches as a bitmap over the text positions (collections of many records)
+    bool branch_bitmap = false;
     DevBuf sx, sppos, sprec, tail_d;   // special-region module on the device: scratch arena, positions / records of the sorted items, tail facts
     bool special_dev = false;   // the tables of this build were made on the device (spkey / spchr / branch / head_keys / tail_d)
     u64 nbranch = 0;            // special branches (specialBranchNum)
@@ -250,7 +252,7 @@ static std::vector<DevBuf *> all_buffers(debwt_ctx *c) {
             &c->branch, &c->pflag, &c->spsym, &c->spn, &c->bwt, &c->hmask, &c->hash_rows, &c->dollar,
             &c->large_q, &c->large_k0, &c->large_en, &c->rowsym, &c->momask, &c->mimask, &c->rbits, &c->rs_over, &c->rs_skew,
             &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
-            &c->sx, &c->sppos, &c->sprec, &c->tail_d,
+            &c->sx, &c->sppos, &c->sprec, &c->tail_d, &c->brbits,
             &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0,
             &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf, &c->vidx, &c->vtmp, &c->qlist, &c->qwave};
 }
@@ -531,6 +533,17 @@ static bool special_wants_device(const debwt_ctx *c) {
     return c->nrec < (1ull << 27) && c->NS < (1ull << 32) && 5 + bits_for(c->nrec) + bits_for(c->NS - 1) <= 64;
 }
 
+// the branch list (c->branch, c->nbranch) as a bitmap for the SP flags pass, where the special suffixes are many
+static int special_branch_bitmap(debwt_ctx *c) {
+    c->branch_bitmap = c->nbranch > 0 && c->NS >= (1ull << 14);
+    if (!c->branch_bitmap) return DEBWT_OK;
+    const size_t bw = (size_t)(c->n >> 6) + 3;
+    ENSURE(c, c->brbits, bw * 8);
+    HIPCHK(c, hipMemsetAsync(c->brbits.p, 0, bw * 8, c->stream));
+    k_set_sepbits<<<grid_for(c->nbranch, 256), 256, 0, c->stream>>>(c->branch.as<u64>(), c->nbranch, c->brbits.as<u64>());
+    return DEBWT_OK;
+}
+
 static int special_device_build(debwt_ctx *c) {
     const u64 N = c->nrec, NS = c->NS, n = c->n;
     const int K = c->K;
@@ -652,6 +665,7 @@ static int special_device_build(debwt_ctx *c) {
     k_heads_tails<<<grid(N), 256, 0, c->stream>>>(T, X, c->tail_d.as<u64>());
     if (!(r = lsd(X, Y, N, 0, 2 * K + 2))) return DEBWT_EDEVICE;
     HIPCHK(c, hipMemcpyAsync(c->head_keys.p, r, N * 8, hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = special_branch_bitmap(c))) return rc;
     if ((rc = sync_check(c))) return rc;
     c->special_dev = true;
     c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -757,6 +771,7 @@ static int sort_range(debwt_ctx *c, size_t i, u64 *imported) {
         HIPCHK(c, hipMemcpyAsync(c->spchr.p, sp.chr.data(), c->NS, hipMemcpyHostToDevice, c->stream));
         if (!sp.branch.empty())
             HIPCHK(c, hipMemcpyAsync(c->branch.p, sp.branch.data(), sp.branch.size() * 8, hipMemcpyHostToDevice, c->stream));
+        if ((rc = special_branch_bitmap(c))) return rc;
     }
     // special suffixes whose key lies in this range, and their rows among the context's instances
     u64 *d_bounds = nullptr;
@@ -1048,17 +1063,17 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
         k_sp_flags<2><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
             c->branch.as<u64>(), c->nbranch, c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
-            sp_block_ids(c));
+            sp_block_ids(c), c->branch_bitmap ? c->brbits.as<u64>() : nullptr);
     else if (ng && c->mzfilter)
         k_sp_flags<1><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
             c->branch.as<u64>(), c->nbranch, c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
-            sp_block_ids(c));
+            sp_block_ids(c), c->branch_bitmap ? c->brbits.as<u64>() : nullptr);
     else if (ng)
         k_sp_flags<0><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
             c->branch.as<u64>(), c->nbranch, c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
-            sp_block_ids(c));
+            sp_block_ids(c), c->branch_bitmap ? c->brbits.as<u64>() : nullptr);
     SpCountF fc{c->momask.as<u32>() + g0, c->mimask.as<u32>() + g0};
     if ((rc = cp_count2(c, fc, ng, cp_area(c, 0), 8, cp_area(c, 1), 10))) return rc;
     if ((rc = sync_check(c))) return rc;

@@ -672,7 +672,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_
                                                            const u32 *__restrict__ rbits, int pb,
                                                            const u64 *__restrict__ branch, u64 nbranch,
                                                            u32 *__restrict__ momask, u32 *__restrict__ mimask,
-                                                           u64 g0, u64 g1, SpBlockIds ids) {
+                                                           u64 g0, u64 g1, SpBlockIds ids, const u64 *__restrict__ brbits) {
     // block ids of the lane's multi-in positions until the wave knows where they go (a lane reads only its own 32 words)
     __shared__ u32 lq[DEBWT_BLOCK * 32];
     u64 g = g0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -788,8 +788,12 @@ __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_
         mi |= ((fl >> 1) & 1u) << t;
         if (ids.list && (fl & 2u)) lq[threadIdx.x * 32 + t] = q;
     }
-    // special module: multi-out iff listed in specialBranch (src/generateSP.c:612-624)
-    if (nbranch) {
+    // special module: multi-out iff listed in specialBranch (src/generateSP.c:612-624).  Collections of many records --
+    // a third of all positions of a read set are special, and millions of them branches -- carry the list as a bitmap over
+    // the text positions (one word beside the text word instead of a binary search per special position)
+    if (brbits) {
+        if (spec) mo |= (u32)sep_window(brbits, i0) & spec;
+    } else if (nbranch) {
         while (spec) {
             u32 t = (u32)__ffs(spec) - 1u;
             spec &= spec - 1u;
