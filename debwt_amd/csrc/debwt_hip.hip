@@ -556,7 +556,7 @@ static int special_device_build(debwt_ctx *c) {
     const size_t o_ord = take(N * 4), o_gid = take(N * 4), o_actA = take(N * 4), o_actB = take(N * 4), o_val = take(N * 8);
     const size_t o_recs = take(N * 4), o_vals = take(N * 8), o_gids = take(N * 4), o_ordv = take(N * 4);
     const size_t o_head = take((N + 1) * 4), o_stay = take(N), o_rank = take(N * 4);
-    const size_t o_grp = take(NS * 4), o_gflag = take(NS), o_headf = take(NS), o_ikey = take(NS * 8), o_bnd = take(64);
+    const size_t o_grp = take(NS * 4), o_gflag = take(NS), o_headf = take(NS), o_spd = take(NS), o_item = take(NS * 16), o_bnd = take(64);
     ENSURE(c, c->sx, off);
     ENSURE(c, c->sppos, NS * 8 + 64);
     ENSURE(c, c->sprec, NS * 4 + 64);
@@ -570,8 +570,8 @@ static int special_device_build(debwt_ctx *c) {
     u32 *headpos = (u32 *)(base + o_head), *rank = (u32 *)(base + o_rank);
     u8 *stay = base + o_stay;
     u32 *grp = (u32 *)(base + o_grp);
-    u8 *gflag = base + o_gflag, *headf = base + o_headf;
-    u64 *ikey = (u64 *)(base + o_ikey);
+    u8 *gflag = base + o_gflag, *headf = base + o_headf, *spd = base + o_spd;
+    ulonglong2 *item = (ulonglong2 *)(base + o_item);
     const SxText T{c->text.as<u64>(), c->sepbits.as<u64>(), c->sep.as<u64>(), n, N, K};
     auto grid = [](u64 m) { return grid_for(m, 256); };
     auto other = [&](u64 *p_) { return p_ == X ? Y : X; };
@@ -635,18 +635,18 @@ static int special_device_build(debwt_ctx *c) {
     const int bR = bits_for(N), bP = bits_for(NS - 1);
     u64 *r = nullptr;
     (void)o_bnd;
-    k_it_pass1<<<grid(NS), 256, 0, c->stream>>>(T, rank, NS, bR, bP, X, ikey);
+    k_it_pass1<<<grid(NS), 256, 0, c->stream>>>(T, rank, NS, bR, bP, X, item);
     if (!(r = lsd(X, Y, NS, bP, bP + 5 + bR))) return DEBWT_EDEVICE;
     for (int hi = 0; hi < 2; hi++) {
         u64 *o = other(r);
-        k_it_rekey<<<grid(NS), 256, 0, c->stream>>>(ikey, r, NS, hi, bP, o);
+        k_it_rekey<<<grid(NS), 256, 0, c->stream>>>(item, r, NS, hi, bP, o);
         if (!(r = lsd(o, other(o), NS, bP, bP + 31))) return DEBWT_EDEVICE;
     }
-    k_it_out<<<grid(NS), 256, 0, c->stream>>>(T, ikey, r, bP, NS, c->spkey.as<u64>(), c->spchr.as<u8>(), c->sppos.as<u64>(),
-                                              c->sprec.as<u32>());
+    k_it_out<<<grid(NS), 256, 0, c->stream>>>(T, item, r, bP, NS, c->spkey.as<u64>(), c->spchr.as<u8>(), c->sppos.as<u64>(),
+                                              c->sprec.as<u32>(), spd);
 
     // 3. special branches; head and tail nodes
-    SxBranchF fb{T, c->sppos.as<u64>(), c->sprec.as<u32>(), c->spkey.as<u64>(), headf, grp};
+    SxBranchF fb{T, c->sppos.as<u64>(), c->sprec.as<u32>(), c->spkey.as<u64>(), spd, headf, grp};
     if ((rc = cp_count(c, fb, NS, cp_area(c, 0), 20))) return rc;
     if ((rc = cp_emit(c, fb, NS, cp_area(c, 0)))) return rc;
     HIPCHK(c, hipMemsetAsync(gflag, 0, NS, c->stream));

@@ -127,49 +127,54 @@ __global__ void k_sx_rank_of(const u32 *__restrict__ ord, u64 N, u32 *__restrict
 
 // first sort key of every item, and its padded key once for all passes: in enumeration order the separator positions and
 // the text windows are read in sequence; the passes then fetch one word per item instead of three scattered ones
+// (item record: .x = padded key, .y = text position | BWT symbol << 62)
 __global__ void k_it_pass1(SxText T, const u32 *__restrict__ rank, u64 NS, int bR, int bP, u64 *__restrict__ key,
-                           u64 *__restrict__ ikey) {
+                           ulonglong2 *__restrict__ item) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NS) return;
     const u64 r = i / (u64)T.K;
     const u64 e = i - r * (u64)T.K;                            // K-1-d: a later separator first
     const u64 follower = r + 1 < T.nrec ? (u64)rank[r + 1] : T.nrec;     // '$' ranks above every '#'
     key[i] = (((e << bR) | follower) << bP) | i;
-    ikey[i] = T.item_key(r, T.K - 1 - (int)e);
+    const int d = T.K - 1 - (int)e;
+    const u64 p = T.sep[r] - (u64)d;
+    item[i] = make_ulonglong2(T.item_key(r, d), p | ((u64)text_symbol(T.text, p - 1) << 62));   // always a base before: records are longer than K
 }
 // the next pass's key bits above the item id, in the order the pass before left: low / high 31 bits of the padded key
-__global__ void k_it_rekey(const u64 *__restrict__ ikey, const u64 *__restrict__ src, u64 NS, int hi, int bP,
+__global__ void k_it_rekey(const ulonglong2 *__restrict__ item, const u64 *__restrict__ src, u64 NS, int hi, int bP,
                            u64 *__restrict__ dst) {
     const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= NS) return;
     const u64 i = src[q] & ((1ull << bP) - 1ull);
-    const u64 k62 = ikey[i];
+    const u64 k62 = item[i].x;
     dst[q] = ((hi ? (k62 >> 31) : (k62 & 0x7FFFFFFFull)) << bP) | i;
 }
-__global__ void k_it_out(SxText T, const u64 *__restrict__ ikey, const u64 *__restrict__ sorted, int bP, u64 NS,
-                         u64 *__restrict__ spkey, u8 *__restrict__ spchr, u64 *__restrict__ sppos, u32 *__restrict__ sprec) {
+__global__ void k_it_out(SxText T, const ulonglong2 *__restrict__ item, const u64 *__restrict__ sorted, int bP, u64 NS,
+                         u64 *__restrict__ spkey, u8 *__restrict__ spchr, u64 *__restrict__ sppos, u32 *__restrict__ sprec,
+                         u8 *__restrict__ spd) {
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= NS) return;
     const u64 i = sorted[s] & ((1ull << bP) - 1ull), r = i / (u64)T.K;
-    const int d = T.K - 1 - (int)(i - r * (u64)T.K);
-    const u64 p = T.sep[r] - (u64)d;
-    spkey[s] = ikey[i];
-    spchr[s] = (u8)text_symbol(T.text, p - 1);                // always a base: records are longer than K
-    sppos[s] = p;
+    const ulonglong2 it = item[i];                             // one 16-byte fetch per item
+    spkey[s] = it.x;
+    spchr[s] = (u8)(it.y >> 62);
+    sppos[s] = it.y & ((1ull << 62) - 1ull);
     sprec[s] = (u32)r;
+    spd[s] = (u8)(T.K - 1 - (int)(i - r * (u64)T.K));         // offset of the separator
 }
 
 // ---- 3. special branches, head and tail nodes -----------------------------------------------------------------------
 
 // equal K-windows with the separator of the same kind at the same offset (src/collect#$.c:603-634)
 struct SxBranchF {
-    SxText T; const u64 *sppos; const u32 *sprec; const u64 *spkey; u8 *head; u32 *grp;
+    SxText T; const u64 *sppos; const u32 *sprec; const u64 *spkey; const u8 *spd; u8 *head; u32 *grp;
     __device__ bool same(u64 a, u64 b) const {
-        if (spkey[a] != spkey[b]) return false;                // equal windows have equal padded keys (read in sequence)
-        const u64 pa = sppos[a], pb = sppos[b];
+        // equal windows have equal padded keys, separator offsets and kinds: all read in sequence, the text only then
+        if (spkey[a] != spkey[b]) return false;
+        const u64 da = spd[a], db = spd[b];
         const u64 ra = sprec[a], rb = sprec[b];
-        const u64 da = T.sep[ra] - pa, db = T.sep[rb] - pb;
         if (da != db || (ra == T.nrec - 1) != (rb == T.nrec - 1)) return false;
+        const u64 pa = sppos[a], pb = sppos[b];
         const u64 slot = 3ull << (2 * (31 - da));
         const u64 keep = (~0ull << (64 - 2 * T.K)) & ~slot;
         return ((text_window(T.text, pa) ^ text_window(T.text, pb)) & keep) == 0;
