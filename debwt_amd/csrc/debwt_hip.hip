@@ -526,11 +526,18 @@ static int bits_for(u64 v) { int b = 1; while (b < 64 && (v >> b)) b++; return b
 // Collections of many records build their special-region tables on the device: from 2^14 special suffixes on
 // (DEBWT_SPECIAL_DEVICE_MIN overrides; tests force either path), as long as the payload fields of its sorts hold the
 // record ranks and item places (2^27 records, 2^32 special suffixes -- beyond that the host threads take over).
-static bool special_wants_device(const debwt_ctx *c) {
+static bool special_wants_device(debwt_ctx *c) {
     const char *e = getenv("DEBWT_SPECIAL_DEVICE_MIN");
     const u64 dev_min = e ? strtoull(e, nullptr, 10) : (1ull << 14);
     if (c->NS < dev_min) return false;
-    return c->nrec < (1ull << 27) && c->NS < (1ull << 32) && 5 + bits_for(c->nrec) + bits_for(c->NS - 1) <= 64;
+    if (!(c->nrec < (1ull << 27) && c->NS < (1ull << 32) && 5 + bits_for(c->nrec) + bits_for(c->NS - 1) <= 64)) return false;
+    // its workspace (59 bytes per special suffix + 12 for their positions, ~60 per record) must fit beside what the build
+    // holds by now -- else the host threads build the tables, as for any collection before round 3
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    const u64 need = c->NS * 72 + c->nrec * 64 + (64ull << 20);
+    const u64 have = free_b + c->sx.cap + c->sppos.cap + c->sprec.cap + c->tail_d.cap;
+    return need + (have >> 4) < have;                          // and 1/16 of it stays free
 }
 
 // the branch list (c->branch, c->nbranch) as a bitmap for the SP flags pass, where the special suffixes are many
