@@ -28,7 +28,9 @@ class DebwtStats(ctypes.Structure):
             "ms_extract", "ms_sort", "ms_classify", "ms_sp", "ms_blue", "ms_assemble", "ms_total",
             "ms_host_special")] +
         [("radix_pass_launches", ctypes.c_uint32), ("radix_pass_ms", ctypes.c_float),
-         ("radix_pass_keys", ctypes.c_uint64), ("special_path", ctypes.c_uint32), ("special_threads", ctypes.c_uint32)])
+         ("radix_pass_keys", ctypes.c_uint64), ("special_path", ctypes.c_uint32), ("special_threads", ctypes.c_uint32),
+         ("sort_unfit_stretches", ctypes.c_uint64), ("sort_unfit_network", ctypes.c_uint64),
+         ("sort_over_stretches", ctypes.c_uint64)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -228,12 +228,13 @@ int sort_keys(debwt_ctx *c, u64 *a, u64 *b, u64 count, int key_bits, u64 **resul
     RadixWorkspace ws = radix_ws(c);
     hipError_t e = hipSuccess;
     const bool main = main_sort || record_passes;
+    const int net = (c->cfg.reserved & 32768) ? 32 : 0;     // bit 15: the bucket finish prefers the 4096-key network (tests)
     if (record_passes) {
-        *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo, &c->ev_pass[0][0], 16,
+        *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo | net, &c->ev_pass[0][0], 16,
                                  &c->n_pass_events, &e, text, sink);
         c->st.radix_pass_keys = count;
     } else {
-        *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo | (main ? 0 : 16), nullptr, 0,
+        *result = radix_sort_u64(c->stream, a, b, count, key_bits, ws, c->cfg.sort_algo | net | (main ? 0 : 16), nullptr, 0,
                                  nullptr, &e, text, sink);
     }
     if (e != hipSuccess) { c->err = std::string("radix sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
@@ -697,6 +698,7 @@ static int sort_begin(debwt_ctx *c) {
     ENSURE(c, c->pflag, maxM + 64);                      // classification byte per distinct key of a range
     ENSURE(c, c->mchar, c->Mctx + 64);
     c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0; c->Dsum = 0;
+    c->st.sort_unfit_stretches = c->st.sort_unfit_network = c->st.sort_over_stretches = 0;
     const size_t P = c->ranges.size();
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     // the keys (node << 2 | pred) are read off the text inside the first radix pass: no unsorted key array
@@ -758,7 +760,8 @@ static int sort_range(debwt_ctx *c, size_t i, u64 *imported) {
                   c->shared_hist ? c->range_hist.as<u32>() + i * radix_text_hist_stride() : nullptr, nullptr, 0};
     // the bucket finish of the sort counts the distinct keys of its tiles and the encoding follows tile by tile
     // (tune bit 8 = 256: separate count and emit passes over the sorted keys instead)
-    RleSink sink{c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase, c->rs_rle.p, &c->h_scalars[0], false};
+    RleSink sink{c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase, c->rs_rle.p, &c->h_scalars[0],
+                 &c->h_scalars[32], 0, false};
     if (imported && r.M < 2) c->sk = c->sort_a;
     else if ((rc = sort_keys(c, c->sort_a, c->sort_b, r.M, 2 * c->cfg.k, &c->sk, i == 0, imported ? nullptr : &ts, true,
                              (c->cfg.reserved & 256) ? nullptr : &sink))) return rc;
@@ -799,6 +802,10 @@ static int sort_range(debwt_ctx *c, size_t i, u64 *imported) {
     if (d_bounds) memcpy(&r.s0, &c->h_scalars[24], 8), memcpy(&r.s1, &c->h_scalars[26], 8);
     c->D = c->h_scalars[0];
     c->Dsum += c->D;
+    if (sink.done) {
+        c->st.sort_unfit_stretches += c->h_scalars[32]; c->st.sort_unfit_network += c->h_scalars[35];
+        c->st.sort_over_stretches += sink.n_over;
+    }
     if (r.s1 > r.s0)
         k_special_rows<<<grid_for(r.s1 - r.s0, 256), 256, 0, c->stream>>>(
             c->dk.as<u64>(), c->dstart.as<u32>(), c->D, r.M, c->spkey.as<u64>() + r.s0, r.s1 - r.s0,

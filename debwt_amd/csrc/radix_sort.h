@@ -86,6 +86,9 @@ struct RleSink {
     u64 *dk; u32 *dstart; u8 *mchar;   // out: distinct keys, their first rows, one symbol per row
     void *ws;                          // radix_rle_ws_bytes(n) bytes of device scratch
     u32 *h_total;                      // pinned host word: number of distinct keys, valid once the stream drained
+    u32 *h_ctr;                        // optional, 4 pinned host words: [0] stretches above a wave tile, [3] those of them
+                                       // left to the 4096-key network (valid once the stream drained)
+    u32 n_over;                        // out: stretches above 4096 keys, finished by all-HBM passes
     bool done;
 };
 size_t radix_rle_ws_bytes(u64 n);

@@ -1016,21 +1016,208 @@ __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ ke
 // marks the two or three tiles that overlap it: in a collection of many genomes, where a quarter of the wave tiles
 // are unfit, 70 % of all tiles ended up in the network, each re-sorting up to 4096 keys around a stretch of ~1500.
 // A stretch above 4096 keys goes to the list of the all-HBM path, as before.
-__global__ __launch_bounds__(256) void rs_local_unfit_kernel(u64 *__restrict__ keys, u64 n, const u64 *__restrict__ bnd,
-                                                             u32 nwtiles, const u32 *__restrict__ unfit,
-                                                             const u32 *__restrict__ nunfit, u32 *__restrict__ over,
-                                                             u32 over_cap) {
+//
+// How a stretch is sorted (RLU_CLASSIFY, the default): an unfit stretch is a repeat family's 16-mer in every genome of
+// the collection -- a thousand keys of which a few dozen are distinct -- between the small buckets of its neighbours, and
+// a comparison network (67,000 VALU instructions per wave for 4096 keys, whether or not the keys are equal) is the
+// wrong tool for that.  Instead: 256 evenly spaced keys of the stretch are sorted (one key per thread) and their
+// distinct values become splitters; every key finds its class by bisection over the splitters in LDS -- "equal to
+// splitter i" or "between splitters i-1 and i" -- and its place inside the class from the class counter (LDS atomic);
+// a scan of the class counts gives the class starts and the keys move there.  Keys that equal a splitter are in place
+// (any frequent key of the stretch is a splitter); the few keys between two splitters are ordered by counting ranks
+// inside their class.  ~60 VALU instructions per key instead of ~470.  A class between splitters that holds more than
+// RLU_GAP_MAX keys (a stretch without duplicates whose sample happened to be skewed) sends the stretch to the network.
+#ifndef RLU_CLASSIFY
+#define RLU_CLASSIFY 1
+#endif
+#define RLU_GAP_MAX 256u
+#ifndef RLU_WAVES_EU
+#define RLU_WAVES_EU 4                 // 128 VGPRs: four workgroups per CU, as the LDS footprint allows
+#endif
+#ifndef RLU_WAVES_EU_SMALL
+#define RLU_WAVES_EU_SMALL 7           // 72 VGPRs: seven workgroups of the 2048-key instance per CU
+#endif
+
+// sorts 256 keys ascending, one per thread of a 256-thread workgroup (bitonic: distances below 64 by lane shuffles, 64
+// and 128 through X)
+__device__ __forceinline__ u64 rlu_sort256(u64 v, u64 *X, const u32 tid) {
+#pragma unroll
+    for (int lk = 1; lk <= 8; lk++) {
+        const u32 kk = 1u << lk;
+#pragma unroll
+        for (int lj = lk - 1; lj >= 0; lj--) {
+            const u32 d = 1u << lj;
+            u64 p;
+            if (lj < 6) p = __shfl_xor(v, (int)d, 64);
+            else { X[tid] = v; __syncthreads(); p = X[tid ^ d]; __syncthreads(); }
+            const bool take_min = ((tid & d) == 0) == ((tid & kk) == 0);
+            const bool pless = p < v;
+            v = (take_min == pless) ? p : v;
+        }
+    }
+    return v;
+}
+
+#define RLU_NET_FLAG 0x80000000u        // list entry: the stretch is left to the network kernel
+
+#if RLU_CLASSIFY
+// KPT = 8: the stretches of up to 2048 keys (99 % of them in a collection of ten genomes: a wave tile's worth of small
+// buckets and one repeat family's bucket) with half the LDS and half the registers -- seven workgroups per CU instead of
+// four, and what these kernels run on is workgroups in flight; KPT = 16: the rest.
+template <int KPT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPT == 8 ? RLU_WAVES_EU_SMALL : RLU_WAVES_EU, KPT == 8 ? RLU_WAVES_EU_SMALL : RLU_WAVES_EU)))
+void rs_local_unfit_kernel(u64 *__restrict__ keys, u64 n, const u64 *__restrict__ bnd, u32 nwtiles, u32 *__restrict__ unfit,
+                           u32 *__restrict__ nunfit, u32 *__restrict__ over, u32 over_cap, u32 gap_max) {
+    constexpr int NT = 256;
+    constexpr u32 CAP = NT * KPT;
+    __shared__ u64 A[CAP + CAP / 16];
+    __shared__ u64 spl[NT];            // the sample, then its distinct values
+    __shared__ u32 ccnt[2 * NT];       // class 2 i: keys between splitters i - 1 and i; class 2 i + 1: keys equal to splitter i
+    __shared__ u32 wtmp[DEBWT_WAVES + 1];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 nu = nunfit[0];
+    for (u32 i = blockIdx.x; i < nu; i += gridDim.x) {
+        const u32 t = unfit[i];
+        if (t & RLU_NET_FLAG) continue;                               // flagged by the other instance: the network's
+        const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
+        const u64 cnt64 = e - s;
+        if (KPT == 8 ? cnt64 > CAP : cnt64 <= CAP / 2) continue;      // the other instance's
+        __syncthreads();                                              // A of the stretch before has been read
+        if (cnt64 > CAP) {
+            // often one long run of equal keys (a repeat family's k-mer in every genome): nothing to do when in order
+            u32 bad = 0;
+            for (u64 j = s + tid; j + 1 < e && !bad; j += NT) bad = keys[j] > keys[j + 1] ? 1u : 0u;
+            if (__syncthreads_or((int)bad) && tid == 0) {
+                const u32 idx = atomicAdd(&over[0], 1u);
+                if (idx < over_cap) {
+                    u64 *list = reinterpret_cast<u64 *>(over + 4);
+                    list[2 * idx] = s; list[2 * idx + 1] = cnt64;
+                }
+            }
+            continue;
+        }
+        const u32 cnt = (u32)cnt64;
+        for (u32 j = tid; j < CAP; j += NT) A[RL_PAD(j)] = j < cnt ? keys[s + j] : ~0ull;
+        __syncthreads();
+        // striped: key j of the stretch belongs to thread j % 256 (every thread holds cnt / 256 keys, whatever cnt is)
+        u64 kk[KPT];
+        u32 bad = 0;
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const u32 j = (u32)r * NT + tid;
+            kk[r] = A[RL_PAD(j)];                                     // (~0 behind the stretch)
+            if (j + 1 < cnt) bad |= kk[r] > A[RL_PAD(j + 1)] ? 1u : 0u;
+        }
+        if (!__syncthreads_or((int)bad)) continue;                    // in order already
+        // the sample: 256 evenly spaced keys (cnt > 1024, so they are different elements), sorted, distinct values kept
+        u64 smp = A[RL_PAD((u32)(((u64)tid * cnt) >> 8))];
+        smp = rlu_sort256(smp, spl, tid);
+        spl[tid] = smp; ccnt[tid] = 0; ccnt[tid + NT] = 0;
+        __syncthreads();
+        const bool head = tid == 0 || spl[tid - 1] != smp;
+        const u64 bm = __ballot(head);
+        if (lane == 0) wtmp[w] = (u32)__popcll(bm);
+        __syncthreads();                                              // every spl[tid - 1] has been read
+        u32 sbase = 0, U = 0;
+#pragma unroll
+        for (u32 x = 0; x < DEBWT_WAVES; x++) { const u32 c = wtmp[x]; sbase += x < w ? c : 0u; U += c; }
+        const u32 sidx = sbase + (u32)__popcll(bm & lanemask_lt());
+        if (head && sidx < NT - 1) spl[sidx] = smp;                  // sidx <= tid: the slots of later threads are untouched
+        if (U > NT - 1) U = NT - 1;                                   // 2 U + 1 classes fit the 512 counters
+        __syncthreads();
+        // class of every key and its place inside the class
+        u32 cr[KPT];                                                  // class << 16 | place in the class
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            cr[r] = 0xFFFFFFFFu;
+            if ((u32)r * NT + tid < cnt) {
+                const u64 key = kk[r];
+                u32 lo = 0;                                           // splitters below the key
+#pragma unroll
+                for (u32 step = NT / 2; step; step >>= 1) {
+                    const u32 c = lo + step;
+                    if (c <= U && spl[c - 1] < key) lo = c;
+                }
+                const u32 cls = 2u * lo + ((lo < U && spl[lo] == key) ? 1u : 0u);
+                cr[r] = (cls << 16) | atomicAdd(&ccnt[cls], 1u);
+            }
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);       // four searches in flight, not sixteen (registers)
+        }
+        __syncthreads();
+        // class starts: thread t scans the classes 2 t and 2 t + 1
+        const u32 v0 = ccnt[2 * tid], v1 = ccnt[2 * tid + 1];
+        u32 total;
+        const u32 cbase = block_scan_excl(v0 + v1, wtmp, &total);
+        if (__syncthreads_or((int)(v0 > gap_max))) {
+            // no duplicates to speak of and a skewed sample: the network's (the keys in HBM are untouched)
+            if (tid == 0) { unfit[i] = t | RLU_NET_FLAG; atomicAdd(nunfit + 3, 1u); }
+            continue;
+        }
+        ccnt[2 * tid] = cbase; ccnt[2 * tid + 1] = cbase + v0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KPT; r++)
+            if (cr[r] != 0xFFFFFFFFu) {
+                const u32 pos = ccnt[cr[r] >> 16] + (cr[r] & 0xFFFFu);
+                A[RL_PAD(pos)] = kk[r];
+                cr[r] = (cr[r] & 0xFFFF0000u) | pos;                  // class << 16 | position (< 4096)
+            }
+        __syncthreads();
+        // keys between two splitters: counting rank inside the class (equal keys keep the order they have there)
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const u32 cls = cr[r] >> 16, pos = cr[r] & 0xFFFFu;
+            u32 np = 0xFFFFFFFFu;
+            if (cr[r] != 0xFFFFFFFFu && !(cls & 1u)) {
+                const u32 st = ccnt[cls], en = ccnt[cls + 1];         // class cls + 1 (odd) always has a counter
+                if (en - st > 1) {
+                    const u64 key = kk[r];
+                    u32 less = 0;
+                    for (u32 y = st; y < en; y++) {
+                        const u64 ky = A[RL_PAD(y)];
+                        less += (ky < key || (ky == key && y < pos)) ? 1u : 0u;
+                    }
+                    np = st + less;
+                }
+            }
+            cr[r] = np;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KPT; r++)
+            if (cr[r] != 0xFFFFFFFFu) A[RL_PAD(cr[r])] = kk[r];
+        __syncthreads();
+        for (u32 j = tid; j < cnt; j += NT) keys[s + j] = A[RL_PAD(j)];
+    }
+}
+#endif
+
+// The 4096-key network over a stretch: every stretch of the list when RLU_CLASSIFY is off, else the ones the
+// classifying kernel flagged (and nothing at all -- one load per workgroup -- when it flagged none).
+__global__ __launch_bounds__(256) void rs_local_unfit_net_kernel(u64 *__restrict__ keys, u64 n, const u64 *__restrict__ bnd,
+                                                                 u32 nwtiles, u32 *__restrict__ unfit,
+                                                                 const u32 *__restrict__ nunfit, u32 *__restrict__ over,
+                                                                 u32 over_cap) {
     constexpr int KPT = 16, NT = 256;
     constexpr u32 CAP = NT * KPT;
     __shared__ u64 A[CAP + CAP / 16];
     const u32 tid = threadIdx.x;
-    const u32 nu = *nunfit;
+    const u32 nu = nunfit[0];
+    if (RLU_CLASSIFY && nunfit[3] == 0) return;
     for (u32 i = blockIdx.x; i < nu; i += gridDim.x) {
-        const u32 t = unfit[i];
+        u32 t = unfit[i];
+        if (RLU_CLASSIFY) {
+            if (!(t & RLU_NET_FLAG)) continue;
+            t &= ~RLU_NET_FLAG;
+            __syncthreads();                                          // (uniform: every thread read the flagged entry)
+            if (tid == 0) unfit[i] = t;
+        }
         const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
         const u64 cnt64 = e - s;
         __syncthreads();                                              // A of the stretch before has been read
         if (cnt64 > CAP) {
+            if (RLU_CLASSIFY) continue;                               // (listed for the all-HBM path by the classifying kernel)
             // often one long run of equal keys (a repeat family's k-mer in every genome): nothing to do when in order
             u32 bad = 0;
             for (u64 j = s + tid; j + 1 < e && !bad; j += NT) bad = keys[j] > keys[j + 1] ? 1u : 0u;
@@ -1356,9 +1543,11 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
                     hipEvent_t *pass_events, int max_pairs, int *npairs, hipError_t *err, const TextKeySrc *text,
                     RleSink *sink) {
     *err = hipSuccess;
-    if (sink) sink->done = false;
+    if (sink) { sink->done = false; sink->n_over = 0; }
     if (npairs) *npairs = 0;
     const bool aux = (algo & 16) != 0;       // bit 4: auxiliary sort
+    const bool net_only = (algo & 32) != 0;  // bit 5: unfit stretches with keys between the splitters go to the network (tests)
+    (void)net_only;
     algo &= 15;
     if (key_bits > 64) key_bits = 64;
     if (!text && (n < 2 || key_bits <= 0)) return a;
@@ -1390,8 +1579,14 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
         rle_boff = rle_bsum + rle_nb(n);
         (void)hipMemsetAsync(rle_ctr, 0, 16, stream);
         rs_local_count_kernel<<<nwtiles, 64, 0, stream>>>(src, n, pshift, mark, rle_bnd, rle_unfit, rle_ctr, rle_tcnt, sink->mchar);
-        rs_local_unfit_kernel<<<nwtiles < 16384u ? nwtiles : 16384u, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr,
-                                                                                        ws.over, ws.over_cap);
+        const u32 ugrid = nwtiles < 16384u ? nwtiles : 16384u;
+#if RLU_CLASSIFY
+        rs_local_unfit_kernel<8><<<ugrid, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, ws.over, ws.over_cap,
+                                                            net_only ? 0u : RLU_GAP_MAX);
+        rs_local_unfit_kernel<16><<<ugrid < 4096u ? ugrid : 4096u, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, ws.over,
+                                                                                      ws.over_cap, net_only ? 0u : RLU_GAP_MAX);
+#endif
+        rs_local_unfit_net_kernel<<<ugrid, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, ws.over, ws.over_cap);
     } else {
         rs_local_kernel<64><<<nwtiles, 64, 0, stream>>>(src, n, pshift, ws.over, ws.over_cap, mark);
         rs_local_kernel<256><<<ntiles, 256, 0, stream>>>(src, n, pshift, ws.over, ws.over_cap, mark);
@@ -1449,6 +1644,8 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
                 rs_unfit_rle_kernel<1, 1><<<dim3(64, RLU_ROWS), 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
                                                        rle_boff, sink->dk, sink->dstart, sink->mchar);
         (void)hipMemcpyAsync(sink->h_total, rle_ctr + 1, sizeof(u32), hipMemcpyDeviceToHost, stream);
+        if (sink->h_ctr) (void)hipMemcpyAsync(sink->h_ctr, rle_ctr, 4 * sizeof(u32), hipMemcpyDeviceToHost, stream);
+        sink->n_over = nover;
         sink->done = true;
     }
     *err = hipGetLastError();

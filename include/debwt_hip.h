@@ -65,6 +65,9 @@ typedef struct {
     /* how the special-region tables of the last run were built (collect, src/collect#$.c:118-157,348-602):
      * special_path 0 = one host thread, 1 = host threads, 2 = device; special_threads = host threads used */
     uint32_t special_path, special_threads;
+    /* bucket finish of the key sort (all key ranges of the last run): stretches above a wave tile (1024 keys), those of
+     * them the classifying kernel left to the 4096-key network, stretches above 4096 keys (all-HBM passes) */
+    uint64_t sort_unfit_stretches, sort_unfit_network, sort_over_stretches;
 } debwt_stats;
 
 int debwt_create(const debwt_config *cfg, debwt_ctx **out);

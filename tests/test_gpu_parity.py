@@ -390,6 +390,79 @@ def test_hip_long_unfit_stretch_of_the_key_sort(api, oracle, k):
     d.close()
 
 
+def _node_keys(recs, k):
+    """(node << 2 | pred) of every main position, by definition (numpy)."""
+    K = k - 1
+    out = []
+    for x in recs:
+        x = np.asarray(x, dtype=np.uint64)
+        m = len(x) - K + 1                                   # windows that end at or before the separator
+        node = np.zeros(m, dtype=np.uint64)
+        for j in range(K):
+            node = (node << np.uint64(2)) | x[j:j + m]
+        pred = np.concatenate([np.array([3], dtype=np.uint64), x[:m - 1]])
+        out.append((node << np.uint64(2)) | pred)
+    return np.concatenate(out)
+
+
+def _unfit_case(name):
+    rng = np.random.default_rng(4242)
+    if name == "families":
+        # repeat families with 2 % divergence: a few hundred keys per 8-mer bucket (two top passes at this size), most
+        # of them copies of a few dozen distinct keys -- what the classifying finish is made for
+        recs = []
+        for r in range(4):
+            parts = []
+            for f in range(3):
+                cons = rng.integers(0, 4, size=600).astype(np.uint8)
+                for _ in range(400):
+                    cp = cons.copy()
+                    hit = rng.random(600) < 0.02
+                    cp[hit] = (cp[hit] + rng.integers(1, 4, size=int(hit.sum()))) & 3
+                    parts.append(cp)
+                    parts.append(rng.integers(0, 4, size=int(rng.integers(5, 200))).astype(np.uint8))
+            recs.append(np.concatenate(parts))
+        return recs
+    if name == "runs":
+        # runs of one symbol with 10 % substitutions: buckets of 1000 to 5000 keys that are nearly all distinct (gap classes
+        # between the splitters do the work; the longest go to the all-HBM passes)
+        parts = []
+        for ln in (1400, 2600, 3900, 14000, 1800, 3100):
+            run = np.full(ln, int(rng.integers(0, 4)), dtype=np.uint8)
+            hit = rng.random(ln) < 0.10
+            run[hit] = (run[hit] + rng.integers(1, 4, size=int(hit.sum()))) & 3
+            parts += [rng.integers(0, 4, size=3000).astype(np.uint8), run]
+        return [np.concatenate(parts), rng.integers(0, 4, size=900).astype(np.uint8)]
+    # exact copies: every key of a stretch equals a splitter, or the stretch is in order already
+    seg = rng.integers(0, 4, size=500).astype(np.uint8)
+    return [np.concatenate([seg] * 700 + [rng.integers(0, 4, size=4000).astype(np.uint8)]), np.concatenate([seg[100:]] * 50)]
+
+
+@pytest.mark.parametrize("tune", [0, 32768])
+@pytest.mark.parametrize("k", [32, 21])
+@pytest.mark.parametrize("name", ["families", "runs", "copies"])
+def test_unfit_stretches_of_the_key_sort_by_classes(api, name, k, tune):
+    """Stretches above a wave tile are sorted by classes around sampled splitters (rs_local_unfit_kernel); tune bit 15
+    sends every stretch with keys between the splitters to the 4096-key network instead.  Sorted keys, distinct keys
+    and row symbols against the definition."""
+    recs = _unfit_case(name)
+    want = np.sort(_node_keys(recs, k))
+    d = api.DeBWT(k=k, tune=tune)
+    d.load_records(recs)
+    for _ in range(2):
+        d.kmer_sort_rle()
+        got = d.fetch_array(api.ARR_SORTED_KEYS)
+        assert np.array_equal(got, want)
+        assert np.array_equal(d.fetch_array(api.ARR_DISTINCT_KEYS), np.unique(want))
+        st = d.stats()
+        assert st["sort_unfit_stretches"] > 0, st
+        if tune and name != "copies":
+            assert st["sort_unfit_network"] > 0, st
+        if name == "runs":
+            assert st["sort_over_stretches"] > 0, st
+    d.close()
+
+
 def test_hip_large_tie_ranges_go_deeper(api, oracle):
     """3000 exact copies of a segment full of branching nodes: the rows of a node early in the segment tie for more than
     the 42 SP symbols a split looks at, in groups above the LDS capacity -- those ranges are split again one pair of
