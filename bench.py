@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--h2h-reps", type=int, default=-1,
                     help="host-to-host steps (N = 1; load + build + fetch, mean over them); default = --steps, 0 = skip")
+    ap.add_argument("--h2h-plain", action="store_true", help="host-to-host steps with build + fetch one after the other (A/B)")
     ap.add_argument("--cpu-configs", action="store_true",
                     help="also time the reference on the whole chr1_250M collection (BASELINE configs[1]; minutes of CPU)")
     ap.add_argument("--other-mode-timeout", type=float, default=180.0, help=argparse.SUPPRESS)
@@ -320,9 +321,13 @@ def main():
             t0 = time.perf_counter()
             d.load_packed(text.a, n, sep)
             t1 = time.perf_counter()
-            d.build()
-            t2 = time.perf_counter()
-            d.fetch_into(out_words.a, out_hash.a, out_dollar.a)
+            if args.h2h_plain:
+                d.build()
+                t2 = time.perf_counter()
+                d.fetch_into(out_words.a, out_hash.a, out_dollar.a)
+            else:
+                d.build_into(out_words.a, out_hash.a, out_dollar.a)      # debwt_build_to_host: rows leave range by range
+                t2 = time.perf_counter()
             t3 = time.perf_counter()
             parts += (t1 - t0, t2 - t1, t3 - t2)
         torch.cuda.synchronize()
@@ -330,9 +335,14 @@ def main():
         parts /= h2h_reps
         h2h = {"value": round(n / mean_s / 1e9, 4), "unit": "Gbp/s", "seconds": round(mean_s, 4), "steps": h2h_reps,
                "load_s": round(parts[0], 4), "build_s": round(parts[1], 4), "fetch_s": round(parts[2], 4),
+               "call": "debwt_load_text + debwt_build + debwt_fetch_bwt" if args.h2h_plain else
+                       "debwt_load_text + debwt_build_to_host (build_s holds the copy of the rows: finished key ranges leave "
+                       "for the host while the blocks of the next range are sorted)",
                "note": "MEAN over `steps` consecutive steps of: page-locked host text -> HBM, build, BWT + '#'/'$' rows -> "
                        "page-locked host memory (SURVEY 8d's region; PCIe both ways inside).  A fresh load also re-plans the "
                        "key ranges (prefix census of the text).  `value` above is the same build with the text resident in HBM"}
+        if not (out_words.a[:4] != 0).any() and n > 4096:
+            h2h["error"] = "the host buffer holds no rows"
         out_words.free(); out_hash.free(); out_dollar.free()
 
     line = None

@@ -67,7 +67,7 @@ SYMBOLS = [
     "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_verify_device", "debwt_multi_create", "debwt_multi_destroy", "debwt_multi_last_error",
     "debwt_multi_load_text", "debwt_multi_load_fasta", "debwt_multi_build", "debwt_multi_fetch_bwt", "debwt_multi_get_stats",
     "debwt_multi_verify", "debwt_multi_shard", "debwt_pinned_alloc", "debwt_pinned_free", "debwt_shard_key_mode",
-    "debwt_multi_set_key_mode", "debwt_special_compare",
+    "debwt_multi_set_key_mode", "debwt_special_compare", "debwt_build_to_host",
 ]
 
 
@@ -113,6 +113,8 @@ def lib():
         fn.argtypes = [vp]
     L.debwt_fetch_bwt.restype = ctypes.c_int
     L.debwt_fetch_bwt.argtypes = [vp, u64p, u64p, u64p]
+    L.debwt_build_to_host.restype = ctypes.c_int
+    L.debwt_build_to_host.argtypes = [vp, u64p, u64p, u64p]
     L.debwt_bwt_device_ptr.restype = ctypes.c_int
     L.debwt_bwt_device_ptr.argtypes = [vp, ctypes.POINTER(vp)]
     L.debwt_get_stats.restype = ctypes.c_int

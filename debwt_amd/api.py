@@ -144,6 +144,11 @@ class DeBWT:
         """fetch() into caller-owned uint64 arrays (e.g. page-locked ones): ceil(n/32), nrec-1 (>= 1), 1 words."""
         self._chk(self._L.debwt_fetch_bwt(self._h, _p64(words), _p64(hrows), _p64(drow)))
 
+    def build_into(self, words, hrows, drow):
+        """build() + fetch_into() with the copy of finished row ranges hidden behind the blue sort of the following ones
+        (debwt_build_to_host); page-locked arrays for the overlap."""
+        self._chk(self._L.debwt_build_to_host(self._h, _p64(words), _p64(hrows), _p64(drow)))
+
     def fetch_small(self):
         """(None, hash_rows, dollar_row): the row lists only, the BWT words stay in HBM."""
         hrows = np.empty(max(self.nrec - 1, 1), dtype=np.uint64)

@@ -70,7 +70,7 @@ struct debwt_ctx {
     // the node instances exceed range_cap: "bucket streaming" for texts whose keys do not fit HBM at once).
     // D, Rmo and the buffers keysA/keysB/dk/dstart/pflag/mi_*/bstart/facts belong to the range being processed;
     // Q, B, nlarge and blk_*/facts_acc/large_q/mchar/sprow cover the whole context with 64-bit offsets.
-    struct KeyRange { u64 key_lo, key_hi, M, Mbase, Q, qbase, B, Bbase, s0, s1; };
+    struct KeyRange { u64 key_lo, key_hi, M, Mbase, Q, qbase, B, Bbase, s0, s1, l0, nl; };   // l0, nl: its blocks above the LDS capacity in large_q
     std::vector<KeyRange> ranges;
     u64 range_cap = 0;          // 0: from the free HBM at the first build (plan_ranges)
     u64 Mctx = 0;               // node instances of this context (sum over its ranges)
@@ -109,6 +109,8 @@ struct debwt_ctx {
     bool mztable = false;       // ... and so is the node table (k_build_hash)
     bool abs32 = true;          // fill cursors hold absolute blue slots
 
+    hipStream_t copy_stream = nullptr;   // debwt_build_to_host: finished row ranges leave on this stream under the blue sort
+    hipEvent_t ev_copy = nullptr;
     hipEvent_t ev[8]{};         // stage boundaries
     hipEvent_t ev_pass[16][2]{};
     int n_pass_events = 0;
@@ -310,6 +312,8 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
     if (c->h_over) (void)hipHostFree(c->h_over);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &p : c->ev_pass) for (auto &e : p) if (e) (void)hipEventDestroy(e);
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -481,7 +485,7 @@ static int plan_ranges(debwt_ctx *c) {
     if (c->shard_world == 1 && !c->shard_planned) { c->key_lo = c->key_hi = 0; c->Mctx = c->Mfull; c->Mbase = 0; c->exchange = false; }
     if (c->shard_planned || (c->plan_valid && c->ranges.size() > 1 && c->shard_world == 1)) {
         // cut by debwt_shard_plan / by the census an earlier build of this text took: same cuts
-        for (auto &r : c->ranges) { r.Q = r.qbase = r.B = r.Bbase = r.s0 = r.s1 = 0; }
+        for (auto &r : c->ranges) { r.Q = r.qbase = r.B = r.Bbase = r.s0 = r.s1 = r.l0 = r.nl = 0; }
         return DEBWT_OK;
     }
     c->ranges.clear();
@@ -914,7 +918,7 @@ static int classify_local(debwt_ctx *c) {
 // appends the range just classified (facts, block tables, large-block list) to the context-wide tables
 static int append_range(debwt_ctx *c, debwt_ctx::KeyRange &r) {
     const u64 Q = c->rQ, nf = c->Rmo + Q;
-    r.Q = Q; r.qbase = c->Q; r.B = c->rB; r.Bbase = c->B;
+    r.Q = Q; r.qbase = c->Q; r.B = c->rB; r.Bbase = c->B; r.l0 = c->nlarge; r.nl = c->rnlarge;
     ENSURE_KEEP(c, c->facts_acc, (c->nfacts_acc + nf) * 8 + 64, c->nfacts_acc * 8);
     ENSURE_KEEP(c, c->blk_j0, (c->Q + Q) * 8 + 64, c->Q * 8);
     ENSURE_KEEP(c, c->blk_freq, (c->Q + Q) * 4 + 64, c->Q * 4);
@@ -1198,13 +1202,14 @@ static int bitonic_large(debwt_ctx *c, u64 b0, u32 m, u64 j0) {
     return DEBWT_OK;
 }
 
-static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
+// the blocks large_q[l0, l0 + nl)
+static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
     int rc;
     // descriptors of the large blocks: one gather, one copy
-    std::vector<u64> desc3(3 * c->nlarge);
-    ENSURE(c, c->large_k0, 3 * c->nlarge * 8);
-    k_large_gather<<<grid_for(c->nlarge, 256), 256, 0, c->stream>>>(c->large_q.as<u32>(), c->nlarge, c->blk_freq.as<u32>(),
-                                                                   c->blk_start.as<u64>(), c->blk_j0.as<u64>(), c->large_k0.as<u64>());
+    std::vector<u64> desc3(3 * nl);
+    ENSURE(c, c->large_k0, 3 * nl * 8);
+    k_large_gather<<<grid_for(nl, 256), 256, 0, c->stream>>>(c->large_q.as<u32>() + l0, nl, c->blk_freq.as<u32>(),
+                                                            c->blk_start.as<u64>(), c->blk_j0.as<u64>(), c->large_k0.as<u64>());
     HIPCHK(c, hipMemcpyAsync(desc3.data(), c->large_k0.p, desc3.size() * 8, hipMemcpyDeviceToHost, c->stream));
     if ((rc = sync_check(c))) return rc;
     // rounds: every pending block is split in the same five launches (batches of at most LS_BATCH_ROWS rows of
@@ -1218,11 +1223,11 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
     struct Work { u64 b0, j0; u32 m, depth, pivot; };
     std::vector<Work> work, next;
     u32 maxm = 0;
-    for (u64 t = 0; t < c->nlarge; t++) {
+    for (u64 t = 0; t < nl; t++) {
         work.push_back(Work{desc3[3 * t], desc3[3 * t + 1], (u32)desc3[3 * t + 2], 0u, 0u});
         maxm = std::max(maxm, (u32)desc3[3 * t + 2]);
     }
-    c->st.blue_max_block = maxm;
+    c->st.blue_max_block = std::max<u64>(c->st.blue_max_block, maxm);
     if (c->cfg.reserved & 1024) {                                  // bit 10: bitonic network only (tests)
         for (const Work &wk : work) if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc;
         return DEBWT_OK;
@@ -1307,73 +1312,89 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub) {
     return DEBWT_OK;
 }
 
+// the sub-block table of a blue sort (BlueSub): the deep tie groups of the larger size classes wait there for the
+// wave-per-block kernels
+struct BlueQueue { BlueSub sub; u32 *count; u32 cap; };
+static int blue_queue(debwt_ctx *c, BlueQueue *bq) {
+    const u32 sub_cap = (u32)std::min<u64>(std::max<u64>(c->B / 8, 1u << 16), 1u << 26);
+    ENSURE(c, c->sub_start, (size_t)sub_cap * 8);
+    ENSURE(c, c->sub_j0, (size_t)sub_cap * 8);
+    ENSURE(c, c->sub_freq, (size_t)sub_cap * 4);
+    ENSURE(c, c->sub_depth, (size_t)sub_cap * 4 + 16);
+    bq->cap = sub_cap;
+    bq->count = c->sub_depth.as<u32>() + sub_cap;
+    bq->sub = BlueSub{c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), c->sub_depth.as<u32>(), bq->count,
+                      (c->cfg.reserved & 128) ? 0u : sub_cap};      // bit 7: no hand-off (tests)
+    return DEBWT_OK;
+}
+
+// Sorts the blocks [q0, q0 + nq) of the context's block table (block order is key order is row order) and, of the blocks
+// above the LDS capacity, large_q[l0, l0 + nl).  A part leaves its rows final: debwt_build_to_host runs one part per key
+// range and hands the rows over while the next part is sorted.
+static int blue_sort_part(debwt_ctx *c, const BlueQueue &bq, u64 q0, u64 nq, u64 l0, u64 nl) {
+    int rc;
+    if (!nq) return DEBWT_OK;
+    const u32 Q = (u32)nq;
+    const u64 *bst = c->blk_start.as<u64>() + q0, *bj0 = c->blk_j0.as<u64>() + q0;
+    const u32 *bfr = c->blk_freq.as<u32>() + q0;
+    const BlueSub &sub = bq.sub;
+    const u32 sub_cap = bq.cap;
+    u32 *sub_count = bq.count;
+    HIPCHK(c, hipMemsetAsync(c->sub_freq.p, 0, (size_t)sub_cap * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(sub_count, 0, 4, c->stream));
+    BlueSub none{};
+    u32 g1 = (u32)std::min<u64>(Q, 1u << 16);
+    // small blocks are the bulk: a small LDS footprint keeps 32 single-wave workgroups per CU in flight
+    k_blue_refine<64, 128, 0><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, 0u,
+                                                       c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, none);
+    // 129..256 rows: one wave per block with the LDS of that capacity (9 KB per workgroup, 17 of them per CU);
+    // 257..512 rows: 18 KB per block allow 8 workgroups per CU -- four waves each rather than one: these kernels wait
+    // on SP gathers, what they need is waves in flight (measured at 30 Gbp: 129..512 rows by one wave and 18 KB each
+    // 86 + 156 ms for blocks + queued ranges; now 6.5 + 67 and 22 + 78 ms)
+    k_blue_refine<64, 256, 128><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, 128u, c->spn.as<u64>(), c->S,
+                                                         c->mchar.as<u8>(), nullptr, nullptr, sub);
+    k_blue_refine<256, BLUE_WAVE_CAP, 128><<<(u32)std::min<u64>(Q, 1u << 14), 256, 0, c->stream>>>(
+        c->blue.as<u64>(), bst, bfr, bj0, Q, 256u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, sub);
+    u32 g2 = (u32)std::min<u64>(Q, 1u << 12);
+    // collections of many genomes put most rows into blocks of 513..1024 rows: those get a kernel of their own
+    // with half the LDS footprint (four workgroups per CU instead of two); otherwise one kernel for 513..2048
+    const bool split1024 = c->n1024 >= 1024;
+    if (split1024)
+        k_blue_refine<256, 1024, BLUE_WAVE_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, (u32)BLUE_WAVE_CAP,
+                                                                      c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, sub);
+    k_blue_refine<256, BLUE_LDS_CAP, BLUE_WAVE_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q,
+                                                                  split1024 ? 1024u : (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
+                                                                  c->mchar.as<u8>(), nullptr, nullptr, sub);
+    // heavy-tail blocks (satellite / poly-A nodes), before the queue is drained: split in HBM into ranges the LDS
+    // kernels take (queued like the tie groups); what a split cannot separate goes through the bitonic network
+    if (nl && (rc = sort_large_blocks(c, sub, l0, nl))) return rc;
+    // the queued groups: blocks of their own that start `depth` windows in (<= 128 rows from the 512 class,
+    // <= 512 rows from the 2048 class and from the split of the large blocks: LS_QUEUE_CAP)
+    const u32 gs = std::min<u32>(sub_cap, 1u << 16);
+    k_blue_refine<64, 128, 0><<<gs, 64, 0, c->stream>>>(
+        c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 0u,
+        c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
+    k_blue_refine<64, 256, 0><<<gs, 64, 0, c->stream>>>(
+        c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 128u,
+        c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
+    // (257..512 queued rows are one deep tie group as a rule: four waves per block gather its windows four times as wide)
+    k_blue_refine<256, BLUE_WAVE_CAP, 0><<<std::min<u32>(gs, 1u << 14), 256, 0, c->stream>>>(
+        c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 256u,
+        c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
+    return DEBWT_OK;
+}
+
 extern "C" int debwt_blue_sort(debwt_ctx *c) {
     if (!c) return DEBWT_EINVAL;
     if (c->stage < ST_SP) return DEBWT_ESTATE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc;
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-    const u64 Q = c->Q;
     c->st.blue_max_block = 0;
-    if (Q) {
-        // sub-block table for the deep tie groups of the larger size classes (BlueSub)
-        const u32 sub_cap = (u32)std::min<u64>(std::max<u64>(c->B / 8, 1u << 16), 1u << 26);
-        ENSURE(c, c->sub_start, (size_t)sub_cap * 8);
-        ENSURE(c, c->sub_j0, (size_t)sub_cap * 8);
-        ENSURE(c, c->sub_freq, (size_t)sub_cap * 4);
-        ENSURE(c, c->sub_depth, (size_t)sub_cap * 4 + 16);
-        u32 *sub_count = c->sub_depth.as<u32>() + sub_cap;
-        HIPCHK(c, hipMemsetAsync(c->sub_freq.p, 0, (size_t)sub_cap * 4, c->stream));
-        HIPCHK(c, hipMemsetAsync(sub_count, 0, 4, c->stream));
-        BlueSub sub{c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), c->sub_depth.as<u32>(), sub_count,
-                    (c->cfg.reserved & 128) ? 0u : sub_cap};      // bit 7: no hand-off (tests)
-        BlueSub none{};
-        u32 g1 = (u32)std::min<u64>(Q, 1u << 16);
-        // small blocks are the bulk: a small LDS footprint keeps 32 single-wave workgroups per CU in flight
-        k_blue_refine<64, 128, 0><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
-                                                           c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q, 0u,
-                                                           c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, none);
-        // 129..256 rows: one wave per block with the LDS of that capacity (9 KB per workgroup, 17 of them per CU);
-        // 257..512 rows: 18 KB per block allow 8 workgroups per CU -- four waves each rather than one: these kernels wait
-        // on SP gathers, what they need is waves in flight (measured at 30 Gbp: 129..512 rows by one wave and 18 KB each
-        // 86 + 156 ms for blocks + queued ranges; now 6.5 + 67 and 22 + 78 ms)
-        k_blue_refine<64, 256, 128><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
-                                                           c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
-                                                           128u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(),
-                                                           nullptr, nullptr, sub);
-        k_blue_refine<256, BLUE_WAVE_CAP, 128><<<(u32)std::min<u64>(Q, 1u << 14), 256, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
-                                                                     c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
-                                                                     256u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(),
-                                                                     nullptr, nullptr, sub);
-        u32 g2 = (u32)std::min<u64>(Q, 1u << 12);
-        // collections of many genomes put most rows into blocks of 513..1024 rows: those get a kernel of their own
-        // with half the LDS footprint (four workgroups per CU instead of two); otherwise one kernel for 513..2048
-        const bool split1024 = c->n1024 >= 1024;
-        if (split1024)
-            k_blue_refine<256, 1024, BLUE_WAVE_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
-                                                                          c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
-                                                                          (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
-                                                                          c->mchar.as<u8>(), nullptr, nullptr, sub);
-        k_blue_refine<256, BLUE_LDS_CAP, BLUE_WAVE_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), c->blk_start.as<u64>(),
-                                                                      c->blk_freq.as<u32>(), c->blk_j0.as<u64>(), (u32)Q,
-                                                                      split1024 ? 1024u : (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
-                                                                      c->mchar.as<u8>(), nullptr, nullptr, sub);
-        // heavy-tail blocks (satellite / poly-A nodes), before the queue is drained: split in HBM into ranges the LDS
-        // kernels take (queued like the tie groups); what a split cannot separate goes through the bitonic network
-        if (c->nlarge && (rc = sort_large_blocks(c, sub))) return rc;
-        // the queued groups: blocks of their own that start `depth` windows in (<= 128 rows from the 512 class,
-        // <= 512 rows from the 2048 class and from the split of the large blocks: LS_QUEUE_CAP)
-        const u32 gs = std::min<u32>(sub_cap, 1u << 16);
-        k_blue_refine<64, 128, 0><<<gs, 64, 0, c->stream>>>(
-            c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 0u,
-            c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
-        k_blue_refine<64, 256, 0><<<gs, 64, 0, c->stream>>>(
-            c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 128u,
-            c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
-        // (257..512 queued rows are one deep tie group as a rule: four waves per block gather its windows four times as wide)
-        k_blue_refine<256, BLUE_WAVE_CAP, 0><<<std::min<u32>(gs, 1u << 14), 256, 0, c->stream>>>(
-            c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 256u,
-            c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);
+    if (c->Q) {
+        BlueQueue bq{};
+        if ((rc = blue_queue(c, &bq))) return rc;
+        if ((rc = blue_sort_part(c, bq, 0, c->Q, 0, c->nlarge))) return rc;
     }
     c->stage = ST_BLUE;
     return DEBWT_OK;
@@ -1385,23 +1406,21 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
 // rows of this shard: its node instances with its special suffixes merged in (the whole BWT when not sharded)
 static u64 shard_rows(const debwt_ctx *c) { return c->Mctx + (c->s1 - c->s0); }
 
-static int run_assemble(debwt_ctx *c, u8 *rowsym) {
+// assembles the 8192-row blocks [b0, b1) of this shard's rows (all of them: b1 = ~0)
+static int run_assemble(debwt_ctx *c, u8 *rowsym, u64 b0 = 0, u64 b1 = ~0ull) {
     const u64 rows = shard_rows(c);
-    u64 nw = (rows + 31) >> 5;
-    k_assemble<<<grid_for(nw, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
+    const u64 nb = (((rows + 31) >> 5) + DEBWT_BLOCK - 1) / DEBWT_BLOCK;
+    b1 = std::min(b1, nb);
+    if (b0 >= b1) return DEBWT_OK;
+    k_assemble<<<(u32)(b1 - b0), DEBWT_BLOCK, 0, c->stream>>>(
         c->mchar.as<u8>(), c->Mctx, c->sprow.as<u64>() + c->s0, c->spchr.as<u8>() + c->s0, c->s1 - c->s0, rows,
-        c->bwt.as<u64>(), c->hmask.as<u32>(), c->dollar.as<u64>(), rowsym);
+        c->bwt.as<u64>(), c->hmask.as<u32>(), c->dollar.as<u64>(), rowsym, b0);
     return DEBWT_OK;
 }
 
-extern "C" int debwt_bwt_assemble(debwt_ctx *c) {
-    if (!c) return DEBWT_EINVAL;
-    if (c->stage < ST_BLUE) return DEBWT_ESTATE;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
+// '#' rows of the assembled words, stage timings, stage = ST_ASSEMBLED
+static int assemble_finish(debwt_ctx *c) {
     int rc;
-    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    HIPCHK(c, hipMemsetAsync(c->dollar.p, 0xFF, 8, c->stream));
-    run_assemble(c, nullptr);
     u64 nw = (shard_rows(c) + 31) >> 5;
     HashRowsF fh{c->hmask.as<u32>(), c->hash_rows.as<u64>()};
     if ((rc = cp_count(c, fh, nw, cp_area(c, 0), 9))) return rc;
@@ -1430,6 +1449,16 @@ extern "C" int debwt_bwt_assemble(debwt_ctx *c) {
     return DEBWT_OK;
 }
 
+extern "C" int debwt_bwt_assemble(debwt_ctx *c) {
+    if (!c) return DEBWT_EINVAL;
+    if (c->stage < ST_BLUE) return DEBWT_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dollar.p, 0xFF, 8, c->stream));
+    run_assemble(c, nullptr);
+    return assemble_finish(c);
+}
+
 extern "C" int debwt_build(debwt_ctx *c) {
     int rc;
     if (!c) return DEBWT_EINVAL;
@@ -1440,6 +1469,61 @@ extern "C" int debwt_build(debwt_ctx *c) {
     if ((rc = debwt_sp_generate(c))) return rc;
     if ((rc = debwt_blue_sort(c))) return rc;
     return debwt_bwt_assemble(c);
+}
+
+// debwt_build with the result handed to the host as it becomes final.  A text built in several key ranges has its
+// multi-in blocks, like its rows, in key-range order: the blue sort runs range by range, the rows of a range are
+// assembled as soon as its blocks are sorted and leave on a second stream while the blocks of the next range are sorted
+// (at 30 Gbp: 7.5 GB of rows, 0.13 s of copy under 0.33 s of kernels; only the last range's copy is exposed).  A text
+// built in one range: debwt_build, then debwt_fetch_bwt.
+extern "C" int debwt_build_to_host(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row) {
+    int rc;
+    if (!c || !bwt || !dollar_row || (c->nrec > 1 && !hash_rows)) return DEBWT_EINVAL;
+    if (c->stage < ST_LOADED) return DEBWT_ESTATE;
+    if (c->shard_world > 1) { c->err = "sharded context: use the debwt_shard_* calls"; return DEBWT_ESTATE; }
+    c->stage = ST_LOADED;
+    if ((rc = debwt_kmer_sort_rle(c))) return rc;
+    if ((rc = debwt_classify(c))) return rc;
+    if ((rc = debwt_sp_generate(c))) return rc;
+    if (c->ranges.size() < 2 || (c->cfg.reserved & 65536)) {        // bit 16: no overlap (tests, A/B)
+        if ((rc = debwt_blue_sort(c))) return rc;
+        if ((rc = debwt_bwt_assemble(c))) return rc;
+        return debwt_fetch_bwt(c, bwt, hash_rows, dollar_row);
+    }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->ev_copy) HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dollar.p, 0xFF, 8, c->stream));
+    c->st.blue_max_block = 0;
+    BlueQueue bq{};
+    if (c->Q && (rc = blue_queue(c, &bq))) return rc;
+    const u64 rows = shard_rows(c), nw = (rows + 31) >> 5;
+    u64 bdone = 0;                                                    // 8192-row blocks assembled and on their way
+    for (size_t i = 0; i < c->ranges.size(); i++) {
+        const debwt_ctx::KeyRange &r = c->ranges[i];
+        if ((rc = blue_sort_part(c, bq, r.qbase, r.Q, r.l0, r.nl))) return rc;
+        // rows below `final` belong to this range or an earlier one: their symbols will not change any more
+        const bool last = i + 1 == c->ranges.size();
+        const u64 final = last ? rows : r.Mbase + r.M + (r.s1 - c->s0);
+        const u64 b1 = last ? (nw + DEBWT_BLOCK - 1) / DEBWT_BLOCK : final / ASM_ROWS;
+        if (last) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+        if (b1 > bdone) {
+            run_assemble(c, nullptr, bdone, b1);
+            const u64 w0 = bdone * DEBWT_BLOCK, w1 = std::min<u64>(b1 * DEBWT_BLOCK, nw);
+            HIPCHK(c, hipEventRecord(c->ev_copy, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+            HIPCHK(c, hipMemcpyAsync(bwt + w0, c->bwt.as<u64>() + w0, (w1 - w0) * 8, hipMemcpyDeviceToHost, c->copy_stream));
+            bdone = b1;
+        }
+    }
+    c->stage = ST_BLUE;
+    if ((rc = assemble_finish(c))) return rc;                          // synchronises the context's stream
+    if (c->nrec > 1)
+        HIPCHK(c, hipMemcpyAsync(hash_rows, c->hash_rows.p, (c->nrec - 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dollar_row, c->dollar.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    return sync_check(c);
 }
 
 extern "C" int debwt_fetch_bwt(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row) {

@@ -1638,10 +1638,14 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_assemble(const u8 *__restrict__
                                                            const u64 *__restrict__ sprow,
                                                            const u8 *__restrict__ spchr, u64 NS, u64 n,
                                                            u64 *__restrict__ bwt, u32 *__restrict__ hmask,
-                                                           u64 *__restrict__ dollar_row, u8 *__restrict__ rowsym) {
+                                                           u64 *__restrict__ dollar_row, u8 *__restrict__ rowsym,
+                                                           u64 block0) {
+    // block0: first 8192-row block of this launch (a build that hands finished row ranges to the host as it goes
+    // assembles them range by range)
     __shared__ u32 sm[ASM_ROWS / 4 + 12];
     __shared__ u64 sblk;
-    const u64 R0 = (u64)blockIdx.x * ASM_ROWS;
+    const u64 blk = block0 + blockIdx.x;
+    const u64 R0 = blk * ASM_ROWS;
     if (threadIdx.x == 0) sblk = lower_bound_dev<u64>(sprow, 0, NS, R0);       // special rows before the block
     __syncthreads();
     const u64 jb = R0 - sblk, jal = jb & ~15ull;                                 // first instance of the block, 16-aligned
@@ -1653,7 +1657,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_assemble(const u8 *__restrict__
         sm[4 * i] = v.x; sm[4 * i + 1] = v.y; sm[4 * i + 2] = v.z; sm[4 * i + 3] = v.w;
     }
     __syncthreads();
-    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 w = blk * blockDim.x + threadIdx.x;
     u64 nw = (n + 31) >> 5;
     if (w >= nw) return;
     u64 r0 = w << 5;

@@ -143,6 +143,11 @@ int debwt_build(debwt_ctx *ctx);
 /* Copies the result to host memory: bwt ceil(n/32) words, hash_rows nrec-1 rows ascending,
  * dollar_row 1 row -- the contents of OUT, OUT.#, OUT.$ (src/insertCase3.c:115-131). */
 int debwt_fetch_bwt(debwt_ctx *ctx, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row);
+/* debwt_build + debwt_fetch_bwt in one call, with the copy hidden behind the build: the reference writes OUT only after
+ * its last stage (src/insertCase3.c:115-131); here a text that is built in several key ranges has the rows of a range
+ * assembled as soon as the range's blocks are sorted, and they travel to `bwt` (page-locked memory for the overlap,
+ * debwt_pinned_alloc) while the blocks of the next range are sorted.  Same buffers and contents as debwt_fetch_bwt. */
+int debwt_build_to_host(debwt_ctx *ctx, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row);
 /* Only the row lists (OUT.#, OUT.$) -- for callers that keep the BWT words in HBM. */
 int debwt_fetch_rows(debwt_ctx *ctx, uint64_t *hash_rows, uint64_t *dollar_row);
 /* Device address of the packed BWT words of the last run (for callers that keep it in HBM). */

@@ -616,6 +616,57 @@ def test_multi_range_build_matches_reference_golden(api, entry):
     d.close()
 
 
+def _build_to_host(api, d):
+    """debwt_build_to_host into page-locked arrays; returns (words, hash rows, dollar row) as fetch() does."""
+    from debwt_amd import synth_native as SN
+    w = SN.PinnedArray((d.n + 31) // 32); h = SN.PinnedArray(max(d.nrec - 1, 1)); dr = SN.PinnedArray(1)
+    w.a[:] = 0xDEADBEEFDEADBEEF
+    try:
+        d.build_into(w.a, h.a, dr.a)
+        return w.a.copy(), h.a[:d.nrec - 1].copy(), int(dr.a[0])
+    finally:
+        w.free(); h.free(); dr.free()
+
+
+@pytest.mark.parametrize("entry", [e for e in MANIFEST if e["k"] in (12, 32)], ids=golden_id)
+def test_build_to_host_streams_the_reference_rows(api, entry):
+    """debwt_build_to_host on the golden vectors cut into many key ranges: the rows of a range leave for the host while
+    the blocks of the next range are sorted -- the reference's bytes; then once more in one range (plain build + fetch
+    inside) and with the overlap switched off (tune bit 16)."""
+    recs = golden_records(entry)
+    sha = entry["sha256"]
+    for cap, tune in ((4096 if entry["n"] < 2_000_000 else entry["n"] // 40, 0), (None, 0), (4096 if entry["n"] < 2_000_000 else entry["n"] // 7, 65536)):
+        d = api.DeBWT(k=entry["k"], tune=tune)
+        if cap:
+            d.set_range_cap(cap)
+        d.load_records(recs)
+        for _ in range(2):
+            words, hrows, drow = _build_to_host(api, d)
+            assert _sha(words) == sha["bwt"] and _sha(hrows) == sha["hash"], (cap, tune)
+            assert _sha(np.array([drow], dtype=np.uint64)) == sha["dollar"]
+        w2, h2, d2 = d.fetch()                                   # the device copy is complete as well
+        assert np.array_equal(w2, words) and np.array_equal(h2, hrows) and d2 == drow
+        d.close()
+
+
+def test_build_to_host_with_large_blocks_and_deep_ties(api, oracle):
+    """Blocks above the LDS capacity, queued tie groups and special suffixes spread over the key ranges of a streamed build."""
+    from debwt_amd import synth
+    rng = np.random.default_rng(78)
+    unit = rng.integers(0, 4, size=50).astype(np.uint8)
+    recs = [np.concatenate([unit] * 120 + [rng.integers(0, 4, size=2000).astype(np.uint8)]) for _ in range(25)]
+    recs += synth.pan_genome(150_000, 6)
+    ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), 32)
+    for cap in (50_000, 300_000):
+        d = api.DeBWT(k=32)
+        d.set_range_cap(cap)
+        d.load_records(recs)
+        words, hrows, drow = _build_to_host(api, d)
+        assert d.stats()["blue_large_blocks"] >= 1
+        assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od, cap
+        d.close()
+
+
 @pytest.mark.parametrize("cap", [1 << 20, 3_000_000, 1 << 23])
 def test_multi_range_equals_single_range_midsize(api, cap):
     from debwt_amd import synth
