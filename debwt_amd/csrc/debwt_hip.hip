@@ -765,7 +765,7 @@ static int sort_range(debwt_ctx *c, size_t i, u64 *imported) {
     // the bucket finish of the sort counts the distinct keys of its tiles and the encoding follows tile by tile
     // (tune bit 8 = 256: separate count and emit passes over the sorted keys instead)
     RleSink sink{c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase, c->rs_rle.p, &c->h_scalars[0],
-                 &c->h_scalars[32], 0, false};
+                 &c->h_scalars[32], 0, (c->cfg.reserved & 131072) != 0, false};   // bit 17: no staging of distinct keys
     if (imported && r.M < 2) c->sk = c->sort_a;
     else if ((rc = sort_keys(c, c->sort_a, c->sort_b, r.M, 2 * c->cfg.k, &c->sk, i == 0, imported ? nullptr : &ts, true,
                              (c->cfg.reserved & 256) ? nullptr : &sink))) return rc;

@@ -89,6 +89,7 @@ struct RleSink {
     u32 *h_ctr;                        // optional, 4 pinned host words: [0] stretches above a wave tile, [3] those of them
                                        // left to the 4096-key network (valid once the stream drained)
     u32 n_over;                        // out: stretches above 4096 keys, finished by all-HBM passes
+    bool no_staging;                   // in: tiles do not stage their distinct keys in the other key buffer (A/B, tests)
     bool done;
 };
 size_t radix_rle_ws_bytes(u64 n);

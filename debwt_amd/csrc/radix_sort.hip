@@ -953,10 +953,19 @@ __device__ __forceinline__ void rlw_sort(u64 (&k)[16], const u32 lane) {
     }
 }
 
+// stg (optional: the sort's other key buffer, free by now): a tile whose distinct keys are at most half of its keys
+// leaves them -- and their places in the tile, 16 bits each -- at the tile's own offset there, and says so in its count
+// (RLT_STAGED); rs_tile_emit_kernel then reads those instead of the whole tile.  In a collection of ten genomes a
+// tenth of the keys are distinct: the emit pass reads 1.1 bytes per key instead of 8.
+#define RLT_STAGED 0x80000000u
+#ifndef RLT_STAGE_RATIO
+#define RLT_STAGE_RATIO 4u             // keys per distinct key from which a tile stages (20 bytes per distinct key written and read
+#endif                                 // against 8 per key read; measured: 2 costs a single genome 1.4 % of its sort, 4 nothing)
 __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ keys, u64 n, int pshift,
                                                             u8 *__restrict__ mark, u64 *__restrict__ bnd,
                                                             u32 *__restrict__ unfit, u32 *__restrict__ nunfit,
-                                                            u32 *__restrict__ tcnt, u8 *__restrict__ mchar) {
+                                                            u32 *__restrict__ tcnt, u8 *__restrict__ mchar,
+                                                            u64 *__restrict__ stg) {
     constexpr int KPT = 16;
     constexpr u32 CAP = RLW_CAP;
     __shared__ u64 A[CAP + CAP / 16];
@@ -986,15 +995,24 @@ __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ ke
     for (int r = 0; r < KPT; r++) A[RL_PAD(lane * KPT + r)] = k[r];
     // a key is a head when it differs from the key before it; the stretch starts at a bucket boundary
     const u64 before = __shfl_up(k[KPT - 1], 1, 64);
-    u32 c = 0;
+    u32 hm = 0;                                                   // heads among this lane's keys
 #pragma unroll
     for (int r = 0; r < KPT; r++) {
         const u64 p = r ? k[r - 1] : before;
-        c += (lane * KPT + r < cnt && ((lane == 0 && r == 0) || k[r] != p)) ? 1u : 0u;
+        hm |= ((lane * KPT + r < cnt && ((lane == 0 && r == 0) || k[r] != p)) ? 1u : 0u) << r;
     }
+    const u32 cl = (u32)__popc(hm), incl = wave_scan_incl(cl);
+    const u32 c = (u32)__shfl((int)incl, 63, 64);
+    const bool staged = stg != nullptr && RLT_STAGE_RATIO * c <= cnt;
+    if (lane == 0) tcnt[blockIdx.x] = c | (staged ? RLT_STAGED : 0u);
+    if (staged) {
+        u64 *kd = stg + s;
+        unsigned short *id = reinterpret_cast<unsigned short *>(stg + s + c);
+        u32 o = incl - cl;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-    if (lane == 0) tcnt[blockIdx.x] = c;
+        for (int r = 0; r < KPT; r++)
+            if ((hm >> r) & 1u) { kd[o] = k[r]; id[o] = (unsigned short)(lane * KPT + r); o++; }
+    }
     if (lane * KPT < cnt) {                                       // row symbols: 16 bytes per lane
         u8 *dst = mchar + s + lane * KPT;
         if (lane * KPT + KPT <= cnt) {
@@ -1259,7 +1277,7 @@ __global__ __launch_bounds__(256) void rs_tile_scan1_kernel(const u32 *__restric
     const u32 i0 = blockIdx.x * RLT_BLOCK + tid * 16u;
     u32 v[16], sum = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) { v[r] = i0 + r < nwtiles ? tcnt[i0 + r] : 0u; sum += v[r]; }
+    for (int r = 0; r < 16; r++) { v[r] = i0 + r < nwtiles ? (tcnt[i0 + r] & ~RLT_STAGED) : 0u; sum += v[r]; }
     u32 inc = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 x = __shfl_up(inc, d, 64); if (lane >= (u32)d) inc += x; }
@@ -1296,13 +1314,22 @@ __global__ __launch_bounds__(1024) void rs_tile_scan2_kernel(const u32 *__restri
 __global__ __launch_bounds__(256) void rs_tile_emit_kernel(const u64 *__restrict__ keys, u64 n,
                                                            const u64 *__restrict__ bnd, u32 nwtiles,
                                                            const u32 *__restrict__ tex, const u32 *__restrict__ boff,
-                                                           u64 *__restrict__ dk, u32 *__restrict__ dstart) {
+                                                           u64 *__restrict__ dk, u32 *__restrict__ dstart,
+                                                           const u32 *__restrict__ tcnt, const u64 *__restrict__ stg) {
     const u32 lane = threadIdx.x & 63u;
     const u32 t = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (t >= nwtiles) return;
     const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
     if (s >= e || e - s > RLW_CAP) return;
     u64 off = (u64)tex[t] + boff[t / RLT_BLOCK];
+    const u32 tc = tcnt[t];
+    if ((tc & RLT_STAGED) && stg) {                               // the tile left its distinct keys in the staging buffer
+        const u32 c = tc & ~RLT_STAGED;
+        const u64 *kd = stg + s;
+        const unsigned short *id = reinterpret_cast<const unsigned short *>(stg + s + c);
+        for (u32 i = lane; i < c; i += 64) { dk[off + i] = kd[i]; dstart[off + i] = (u32)s + id[i]; }
+        return;
+    }
     u64 carry = 0;
     for (u64 p = s; p < e; p += 64) {
         const u64 j = p + lane;
@@ -1578,7 +1605,10 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
         rle_bsum = rle_tex + nw;
         rle_boff = rle_bsum + rle_nb(n);
         (void)hipMemsetAsync(rle_ctr, 0, 16, stream);
-        rs_local_count_kernel<<<nwtiles, 64, 0, stream>>>(src, n, pshift, mark, rle_bnd, rle_unfit, rle_ctr, rle_tcnt, sink->mchar);
+        // (the other key buffer takes the distinct keys of the tiles that hold few: it is free until the all-HBM path of
+        // oversize stretches, which then works in the buffer of the distinct keys instead)
+        rs_local_count_kernel<<<nwtiles, 64, 0, stream>>>(src, n, pshift, mark, rle_bnd, rle_unfit, rle_ctr, rle_tcnt, sink->mchar,
+                                                          sink->no_staging ? nullptr : other);
         const u32 ugrid = nwtiles < 16384u ? nwtiles : 16384u;
 #if RLU_CLASSIFY
         rs_local_unfit_kernel<8><<<ugrid, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, ws.over, ws.over_cap,
@@ -1594,6 +1624,7 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
     (void)hipMemcpyAsync(ws.h_over, ws.over, 16, hipMemcpyDeviceToHost, stream);
     if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;
     u32 nover = ws.h_over[0];
+    bool staging_lost = false;
     if (nover) {
         // heavy buckets (low-complexity k-mers): finish them together with the all-HBM passes
         bool whole = nover > ws.over_cap;
@@ -1617,8 +1648,10 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
         }
         if (whole) {
             src = rs_lsd(stream, src, other, n, 0, key_bits, ws, nullptr, 0, nullptr);
+            staging_lost = true;                                   // both key buffers were overwritten
         } else {
-            u64 *scratch = other, *tmp = other + total, *d_offs = other + 2 * total;
+            u64 *const free_buf = sink ? sink->dk : other;            // sink: `other` holds staged distinct keys
+            u64 *scratch = free_buf, *tmp = free_buf + total, *d_offs = free_buf + 2 * total;
             (void)hipMemcpyAsync(d_offs, offs.data(), 3 * (size_t)nover * 8, hipMemcpyHostToDevice, stream);
             const u64 *d_list = d_offs + nover;
             u32 grid = (u32)((total + 255) / 256);
@@ -1638,7 +1671,8 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
                                                        rle_boff, sink->dk, sink->dstart, sink->mchar);
         rs_tile_scan1_kernel<<<nb, 256, 0, stream>>>(rle_tcnt, nwtiles, rle_tex, rle_bsum);
         rs_tile_scan2_kernel<<<1, 1024, 0, stream>>>(rle_bsum, nb, rle_boff, rle_ctr + 1);
-        rs_tile_emit_kernel<<<(nwtiles + 3) / 4, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_tex, rle_boff, sink->dk, sink->dstart);
+        rs_tile_emit_kernel<<<(nwtiles + 3) / 4, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_tex, rle_boff, sink->dk, sink->dstart,
+                                                                   rle_tcnt, staging_lost ? nullptr : other);
         rs_unfit_rle_kernel<1, 0><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
                                                        rle_boff, sink->dk, sink->dstart, sink->mchar);
                 rs_unfit_rle_kernel<1, 1><<<dim3(64, RLU_ROWS), 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
