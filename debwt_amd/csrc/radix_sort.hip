@@ -1077,6 +1077,9 @@ __device__ __forceinline__ u64 rlu_sort256(u64 v, u64 *X, const u32 tid) {
 }
 
 #define RLU_NET_FLAG 0x80000000u        // list entry: the stretch is left to the network kernel
+#define RLU_COUNTED 0x40000000u         // list entry: the classifying kernel has counted the stretch's distinct keys (and written
+                                        // its row symbols); its count says whether it staged them too (RLT_STAGED)
+#define RLU_TILE(x) ((x) & 0x3FFFFFFFu)
 
 #if RLU_CLASSIFY
 // KPT = 8: the stretches of up to 2048 keys (99 % of them in a collection of ten genomes: a wave tile's worth of small
@@ -1085,7 +1088,8 @@ __device__ __forceinline__ u64 rlu_sort256(u64 v, u64 *X, const u32 tid) {
 template <int KPT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPT == 8 ? RLU_WAVES_EU_SMALL : RLU_WAVES_EU, KPT == 8 ? RLU_WAVES_EU_SMALL : RLU_WAVES_EU)))
 void rs_local_unfit_kernel(u64 *__restrict__ keys, u64 n, const u64 *__restrict__ bnd, u32 nwtiles, u32 *__restrict__ unfit,
-                           u32 *__restrict__ nunfit, u32 *__restrict__ over, u32 over_cap, u32 gap_max) {
+                           u32 *__restrict__ nunfit, u32 *__restrict__ over, u32 over_cap, u32 gap_max,
+                           u32 *__restrict__ tcnt, u8 *__restrict__ mchar, u64 *__restrict__ stg) {
     constexpr int NT = 256;
     constexpr u32 CAP = NT * KPT;
     __shared__ u64 A[CAP + CAP / 16];
@@ -1096,7 +1100,7 @@ void rs_local_unfit_kernel(u64 *__restrict__ keys, u64 n, const u64 *__restrict_
     const u32 nu = nunfit[0];
     for (u32 i = blockIdx.x; i < nu; i += gridDim.x) {
         const u32 t = unfit[i];
-        if (t & RLU_NET_FLAG) continue;                               // flagged by the other instance: the network's
+        if (t & (RLU_NET_FLAG | RLU_COUNTED)) continue;               // done, or left to the network, by the other instance
         const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
         const u64 cnt64 = e - s;
         if (KPT == 8 ? cnt64 > CAP : cnt64 <= CAP / 2) continue;      // the other instance's
@@ -1206,7 +1210,37 @@ void rs_local_unfit_kernel(u64 *__restrict__ keys, u64 n, const u64 *__restrict_
         for (int r = 0; r < KPT; r++)
             if (cr[r] != 0xFFFFFFFFu) A[RL_PAD(cr[r])] = kk[r];
         __syncthreads();
-        for (u32 j = tid; j < cnt; j += NT) keys[s + j] = A[RL_PAD(j)];
+        for (u32 j = tid; j < cnt; j += NT) {
+            const u64 key = A[RL_PAD(j)];
+            keys[s + j] = key;
+            if (tcnt) mchar[s + j] = (u8)(key & 3ull);
+        }
+        if (tcnt) {
+            // The stretch lies sorted in LDS: its run-length encoding follows here instead of in two more passes over
+            // it (rs_unfit_rle_kernel counts, then emits): distinct keys counted into the stretch's raster slot and, few
+            // as they are, staged for rs_tile_emit_kernel like those of a wave tile; the list entry is marked RLU_COUNTED.
+            u32 hm = 0;
+            u64 prev = tid ? A[RL_PAD(tid * KPT - 1)] : 0ull;
+#pragma unroll
+            for (int r = 0; r < KPT; r++) {
+                const u32 j = tid * KPT + (u32)r;
+                const u64 key = A[RL_PAD(j)];
+                hm |= ((j < cnt && (j == 0 || key != prev)) ? 1u : 0u) << r;
+                prev = key;
+            }
+            const u32 cl = (u32)__popc(hm);
+            u32 c;
+            u32 o = block_scan_excl(cl, wtmp, &c);
+            const bool staged = stg != nullptr && RLT_STAGE_RATIO * c <= cnt;
+            if (tid == 0) { tcnt[t] = c | (staged ? RLT_STAGED : 0u); unfit[i] = t | RLU_COUNTED; }
+            if (staged) {
+                u64 *kd = stg + s;
+                unsigned short *id = reinterpret_cast<unsigned short *>(stg + s + c);
+#pragma unroll
+                for (int r = 0; r < KPT; r++)
+                    if ((hm >> r) & 1u) { kd[o] = A[RL_PAD(tid * KPT + r)]; id[o] = (unsigned short)(tid * KPT + r); o++; }
+            }
+        }
     }
 }
 #endif
@@ -1320,9 +1354,10 @@ __global__ __launch_bounds__(256) void rs_tile_emit_kernel(const u64 *__restrict
     const u32 t = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (t >= nwtiles) return;
     const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
-    if (s >= e || e - s > RLW_CAP) return;
-    u64 off = (u64)tex[t] + boff[t / RLT_BLOCK];
+    if (s >= e) return;
     const u32 tc = tcnt[t];
+    if (e - s > RLW_CAP && !((tc & RLT_STAGED) && stg)) return;   // an unfit stretch: rs_unfit_rle_kernel's, unless it was staged
+    u64 off = (u64)tex[t] + boff[t / RLT_BLOCK];
     if ((tc & RLT_STAGED) && stg) {                               // the tile left its distinct keys in the staging buffer
         const u32 c = tc & ~RLT_STAGED;
         const u64 *kd = stg + s;
@@ -1361,17 +1396,23 @@ __global__ __launch_bounds__(256) void rs_unfit_rle_kernel(const u64 *__restrict
                                                            const u32 *__restrict__ unfit, const u32 *__restrict__ nunfit,
                                                            u32 *__restrict__ tcnt, const u32 *__restrict__ tex,
                                                            const u32 *__restrict__ boff, u64 *__restrict__ dk,
-                                                           u32 *__restrict__ dstart, u8 *__restrict__ mchar) {
+                                                           u32 *__restrict__ dstart, u8 *__restrict__ mchar, int staging_ok) {
     constexpr u32 V = 8, STEP = 256 * V;
     __shared__ u32 wsum[4];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const u32 nu = LONG ? nunfit[2] : nunfit[0];
     for (u32 i = blockIdx.x; i < nu; i += gridDim.x) {
-        const u32 t = LONG ? unfit[nwtiles - 1u - i] : unfit[i];
+        const u32 entry = LONG ? unfit[nwtiles - 1u - i] : unfit[i];
+        const u32 t = RLU_TILE(entry);
+        if (!LONG && (entry & RLU_COUNTED)) {
+            // counted by the classifying kernel; emitted by rs_tile_emit_kernel when staged (unless the staging buffer was lost)
+            if (!EMIT || ((tcnt[t] & RLT_STAGED) && staging_ok)) continue;
+        }
         const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
         const u64 x0 = (u64)t * RLW_H;
         const u64 K64 = (e - x0) / RLW_H;                                    // raster tiles wholly inside [x0, e)
-        const u32 K = K64 < 1 ? 1u : (u32)K64;
+        // (a stretch the classifying kernel counted has its whole count in the slot of its first tile: one piece)
+        const u32 K = (K64 < 1 || (!LONG && (entry & RLU_COUNTED))) ? 1u : (u32)K64;
         if (!LONG && K >= RLU_LONG) continue;                                // the long list's
         const u64 kfirst = keys[s];
         const bool one_run = kfirst == keys[e - 1];                          // sorted: every key of the stretch is equal
@@ -1611,10 +1652,12 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
                                                           sink->no_staging ? nullptr : other);
         const u32 ugrid = nwtiles < 16384u ? nwtiles : 16384u;
 #if RLU_CLASSIFY
+        u64 *const stg = sink->no_staging ? nullptr : other;
         rs_local_unfit_kernel<8><<<ugrid, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, ws.over, ws.over_cap,
-                                                            net_only ? 0u : RLU_GAP_MAX);
+                                                            net_only ? 0u : RLU_GAP_MAX, rle_tcnt, sink->mchar, stg);
         rs_local_unfit_kernel<16><<<ugrid < 4096u ? ugrid : 4096u, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, ws.over,
-                                                                                      ws.over_cap, net_only ? 0u : RLU_GAP_MAX);
+                                                                                      ws.over_cap, net_only ? 0u : RLU_GAP_MAX,
+                                                                                      rle_tcnt, sink->mchar, stg);
 #endif
         rs_local_unfit_net_kernel<<<ugrid, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, ws.over, ws.over_cap);
     } else {
@@ -1666,17 +1709,17 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
         const u32 ug = nwtiles < 2048u ? nwtiles : 2048u;
         const u32 nb = (nwtiles + RLT_BLOCK - 1) / RLT_BLOCK;
         rs_unfit_rle_kernel<0, 0><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
-                                                       rle_boff, sink->dk, sink->dstart, sink->mchar);
+                                                       rle_boff, sink->dk, sink->dstart, sink->mchar, staging_lost ? 0 : 1);
                 rs_unfit_rle_kernel<0, 1><<<dim3(64, RLU_ROWS), 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
-                                                       rle_boff, sink->dk, sink->dstart, sink->mchar);
+                                                       rle_boff, sink->dk, sink->dstart, sink->mchar, staging_lost ? 0 : 1);
         rs_tile_scan1_kernel<<<nb, 256, 0, stream>>>(rle_tcnt, nwtiles, rle_tex, rle_bsum);
         rs_tile_scan2_kernel<<<1, 1024, 0, stream>>>(rle_bsum, nb, rle_boff, rle_ctr + 1);
         rs_tile_emit_kernel<<<(nwtiles + 3) / 4, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_tex, rle_boff, sink->dk, sink->dstart,
                                                                    rle_tcnt, staging_lost ? nullptr : other);
         rs_unfit_rle_kernel<1, 0><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
-                                                       rle_boff, sink->dk, sink->dstart, sink->mchar);
+                                                       rle_boff, sink->dk, sink->dstart, sink->mchar, staging_lost ? 0 : 1);
                 rs_unfit_rle_kernel<1, 1><<<dim3(64, RLU_ROWS), 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
-                                                       rle_boff, sink->dk, sink->dstart, sink->mchar);
+                                                       rle_boff, sink->dk, sink->dstart, sink->mchar, staging_lost ? 0 : 1);
         (void)hipMemcpyAsync(sink->h_total, rle_ctr + 1, sizeof(u32), hipMemcpyDeviceToHost, stream);
         if (sink->h_ctr) (void)hipMemcpyAsync(sink->h_ctr, rle_ctr, 4 * sizeof(u32), hipMemcpyDeviceToHost, stream);
         sink->n_over = nover;
