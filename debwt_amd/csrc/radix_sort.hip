@@ -961,6 +961,9 @@ __device__ __forceinline__ void rlw_sort(u64 (&k)[16], const u32 lane) {
 #ifndef RLT_STAGE_RATIO
 #define RLT_STAGE_RATIO 4u             // keys per distinct key from which a tile stages (20 bytes per distinct key written and read
 #endif                                 // against 8 per key read; measured: 2 costs a single genome 1.4 % of its sort, 4 nothing)
+#ifndef RLW_WINDOW
+#define RLW_WINDOW 1                   // the tile and both its boundaries out of ONE window of keys (one global round trip per tile)
+#endif
 __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ keys, u64 n, int pshift,
                                                             u8 *__restrict__ mark, u64 *__restrict__ bnd,
                                                             u32 *__restrict__ unfit, u32 *__restrict__ nunfit,
@@ -968,11 +971,53 @@ __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ ke
                                                             u64 *__restrict__ stg) {
     constexpr int KPT = 16;
     constexpr u32 CAP = RLW_CAP;
-    __shared__ u64 A[CAP + CAP / 16];
     const u32 lane = threadIdx.x;
     const u64 x0 = (u64)blockIdx.x * RLW_H, x1 = x0 + RLW_H;
+#if RLW_WINDOW
+    // Slot i of the window holds position x0 - 1 + i: the key before the raster point (its bucket is the one that may
+    // reach into the tile), the 128 positions in which the tile may start, and everything up to the last position at
+    // which it may end (x1 + 127 = slot 1024).  The start and the end are found in the window -- the version before
+    // went to HBM three times per tile, each trip waiting for the one before: the key before the raster point, the
+    // keys behind it, then the tile.
+    // A tile that starts within the reach (slot 1 + 127 at the latest) and fits (at most 1024 keys) lies inside 1152 slots.
+    constexpr u32 REACH = RLW_CAP - RLW_H, NR = 18, WN = NR * 64;
+    static_assert(RLW_H + REACH + 1 <= WN && REACH + RLW_CAP <= WN, "the window holds every boundary slot and every fit tile");
+    __shared__ u64 A[WN + WN / 16];
+    {
+        u64 g[NR];
+#pragma unroll
+        for (u32 r = 0; r < NR; r++) {
+            const u64 p1 = x0 + r * 64u + lane;                   // position + 1
+            g[r] = (p1 >= 1 && p1 - 1 < n) ? keys[p1 - 1] : ~0ull;
+        }
+#pragma unroll
+        for (u32 r = 0; r < NR; r++) A[RL_PAD(r * 64u + lane)] = g[r];
+    }
+    // first slot in (from, from + REACH] whose position lies behind the text or holds another bucket than slot `from`;
+    // none: the bucket overflows the reach, its end is found by bisection (as rl_boundary does)
+    auto boundary = [&](u32 from) -> u64 {
+        const u64 p = A[RL_PAD(from)] >> pshift;
+        for (u32 b = from + 1; b <= from + REACH; b += 64) {
+            const u32 i = b + lane;
+            const u64 pos = x0 - 1 + i;
+            const bool diff = pos >= n || (A[RL_PAD(i)] >> pshift) != p;
+            const u64 mk = __ballot(diff);
+            if (mk) return x0 - 1 + b + (u64)__ffsll((long long)mk) - 1;
+        }
+        u64 lo = x0 + from + REACH, hi = n;
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1;
+            if ((keys[mid] >> pshift) <= p) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const u64 s = x0 == 0 ? 0 : boundary(0);
+    const u64 e = x1 >= n ? n : boundary(RLW_H);
+#else
+    __shared__ u64 A[CAP + CAP / 16];
     const u64 s = x0 == 0 ? 0 : rl_boundary(keys, n, x0, pshift, RLW_CAP - RLW_H);
     const u64 e = x1 >= n ? n : rl_boundary(keys, n, x1, pshift, RLW_CAP - RLW_H);
+#endif
     if (lane == 0) bnd[blockIdx.x] = s;
     if (s >= e) { if (lane == 0) tcnt[blockIdx.x] = 0; return; }
     if (e - s > CAP) {
@@ -985,11 +1030,25 @@ __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ ke
         return;                               // rs_local_unfit_kernel takes the stretch from the list (and tests its order there)
     }
     const u32 cnt = (u32)(e - s);
-    // LDS operations of one wave execute in order: no barrier between the writes and the reads of its own tile
-    for (u32 i = lane; i < CAP; i += 64) A[RL_PAD(i)] = i < cnt ? keys[s + i] : ~0ull;
     u64 k[KPT];
+    // LDS operations of one wave execute in order: no barrier between the writes and the reads of its own tile
+#if RLW_WINDOW
+    if (s - x0 + 1 + cnt <= WN) {
+        const u32 off = (u32)(s - x0) + 1u;                       // slot of the tile's first key
+#pragma unroll
+        for (int r = 0; r < KPT; r++) k[r] = lane * KPT + r < cnt ? A[RL_PAD(off + lane * KPT + r)] : ~0ull;
+    } else {
+        // the tile starts behind the reach (the bucket of the raster point is a long one, its end was found by
+        // bisection) and ends outside the window: read it from where it lies
+        for (u32 i = lane; i < CAP; i += 64) A[RL_PAD(i)] = i < cnt ? keys[s + i] : ~0ull;
+#pragma unroll
+        for (int r = 0; r < KPT; r++) k[r] = A[RL_PAD(lane * KPT + r)];
+    }
+#else
+    for (u32 i = lane; i < CAP; i += 64) A[RL_PAD(i)] = i < cnt ? keys[s + i] : ~0ull;
 #pragma unroll
     for (int r = 0; r < KPT; r++) k[r] = A[RL_PAD(lane * KPT + r)];
+#endif
     rlw_sort(k, lane);
 #pragma unroll
     for (int r = 0; r < KPT; r++) A[RL_PAD(lane * KPT + r)] = k[r];
