@@ -9,11 +9,12 @@ sys.path.insert(0, ROOT)
 SHM = "/dev/shm/debwt_ab"
 
 
-def child(label, tune, reps, h2h):
+def child(label, tune, reps, cap):
     import numpy as np, time
     from debwt_amd import api
     words = np.load(SHM + "_words.npy"); sep = np.load(SHM + "_sep.npy"); n = int(np.load(SHM + "_n.npy")[0])
     d = api.DeBWT(k=32, tune=tune)
+    if cap: d.set_range_cap(cap)
     t0 = time.perf_counter(); d.load_packed(words, n, sep); d.build(); first = time.perf_counter() - t0
     best, wall = None, 1e9
     for it in range(reps):
@@ -38,11 +39,12 @@ def main():
     ap.add_argument("--tune", type=int, default=0)
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--child", default=None)
+    ap.add_argument("--cap", type=int, default=0, help="range cap (node instances per key range): several ranges on a small text")
     ap.add_argument("--keep", action="store_true", help="leave the generated text in /dev/shm (for a profiled --child run)")
     ap.add_argument("libs", nargs="*")
     a = ap.parse_args()
     if a.child is not None:
-        return child(a.child, a.tune, a.reps, False)
+        return child(a.child, a.tune, a.reps, a.cap)
     import numpy as np, time
     from debwt_amd import synth_native as SN
     t0 = time.perf_counter()
@@ -62,7 +64,7 @@ def main():
             if name != "default":
                 env["DEBWT_HIP_LIB"] = os.path.join(ROOT, "build", "variants", f"libdebwt_{name}.so")
             rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--child", lib, "--tune", tune or str(a.tune),
-                                  "--reps", str(a.reps)], env=env)
+                                  "--reps", str(a.reps), "--cap", str(a.cap)], env=env)
             if rc: print(lib, "FAILED rc", rc, flush=True)
     finally:
         for s in ("_words.npy", "_sep.npy", "_n.npy") if not a.keep else ():
