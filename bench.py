@@ -423,19 +423,23 @@ def main():
         chosen = acc["info"].get("keys", "rescan")
         other = "exchange" if chosen == "rescan" else "rescan"
         key_modes = {chosen: round(dt * 1e3 / args.steps, 3)}
-        state = {"why": f"not back within {args.other_mode_timeout} s"}
+        state = {"why": f"not back within {args.other_mode_timeout} s", "failed": False}
 
         def bail():
+            # a true timeout ends the run with the finished line and exit code 0; a rank that RAISED ends with exit code 1
+            # (its own watchdog, or at once when it is rank 0): CI must be able to tell a failed key path from a slow one
             if rank == 0:
                 key_modes[other] = f"dropped: {state['why']}"
                 line["key_modes_ms"] = key_modes
                 emit_line(line)
-            os._exit(0)
+            os._exit(1 if state["failed"] else 0)
 
         timer = threading.Timer(args.other_mode_timeout, bail)
         timer.daemon = True
         timer.start()
         try:
+            if os.environ.get("DEBWT_BENCH_FAIL_OTHER_MODE", "") == str(rank):   # tests: this rank's extra build raises
+                raise RuntimeError("injected failure of the extra key-path build")
             ws2 = SH.Workspace(d, device, mode=other)
             ws2.buf = shard_ws.buf                            # the same exchange buffers
             k2 = max(1, min(3, args.steps))
@@ -446,8 +450,14 @@ def main():
                                  f"'{other}' was timed over {k2} steps after one warm-up")
             timer.cancel()
         except Exception as e:                                # noqa: BLE001
-            state["why"] = f"rank {rank} failed: {e}"
-            threading.Event().wait()                          # the other ranks wait in a collective: the watchdogs end the run
+            state["why"] = f"rank {rank} failed: {type(e).__name__}: {e}"
+            state["failed"] = True
+            sys.stderr.write(f"bench.py: extra build of the '{other}' key path failed on rank {rank}: {e}\n")
+            if rank == 0:
+                timer.cancel()
+                bail()                                        # the line (with the exception text) now, exit code 1
+            threading.Event().wait()                          # the other ranks wait in a collective: the watchdogs end the run,
+                                                              # this rank's with exit code 1
         if rank == 0:
             line["key_modes_ms"] = key_modes
     if rank == 0:

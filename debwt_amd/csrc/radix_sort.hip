@@ -259,8 +259,8 @@ __global__ __launch_bounds__(RS_RADIX) void rs_scan_tot_kernel(u32 *__restrict__
 }
 
 // ---- scatter pass -----------------------------------------------------------------------------------
-// A workgroup of SC_NT threads ranks a tile of RS_TILE keys per iteration.  Tile layout: wave w owns items
-// [w*64*SC_ITEMS, ...), round r of it the 64 consecutive items at r*64 (one coalesced 512-byte load per round).
+// A workgroup of SC_NT threads ranks a tile of RS_TILE keys per iteration.  Tile layout: ranking unit u (32 lanes) owns
+// items [u*32*SC_ITEMS, ...), round r of it the 32 consecutive items at r*32 (a wave's load covers two stretches of 256 bytes).
 //
 // What bounds the pass is not the ranking but the write pattern: a tile holds ~16 keys per digit, so writing each
 // digit's run straight out means 128-byte pieces at arbitrary alignment, every output line is completed by two
@@ -277,15 +277,26 @@ __global__ __launch_bounds__(RS_RADIX) void rs_scan_tot_kernel(u32 *__restrict__
 #define SC_WAVES (SC_NT / 64)
 #define SC_LINE 16                     // keys per output line (128 bytes)
 
+// Ranking unit: RS_SUB lanes that share their peer-mask words (see rs_rank_tile).  Item layout of a tile: unit u owns
+// the items [u * RS_SUB * SC_ITEMS, ...), round r of it the RS_SUB consecutive items at r * RS_SUB -- with 32-lane units
+// a wave's load covers two stretches of 256 bytes per round.
+#ifndef RS_HALFWAVE
+#define RS_HALFWAVE 1
+#endif
+#define RS_SUB (RS_HALFWAVE ? 32u : 64u)
+#define SC_UNITS (SC_NT / RS_SUB)
+// offset of item (unit of this thread, round 0) inside a tile
+__device__ __forceinline__ u32 rs_item0() {
+    return (threadIdx.x / RS_SUB) * (RS_SUB * SC_ITEMS) + (threadIdx.x % RS_SUB);
+}
 template <int SRC>
 __device__ __forceinline__ u32 rs_load_tile(const u64 *__restrict__ in, const TextKeySrc &ts, u64 tile, u64 end,
                                             u64 (&key)[SC_ITEMS]) {
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const u64 wbase = tile + (u64)w * (64u * SC_ITEMS);
+    const u64 wbase = tile + rs_item0();
     u32 vmask = 0;
 #pragma unroll
     for (int r = 0; r < SC_ITEMS; r++) {
-        u64 idx = wbase + (u64)r * 64u + lane;
+        u64 idx = wbase + (u64)r * RS_SUB;
         if (rs_load_key<SRC>(in, ts, idx, end, &key[r])) vmask |= 1u << r;
     }
     return vmask;
@@ -305,9 +316,9 @@ struct __attribute__((aligned(8))) ScHead { u32 a0; unsigned short ls; u8 cc, nh
 struct __attribute__((aligned(8))) ScBody { u32 delta; short lo, fl; };
 
 struct ScShared {
-    u64 skeys[RS_TILE];                   // the tile grouped by digit; its first 8*SC_WAVES*256 bytes double as peer masks
+    u64 skeys[RS_TILE];                   // the tile grouped by digit; doubles as rank state: one word per (unit, digit)
     u64 carry[RS_RADIX][SC_LINE];
-    unsigned short wavecnt[SC_WAVES][RS_RADIX];   // counts, then first slots (< RS_TILE)
+    unsigned short wavecnt[SC_UNITS][RS_RADIX];   // first slots (< RS_TILE) of the (unit, digit) runs; full-wave units: counts first
     ScHead head[RS_RADIX];
     ScBody body[RS_RADIX];
     u32 run[RS_RADIX];                    // absolute output position of the digit's next key
@@ -315,9 +326,13 @@ struct ScShared {
     u32 scan_tmp[SC_WAVES + 1];
 };
 
-// counters and peer masks (the masks alias the first SC_WAVES*256 slots of skeys) to zero
+// rank state (aliases the first SC_UNITS*256 slots of skeys) to zero
 __device__ __forceinline__ void rs_clear_rank_state(ScShared &sh) {
-    for (u32 i = threadIdx.x; i < SC_WAVES * RS_RADIX; i += SC_NT) { (&sh.wavecnt[0][0])[i] = 0; sh.skeys[i] = 0ull; }
+    static_assert(SC_UNITS * RS_RADIX <= RS_TILE, "the rank state fits the tile buffer");
+    for (u32 i = threadIdx.x; i < SC_UNITS * RS_RADIX; i += SC_NT) {
+        if (!RS_HALFWAVE) (&sh.wavecnt[0][0])[i] = 0;
+        sh.skeys[i] = 0ull;
+    }
 }
 
 // Ranks one loaded tile and stages it in sh.skeys grouped by digit (stable); fills head/body for the flush and
@@ -331,9 +346,34 @@ template <int FIXED0, int FULL>
 __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmask, const RsDigit &dg, ScShared &sh,
                                             u32 oalign, u32 nrounds = SC_ITEMS) {
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    // rank state is clear: rs_clear_rank_state ran during the previous tile's flush
+    u32 pk[SC_ITEMS];                         // rank inside the unit's digit run | digit << 16
+#if RS_HALFWAVE
+    // One 64-bit word per (32-lane unit, digit): the peer mask of the current round in its low half, the unit's count of
+    // the digit so far in its high half.  A lane ORs its bit into the low half (32-bit LDS atomic), reads the word back --
+    // mask and count in one read -- and the first peer stores count + peers with the mask cleared: three LDS operations
+    // and 20 bytes per key where full-wave masks with separate counters took five and 28 (the pass is bound by the LDS
+    // pipe: 60 % of its cycles at 4096 keys per tile).
+    u64 *wword = sh.skeys + (tid >> 5) * RS_RADIX;
+    const u32 lbit = 1u << (tid & 31u);
+#pragma unroll
+    for (int r = 0; r < SC_ITEMS; r++) {
+        if (!FULL && (u32)r >= nrounds) { pk[r] = 0; continue; }       // (workgroup-uniform) no keys in this round
+        const bool valid = FULL || ((vmask >> r) & 1u);
+        const u32 d = rs_digit<FIXED0>(dg, key[r]);
+        if (valid) __hip_atomic_fetch_or(reinterpret_cast<u32 *>(&wword[d]), lbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();
+        const u64 cm = valid ? __hip_atomic_load(&wword[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+        const u32 m = (u32)cm, base = (u32)(cm >> 32);
+        const u32 before = (u32)__popc(m & (lbit - 1u));
+        pk[r] = (base + before) | (d << 16);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0)
+            __hip_atomic_store(&wword[d], (u64)(base + (u32)__popc(m)) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_sched_barrier(0);    // keep a round's arithmetic inside the round (register pressure)
+    }
+#else
     u64 *wmask = sh.skeys + w * RS_RADIX;
-    // counters and peer masks are clear: rs_clear_rank_state ran during the previous tile's flush
-    u32 pk[SC_ITEMS];                         // rank inside the wave's digit run | digit << 16
     const u64 lbit = 1ull << lane;
 #pragma unroll
     for (int r = 0; r < SC_ITEMS; r++) {
@@ -353,12 +393,16 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
         }
         __builtin_amdgcn_sched_barrier(0);    // keep a round's arithmetic inside the round (register pressure)
     }
+#endif
     lds_barrier();
     // digit d = thread d: counts of the waves -> first LDS slot of every (wave, digit) run; flush parameters
-    u32 len = 0, c[SC_WAVES];
+    u32 len = 0, c[SC_UNITS];
     if (tid < RS_RADIX) {
 #pragma unroll
-        for (u32 i = 0; i < SC_WAVES; i++) { c[i] = sh.wavecnt[i][tid]; len += c[i]; }
+        for (u32 i = 0; i < SC_UNITS; i++) {
+            c[i] = RS_HALFWAVE ? reinterpret_cast<const u32 *>(&sh.skeys[i * RS_RADIX + tid])[1] : (u32)sh.wavecnt[i][tid];
+            len += c[i];
+        }
     }
     u32 incl = wave_scan_incl(len);
     if (lane == 63) sh.scan_tmp[w] = incl;
@@ -370,7 +414,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
         for (u32 i = 0; i < RS_RADIX / 64; i++) { u32 t = sh.scan_tmp[i]; if (i < w) ls += t; tile_total += t; }
         u32 acc = ls;
 #pragma unroll
-        for (u32 i = 0; i < SC_WAVES; i++) { sh.wavecnt[i][tid] = (unsigned short)acc; acc += c[i]; }
+        for (u32 i = 0; i < SC_UNITS; i++) { sh.wavecnt[i][tid] = (unsigned short)acc; acc += c[i]; }
         const u32 run = sh.run[tid], cc = sh.cc[tid];
         const u32 a0 = run - cc, e = run + len;
         const u32 ae = ((e + oalign) & ~(SC_LINE - 1u)) - oalign;           // last line boundary <= e
@@ -388,7 +432,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
     lds_barrier();
     u32 slot[SC_ITEMS];                       // all offset reads in flight, then the writes
 #pragma unroll
-    for (int r = 0; r < SC_ITEMS; r++) slot[r] = sh.wavecnt[w][pk[r] >> 16] + (pk[r] & 0xFFFFu);
+    for (int r = 0; r < SC_ITEMS; r++) slot[r] = sh.wavecnt[tid / RS_SUB][pk[r] >> 16] + (pk[r] & 0xFFFFu);
 #pragma unroll
     for (int r = 0; r < SC_ITEMS; r++)
         if (FULL || ((vmask >> r) & 1u)) sh.skeys[slot[r]] = key[r];
@@ -448,7 +492,7 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
     constexpr int DG = AUX ? 0 : (HI ? 2 : 1);
     __shared__ ScShared sh;
     __shared__ u64 stext[SRC ? RS_STEXT : 1], ssep[SRC ? RS_SSEP : 1];
-    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 tid = threadIdx.x;
     if (tid < RS_RADIX) {
         sh.run[tid] = offsets[(u64)tid * nchunks + blockIdx.x] + digit_base[tid];
         sh.cc[tid] = 0;
@@ -460,10 +504,10 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
     rs_clear_rank_state(sh);
     lds_barrier();
     u64 key[SC_ITEMS];
-    const u64 *src = in + (u64)w * (64u * SC_ITEMS) + lane;
+    const u64 *src = in + rs_item0();
     if (SRC == 0 && beg + RS_TILE <= end) {
 #pragma unroll
-        for (int r = 0; r < SC_ITEMS; r++) key[r] = src[beg + r * 64];
+        for (int r = 0; r < SC_ITEMS; r++) key[r] = src[beg + r * RS_SUB];
     }
     for (u64 tile = beg; tile < end; tile += RS_TILE) {
         int tot = RS_TILE;
@@ -472,7 +516,7 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
             rs_rank_tile<DG, 1>(key, 0xFFFFFFFFu, dg, sh, oalign);
             if (tile + 2 * RS_TILE <= end) {
 #pragma unroll
-                for (int r = 0; r < SC_ITEMS; r++) key[r] = src[tile + RS_TILE + r * 64];
+                for (int r = 0; r < SC_ITEMS; r++) key[r] = src[tile + RS_TILE + r * RS_SUB];
             }
         } else {
             u32 vmask = SRC ? rs_load_tile_text(ts, st, tile, end, key) : rs_load_tile<SRC>(in, ts, tile, end, key);
@@ -512,13 +556,17 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
                               const u32 *__restrict__ offsets, const u32 *__restrict__ digit_base, u32 nchunks) {
     constexpr int DG = AUX ? 0 : (HI ? 2 : 1);
     __shared__ ScShared sh;
-    __shared__ u8 stab[AUX ? 4096 : 4];
+    __shared__ u32 stab[AUX ? 128 : 1];                        // one bit per 12-mer prefix bin: keys of the bin leave the slice in this round
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     if (tid < RS_RADIX) {
         sh.run[tid] = offsets[(u64)tid * nchunks + blockIdx.x] + digit_base[tid];
         sh.cc[tid] = 0;
     }
-    if (AUX) for (u32 i = tid; i < 4096; i += SC_NT) stab[i] = ts.bin_tab ? ts.bin_tab[i] : 0;
+    if (AUX && tid < 128) {
+        u32 bits = 0;
+        for (u32 b = 0; b < 32; b++) bits |= ((ts.bin_tab ? ts.bin_tab[tid * 32 + b] : 0) != 0xFFu ? 1u : 0u) << b;
+        stab[tid] = bits;
+    }
     const u32 oalign = (u32)(reinterpret_cast<uintptr_t>(out) >> 3) & (SC_LINE - 1u);
     const u64 beg = (u64)blockIdx.x * chunk;                  // a multiple of RS_TILE: word-aligned
     const u64 end = beg + chunk < n ? beg + chunk : n;
@@ -556,7 +604,7 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
             for (u32 t = 0; t < 32; t++) {
                 const u32 pre = t <= 26 ? (u32)(w0 >> (52 - 2 * t)) & 0xFFFu
                                         : (u32)(((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) >> 52);
-                const bool in = AUX ? stab[pre] != 0xFFu : (pre - lo12) < span12;
+                const bool in = AUX ? ((stab[pre >> 5] >> (pre & 31u)) & 1u) != 0u : (pre - lo12) < span12;
                 m |= (in ? 1u : 0u) << t;
             }
             if (sb) {                                          // a separator within 64 positions: rare, tested apart

@@ -217,6 +217,31 @@ def test_bench_extra_key_mode_cannot_cost_the_result():
     assert len(dropped) == 1, j["key_modes_ms"]
 
 
+@pytest.mark.parametrize("failing_rank", [0, 1])
+def test_bench_extra_key_mode_failure_is_an_error_not_a_timeout(failing_rank):
+    """A rank whose extra build RAISES ends the run with a non-zero exit code -- after rank 0 has printed the finished line
+    with the exception text (rank 0's own failure) or the watchdog's words (another rank's) -- so that a broken key path
+    cannot pass for a slow one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DEBWT_BENCH_FAIL_OTHER_MODE"] = str(failing_rank)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload",
+                        "ecoli_4.6M", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--other-mode-timeout", "20"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["value"] > 0 and j["check"]["inverse_bwt_ok"]
+    dropped = [v for v in j["key_modes_ms"].values() if isinstance(v, str) and v.startswith("dropped")]
+    assert len(dropped) == 1 and ("failed" in dropped[0]) == (failing_rank == 0), j["key_modes_ms"]
+    assert "injected failure" in r.stderr
+
+
 def test_bench_two_ranks_started_by_bench_itself_rccl():
     """The same over RCCL when the box has two GPUs (the driver's 8-GPU node; skipped on a one-GPU box)."""
     import torch
