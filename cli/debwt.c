@@ -1,18 +1,22 @@
 /*
  * debwt.c -- host program with the reference's command line over libdebwt_hip.so.
  *
- *   deBWT -o OUT [-t T] [-k K] [-j DIR] [--device D | --gpus G [--devices a,b,...] [--keys auto|exchange|rescan]] [--iupac SEED] INPUT.fa[.gz]
+ *   deBWT -o OUT [-t T] [-k K] [-j DIR] [--device D | --gpus G [--devices a,b,...] [--keys auto|exchange|rescan] [--exchange peer|rccl]] [--iupac SEED] INPUT.fa[.gz]
  *
  * Same contract as /root/reference/src/main.c:25-53,175-186: options are `flag value` pairs, INPUT last;
  * -k 12..32 (default 32); -t (default 8) = host threads of the FASTA ingest; -j accepted and ignored (no Jellyfish); OUT is probed by create+remove before any work
  * (src/main.c:55-58); exit status 0 on success, 1 with a message on stderr otherwise.  Output files OUT,
  * OUT.#, OUT.$ are those of src/insertCase3.c:115-131.
  */
+#include <fcntl.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "../include/debwt_hip.h"
 
@@ -30,23 +34,53 @@ static void usage(void) {
                     "--devices (optional): comma-separated GPU ordinals of the G shards (default 0,1,...; may repeat)\n"
                     "--keys (optional): with --gpus, how the k-mers reach their shard: exchange (alltoallv of the keys), rescan (every\n"
                     "       GPU reads its own copy of the text), auto (default: the cheaper one by the library's cost model)\n"
+                    "--exchange (optional): with --gpus, what carries the exchanges between the GPUs: peer (device-to-device copies,\n"
+                    "       default) or rccl (grouped ncclSend / ncclRecv over xGMI; one distinct GPU per shard)\n"
                     "--iupac (optional): seed; N and other ambiguity letters become pseudo-random bases of their sets\n"
                     "                    (what otherTool/transferN does, reproducibly)\n"
                     "reference: sequence in fasta format (plain or gzip)\n");
 }
 
-static double now(void) {
+double now(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
 
+/* a large file (the 7.5 GB of rows of a 30 Gbp collection) is written by several threads, each its slice at its offset */
+struct write_job { int fd; const char *p; size_t off, bytes; int rc; };
+static void *write_main(void *arg) {
+    struct write_job *j = arg;
+    while (j->bytes) {
+        ssize_t w = pwrite(j->fd, j->p + j->off, j->bytes > ((size_t)1 << 30) ? (size_t)1 << 30 : j->bytes, (off_t)j->off);
+        if (w <= 0) { j->rc = -1; return NULL; }
+        j->off += (size_t)w; j->bytes -= (size_t)w;
+    }
+    return NULL;
+}
 static int write_file(const char *path, const void *p, size_t bytes) {
-    FILE *f = fopen(path, "wb");
-    if (!f) { fprintf(stderr, "cannot create %s!\n", path); return -1; }
-    size_t w = fwrite(p, 1, bytes, f);
-    fclose(f);
-    return w == bytes ? 0 : -1;
+    enum { WT = 8 };
+    if (bytes < ((size_t)256 << 20)) {
+        FILE *f = fopen(path, "wb");
+        if (!f) { fprintf(stderr, "cannot create %s!\n", path); return -1; }
+        size_t w = fwrite(p, 1, bytes, f);
+        return (fclose(f) == 0 && w == bytes) ? 0 : -1;
+    }
+    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { fprintf(stderr, "cannot create %s!\n", path); return -1; }
+    struct write_job job[WT];
+    pthread_t th[WT];
+    int started[WT], rc = 0;
+    const size_t per = ((bytes + WT - 1) / WT + 4095) & ~(size_t)4095;
+    for (int i = 0; i < WT; i++) {
+        const size_t a = per * (size_t)i < bytes ? per * (size_t)i : bytes, b = a + per < bytes ? a + per : bytes;
+        job[i] = (struct write_job){fd, p, a, b - a, 0};
+        started[i] = b > a && pthread_create(&th[i], NULL, write_main, &job[i]) == 0;
+        if (b > a && !started[i]) write_main(&job[i]);                     /* no thread: this one writes the slice */
+    }
+    for (int i = 0; i < WT; i++) { if (started[i]) pthread_join(th[i], NULL); if (job[i].rc) rc = -1; }
+    if (close(fd)) rc = -1;
+    return rc;
 }
 
 /* the outputs of src/insertCase3.c:115-131 */
@@ -63,15 +97,35 @@ static int write_outputs(const char *obj, const uint64_t *bwt, uint64_t n, const
     return rc;
 }
 
+/* A one-shot program pays for its device memory (the driver clears what another process released, ~33 GiB/s): the helper
+ * thread allocates the workspace (debwt_reserve) and the page-locked output buffers while the main thread still reads and
+ * packs the FASTA file -- the file size bounds the text length. */
+struct reserve_job { debwt_ctx *ctx; uint64_t n_bound; uint64_t *bwt; int rc; double seconds; };
+double now(void);
+static void *reserve_main(void *arg) {
+    struct reserve_job *j = arg;
+    double t0 = now();
+    j->rc = debwt_reserve(j->ctx, j->n_bound, 1, 0.0, DEBWT_RESERVE_ONE_SHOT);
+    void *p = NULL;
+    if (debwt_pinned_alloc((size_t)((j->n_bound + 31) >> 5) * 8 + 64, &p) == DEBWT_OK) j->bwt = p;
+    j->seconds = now() - t0;
+    return NULL;
+}
+
 /* --gpus G: the same program over G GPUs (debwt_multi_*: one host thread per GPU inside the library) */
 static int multi_main(const char *source, const char *obj, int k, int threads, int iupac, unsigned long long seed, int gpus,
-                      const int *devs, int key_mode) {
+                      const int *devs, int key_mode, int exchange) {
     double t0 = now();
     debwt_config cfg = {k, 0, 0, 0};
     debwt_multi *m = NULL;
     int rc = debwt_multi_create(&cfg, devs, gpus, &m);
     if (rc) { fprintf(stderr, "debwt_multi_create (%d GPUs): %s\n", gpus, debwt_strerror(rc)); return 1; }
     debwt_multi_set_key_mode(m, key_mode);
+    if (exchange != DEBWT_EXCHANGE_PEER_COPY && (rc = debwt_multi_set_exchange(m, exchange))) {
+        fprintf(stderr, "--exchange rccl: %s %s\n", debwt_strerror(rc), debwt_multi_last_error(m));
+        debwt_multi_destroy(m);
+        return 1;
+    }
     double t1 = now();
     rc = debwt_multi_load_fasta(m, source, threads, iupac ? DEBWT_FASTA_IUPAC_RANDOM : 0u, seed);
     if (rc) {
@@ -92,9 +146,9 @@ static int multi_main(const char *source, const char *obj, int k, int threads, i
     double t4 = now();
     if (!rc) {
         printf("BWTLEN=%lu\n", (unsigned long)st.n);
-        printf("%u GPUs, keys %s, %u key round(s): init %.3f s, read+pack+load (%d threads) %.3f s, build %.3f s, fetch+write %.3f s; "
+        printf("%u GPUs, exchanges by %s, keys %s, %u key round(s): init %.3f s, read+pack+load (%d threads) %.3f s, build %.3f s, fetch+write %.3f s; "
                "shard 0 received %.3f GB of k-mers and %.3f GB of blue entries\n", st.ngpus,
-               st.key_mode == DEBWT_KEYS_EXCHANGE ? "exchanged" : "rescanned", st.rounds, t1 - t0, threads, t2 - t1,
+               st.exchange_backend == DEBWT_EXCHANGE_RCCL ? "RCCL send/recv groups" : "peer-to-peer copies", st.key_mode == DEBWT_KEYS_EXCHANGE ? "exchanged" : "rescanned", st.rounds, t1 - t0, threads, t2 - t1,
                t3 - t2, t4 - t3, st.key_bytes_in / 1e9, st.blue_bytes_in / 1e9);
         fprintf(stderr, "success output bwt!\n");
     } else fprintf(stderr, "fetch/write: %s\n", debwt_strerror(rc));
@@ -106,7 +160,7 @@ static int multi_main(const char *source, const char *obj, int k, int threads, i
 int main(int argc, char **argv) {
     if (argc < 4 || (argc & 1) == 1) { usage(); return 1; }            /* src/main.c:25 */
     const char *source = argv[argc - 1], *obj = NULL;
-    int k = 32, device = 0, iupac = 0, gpus = 0, devs[256], ndevs = 0, key_mode = -1;
+    int k = 32, device = 0, iupac = 0, gpus = 0, devs[256], ndevs = 0, key_mode = -1, exchange = DEBWT_EXCHANGE_PEER_COPY;
     unsigned long long iupac_seed = 0;
     long threads = 8;
     for (int i = 1; i < argc - 1; i += 2) {
@@ -142,6 +196,11 @@ int main(int argc, char **argv) {
             else if (!strcmp(argv[i + 1], "auto")) key_mode = -1;
             else { usage(); return 1; }
         }
+        else if (!strcmp(argv[i], "--exchange")) {
+            if (!strcmp(argv[i + 1], "rccl")) exchange = DEBWT_EXCHANGE_RCCL;
+            else if (!strcmp(argv[i + 1], "peer")) exchange = DEBWT_EXCHANGE_PEER_COPY;
+            else { usage(); return 1; }
+        }
         else if (!strcmp(argv[i], "--iupac")) { iupac = 1; iupac_seed = strtoull(argv[i + 1], NULL, 10); }
         else { usage(); return 1; }
     }
@@ -158,44 +217,82 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (gpus) return multi_main(source, obj, k, (int)(threads > 256 ? 256 : threads), iupac, iupac_seed, gpus,
-                                ndevs ? devs : NULL, key_mode);
+                                ndevs ? devs : NULL, key_mode, exchange);
     double t0 = now();
     debwt_config cfg = {k, device, 0, 0};
     debwt_ctx *ctx = NULL;
     int rc = debwt_create(&cfg, &ctx);
     if (rc) { fprintf(stderr, "debwt_create: %s\n", debwt_strerror(rc)); return 1; }
     double t1 = now();
+    /* workspace and output buffer on a helper thread while the file is read (plain FASTA: a base takes a byte of the file) */
+    struct reserve_job job = {ctx, 0, NULL, 0, 0.0};
+    pthread_t helper;
+    int have_helper = 0;
+    {
+        struct stat sb;
+        size_t sl = strlen(source);
+        int gz = sl > 3 && !strcmp(source + sl - 3, ".gz");
+        if (!gz && stat(source, &sb) == 0 && sb.st_size > 64) {
+            job.n_bound = (uint64_t)sb.st_size + 1;
+            have_helper = pthread_create(&helper, NULL, reserve_main, &job) == 0;
+        }
+    }
     /* the reference's collect (src/collect#$.c:34-90): here `threads` host threads parse and pack the file */
-    rc = debwt_load_fasta_opts(ctx, source, (int)(threads > 256 ? 256 : threads), iupac ? DEBWT_FASTA_IUPAC_RANDOM : 0u, iupac_seed);
+    debwt_packed_text pt;
+    char msg[256] = "";
+    rc = debwt_pack_fasta_opts(source, (int)(threads > 256 ? 256 : threads), iupac ? DEBWT_FASTA_IUPAC_RANDOM : 0u, iupac_seed, &pt,
+                               msg, sizeof msg);
+    double t1b = now();
+    if (have_helper) pthread_join(helper, NULL);
+    double t1c = now();
+    if (!rc) { rc = debwt_load_text(ctx, pt.words, pt.n, pt.sep, pt.nrec); if (rc) snprintf(msg, sizeof msg, "%s", debwt_last_error(ctx)); }
     if (rc) {
-        fprintf(stderr, "%s (sequence must be ACGT only unless --iupac is given, records > 32 bases)\n", debwt_last_error(ctx));
+        fprintf(stderr, "%s (sequence must be ACGT only unless --iupac is given, records > 32 bases)\n", msg);
+        if (job.bwt) debwt_pinned_free(job.bwt);
+        debwt_free_packed(&pt);
         debwt_destroy(ctx);
         return 1;
     }
     double t2 = now();
-    rc = debwt_build(ctx);
-    if (rc) { fprintf(stderr, "build: %s %s\n", debwt_strerror(rc), debwt_last_error(ctx)); debwt_destroy(ctx); return 1; }
+    const uint64_t n = pt.n, nrec = pt.nrec;
+    size_t nw = (size_t)((n + 31) >> 5);
+    /* rows of finished key ranges travel to the host while the next range is sorted (debwt_build_to_host) */
+    uint64_t *bwt = job.bwt, *hash_rows = malloc((nrec ? nrec : 1) * 8), dollar = 0;
+    int bwt_pinned = bwt != NULL;
+    if (!bwt) bwt = malloc(nw * 8);
+    rc = (bwt && hash_rows) ? debwt_build_to_host(ctx, bwt, hash_rows, &dollar) : DEBWT_ENOMEM;
+    if (rc) fprintf(stderr, "build: %s %s\n", debwt_strerror(rc), debwt_last_error(ctx));
     double t3 = now();
     debwt_stats st;
     debwt_get_stats(ctx, &st);
-    const uint64_t n = st.n, nrec = st.nrec;
-    size_t nw = (size_t)((n + 31) >> 5);
-    uint64_t *bwt = malloc(nw * 8), *hash_rows = malloc((nrec ? nrec : 1) * 8), dollar = 0;
-    rc = (bwt && hash_rows) ? debwt_fetch_bwt(ctx, bwt, hash_rows, &dollar) : DEBWT_ENOMEM;
-    if (rc) fprintf(stderr, "fetch: %s\n", debwt_strerror(rc));
-    else if (write_outputs(obj, bwt, n, hash_rows, nrec, dollar)) rc = DEBWT_EINVAL;   /* src/insertCase3.c:115-131 */
-    if (rc) { free(bwt); free(hash_rows); debwt_destroy(ctx); return 1; }
+    if (!rc && write_outputs(obj, bwt, n, hash_rows, nrec, dollar)) rc = DEBWT_EINVAL;   /* src/insertCase3.c:115-131 */
+    if (rc) {
+        if (bwt_pinned) debwt_pinned_free(bwt); else free(bwt);
+        free(hash_rows);
+        debwt_free_packed(&pt);
+        debwt_destroy(ctx);
+        return 1;
+    }
     double t4 = now();
     printf("BWTLEN=%lu\n", (unsigned long)st.n);                           /* src/collect#$.c:59 */
     printf("the case3num is %lu\nthe blueBoundNum is %lu\nthe redCapacity is %lu\nthe blueCapacity is %lu\n",
            (unsigned long)st.case3num, (unsigned long)st.blue_bound_num, (unsigned long)st.red_capacity,
            (unsigned long)st.blue_capacity);                               /* src/generateSP.c:28-31 */
-    printf("device init %.3f s, read+pack+load (%ld threads) %.3f s, build %.3f s (device %.3f ms: extract %.2f sort %.2f classify %.2f "
-           "SP %.2f blue %.2f assemble %.2f), write %.3f s\n",
-           t1 - t0, threads, t2 - t1, t3 - t2, st.ms_total, st.ms_extract, st.ms_sort, st.ms_classify, st.ms_sp, st.ms_blue,
-           st.ms_assemble, t4 - t3);
+    printf("device init %.3f s, read+pack (%ld threads) %.3f s [workspace reserved beside it in %.3f s, %.3f s of that after the "
+           "parse], load %.3f s, build+fetch %.3f s (device %.3f ms: extract %.2f sort %.2f classify %.2f SP %.2f blue %.2f "
+           "assemble %.2f), write %.3f s\n",
+           t1 - t0, threads, t1b - t1, job.seconds, t1c - t1b, t2 - t1c, t3 - t2, st.ms_total, st.ms_extract, st.ms_sort,
+           st.ms_classify, st.ms_sp, st.ms_blue, st.ms_assemble, t4 - t3);
     fprintf(stderr, "success output bwt!\n");
+    if (n > ((uint64_t)1 << 30) && !getenv("DEBWT_CLI_TEARDOWN")) {
+        /* the files are written and closed: a one-shot program leaves the hundreds of GB of device memory and page-locked
+         * buffers to the operating system instead of unmapping them one by one first (1.5 s at 30 Gbp) */
+        fflush(stdout); fflush(stderr);
+        _exit(0);
+    }
+    if (bwt_pinned) debwt_pinned_free(bwt); else free(bwt);
+    free(hash_rows);
+    debwt_free_packed(&pt);
     debwt_destroy(ctx);
-    free(bwt); free(hash_rows);
     return 0;
 }

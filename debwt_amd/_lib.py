@@ -48,7 +48,7 @@ class DebwtVerifyReport(ctypes.Structure):
 class DebwtMultiStats(ctypes.Structure):
     _fields_ = [("n", ctypes.c_uint64), ("nrec", ctypes.c_uint64), ("ngpus", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
                 ("key_bytes_in", ctypes.c_uint64), ("blue_bytes_in", ctypes.c_uint64), ("ms_build", ctypes.c_float),
-                ("key_mode", ctypes.c_uint32)]
+                ("key_mode", ctypes.c_uint32), ("exchange_backend", ctypes.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -67,7 +67,7 @@ SYMBOLS = [
     "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_verify_device", "debwt_multi_create", "debwt_multi_destroy", "debwt_multi_last_error",
     "debwt_multi_load_text", "debwt_multi_load_fasta", "debwt_multi_build", "debwt_multi_fetch_bwt", "debwt_multi_get_stats",
     "debwt_multi_verify", "debwt_multi_shard", "debwt_pinned_alloc", "debwt_pinned_free", "debwt_shard_key_mode",
-    "debwt_multi_set_key_mode", "debwt_special_compare", "debwt_build_to_host",
+    "debwt_multi_set_key_mode", "debwt_special_compare", "debwt_build_to_host", "debwt_multi_set_exchange", "debwt_reserve",
 ]
 
 
@@ -113,6 +113,8 @@ def lib():
         fn.argtypes = [vp]
     L.debwt_fetch_bwt.restype = ctypes.c_int
     L.debwt_fetch_bwt.argtypes = [vp, u64p, u64p, u64p]
+    L.debwt_reserve.restype = ctypes.c_int
+    L.debwt_reserve.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double, ctypes.c_uint]
     L.debwt_build_to_host.restype = ctypes.c_int
     L.debwt_build_to_host.argtypes = [vp, u64p, u64p, u64p]
     L.debwt_bwt_device_ptr.restype = ctypes.c_int
@@ -151,6 +153,8 @@ def lib():
                                        ctypes.POINTER(ctypes.c_double)]
     L.debwt_multi_set_key_mode.restype = ctypes.c_int
     L.debwt_multi_set_key_mode.argtypes = [vp, ctypes.c_int]
+    L.debwt_multi_set_exchange.restype = ctypes.c_int
+    L.debwt_multi_set_exchange.argtypes = [vp, ctypes.c_int]
     L.debwt_shard_ranges.restype = ctypes.c_int
     L.debwt_shard_ranges.argtypes = [vp, u32p, u64p, ctypes.c_uint32]
     L.debwt_shard_sort_begin.restype = ctypes.c_int

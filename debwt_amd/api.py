@@ -109,6 +109,11 @@ class DeBWT:
         st = self.stats()
         self.n, self.nrec = st["n"], st["nrec"]
 
+    def reserve(self, n, nrec, branching=0.0, one_shot=False):
+        """Allocate the workspace of a text of up to n symbols in nrec records ahead of the load (debwt_reserve): call it
+        on a thread of its own while the input is still being read -- ctypes releases the GIL for the call."""
+        self._chk(self._L.debwt_reserve(self._h, int(n), int(nrec), float(branching), 1 if one_shot else 0))
+
     def set_range_cap(self, max_instances):
         """Largest number of node instances sorted in one go; larger texts are built in k-mer-prefix ranges."""
         self._chk(self._L.debwt_set_range_cap(self._h, int(max_instances)))
@@ -260,6 +265,10 @@ class MultiDeBWT:
     def set_key_mode(self, mode):
         """"exchange", "rescan" or "auto" (the library's cost model decides): how the keys reach their shards."""
         self._chk(self._L.debwt_multi_set_key_mode(self._h, {"exchange": 0, "rescan": 1, "auto": -1}[mode]))
+
+    def set_exchange(self, backend):
+        """"peer" (device-to-device copies, the default) or "rccl" (grouped ncclSend / ncclRecv; one distinct GPU per shard)."""
+        self._chk(self._L.debwt_multi_set_exchange(self._h, {"peer": 0, "rccl": 1}[backend]))
 
     def build(self):
         self._chk(self._L.debwt_multi_build(self._h))

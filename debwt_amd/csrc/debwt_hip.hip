@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <new>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <atomic>
@@ -1457,6 +1458,81 @@ extern "C" int debwt_bwt_assemble(debwt_ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->dollar.p, 0xFF, 8, c->stream));
     run_assemble(c, nullptr);
     return assemble_finish(c);
+}
+
+// Device memory for a text of up to `n` symbols in `nrec` records, before the text is there.  What a cold build pays for is
+// not hipMalloc's work but the driver handing out memory another process released: beyond a pool of cleared pages it
+// clears on allocation, 30 ms per GiB on this system (profiles/r04_alloc_probe.txt: 6.2 s before the second 25-GiB block
+// of a process started right after one that held 250 GiB) -- seconds for the ~250 GB of a 30 Gbp build, whose kernels take 1.8 s.
+// A one-shot host calls this on a helper thread while it still reads and packs its input (the file size bounds n); the
+// buffers are those debwt_load_text and the stages would allocate, sized as they would size them, the data-dependent ones
+// (blue entries, SP code, sub-block tables) for `branching` of the positions being branching nodes (<= 0: 0.12; a text that
+// needs more grows them when it gets there).  Not to be called while another call on the context is running.
+extern "C" int debwt_reserve(debwt_ctx *c, uint64_t n, uint64_t nrec, double branching, unsigned flags) {
+    if (!c || n < 34 || nrec == 0 || n <= nrec * (uint64_t)c->K || (flags & ~DEBWT_RESERVE_ONE_SHOT)) return DEBWT_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (branching <= 0) branching = 0.12;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const u64 NS = nrec * (u64)c->K, M = n - NS;
+    const size_t tw = (size_t)((n + 63) >> 5) + 2, bw = (size_t)(n >> 6) + 3, ngroups = (size_t)((n + 31) >> 5);
+    ENSURE(c, c->text, tw * 8);
+    ENSURE(c, c->sepbits, bw * 8);
+    ENSURE(c, c->sep, nrec * 8);
+    ENSURE(c, c->head_keys, nrec * 8);
+    ENSURE(c, c->spkey, NS * 8);
+    ENSURE(c, c->sprow, NS * 8);
+    ENSURE(c, c->spchr, NS + 64);
+    ENSURE(c, c->bwt, ngroups * 8 + 64);
+    ENSURE(c, c->hmask, ngroups * 4 + 64);
+    ENSURE(c, c->hash_rows, nrec * 8 + 64);
+    ENSURE(c, c->mchar, (n - NS) + 64);
+    ENSURE(c, c->momask, ngroups * 4 + 64);
+    ENSURE(c, c->mimask, ngroups * 4 + 64);
+    // the key ranges as plan_ranges will cut them: the cap from the memory that is free now plus what the context holds
+    u64 cap = c->range_cap;
+    if (!cap) {
+        const u64 keep_n = c->n; c->n = n;
+        int rc = default_range_cap(c, 30, 4 * n + (8ull << 30), 0, &cap);
+        c->n = keep_n;
+        if (rc) return rc;
+        // A one-shot build that is being handed memory at the driver's clearing rate (the ~2 bytes per position above came
+        // slower than 10 ms per GiB) is better off with more, smaller key ranges: 30 bytes per key of range workspace at
+        // ~30 ms per GiB against ~34 ms per range and 30 Gbp for another first pass over the text -- the sum is least at
+        // P = sqrt(0.9 s x M / 1e9 / ms per range) ranges, but never more than RS_MAX_RANGES: beyond that the first-pass
+        // histograms of the ranges no longer come from one scan of the text (28 ranges at 30 Gbp: sort stage 2.1 s instead
+        // of 1.0 s, profiles/r04_cli_30G.txt).  16 ranges at 30 Gbp: 54 GB of range workspace instead of 125.  The cap stays
+        // with the context (debwt_set_range_cap).
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        const double gib = (double)(tw * 8 + bw * 8 + ngroups * 20 + (n - NS)) / (double)(1ull << 30);
+        if ((flags & DEBWT_RESERVE_ONE_SHOT) && gib > 4.0 && secs > 0.010 * gib) {
+            const double per_range_s = 0.034 * (double)n / 30e9 + 0.004;
+            const double P = std::min<double>(RS_MAX_RANGES, std::sqrt(30.0 * (double)(n - NS) / 35e9 / per_range_s));
+            const u64 want = (u64)((double)(n - NS) / std::max(1.0, P) * 1.02) + 1;   // (cuts fall on prefix bins: a little slack)
+            if (want < cap) { cap = std::max<u64>(want, 1ull << 26); c->range_cap = cap; c->plan_valid = false; }
+        }
+    }
+    cap = std::min<u64>(cap, 0xFFFFFFF0ull - 1);
+    u64 maxM = M;
+    if (M > cap) { const u64 P = (M + cap - 1) / cap, per = (M + P - 1) / P; maxM = std::min(cap, per + per / 16); }
+    ENSURE(c, c->keysA, maxM * 8 + 64);
+    ENSURE(c, c->keysB, maxM * 8 + 64);
+    ENSURE(c, c->rs_skew, (maxM / 2048 + 2) * 4);
+    ENSURE(c, c->rs_rle, radix_rle_ws_bytes(maxM));
+    ENSURE(c, c->dk, maxM * 8 + 64);
+    ENSURE(c, c->dstart, maxM * 4 + 64);
+    ENSURE(c, c->pflag, maxM + 64);
+    const u64 Best = (u64)((double)n * branching);
+    ENSURE(c, c->blue, Best * 8 + 64);
+    ENSURE(c, c->spsym, Best + 64);
+    ENSURE(c, c->spn, ((Best >> 6) + 3) * 24);
+    const u32 sub_cap = (u32)std::min<u64>(std::max<u64>(Best / 8, 1u << 16), 1u << 26);
+    ENSURE(c, c->sub_start, (size_t)sub_cap * 8);
+    ENSURE(c, c->sub_j0, (size_t)sub_cap * 8);
+    ENSURE(c, c->sub_freq, (size_t)sub_cap * 4);
+    ENSURE(c, c->sub_depth, (size_t)sub_cap * 4 + 16);
+    ENSURE(c, c->qlist, (std::min<u64>(SP_SLICE_GROUPS * 32, Best) + 64) * 4);
+    ENSURE(c, c->qwave, ((std::min<u64>(SP_SLICE_GROUPS, ngroups) + 63) / 64 + 2) * 8);
+    return DEBWT_OK;
 }
 
 extern "C" int debwt_build(debwt_ctx *c) {

@@ -9,6 +9,8 @@
 #include "../../include/debwt_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library is loaded on demand (dlopen), never linked
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -61,6 +63,35 @@ struct Rendezvous {
     }
 };
 
+// RCCL entry points, resolved at run time when a multi-GPU build asks for them (DEBWT_EXCHANGE_RCCL): the library has no
+// link-time dependency on RCCL, so it loads on hosts without it, and inside a process that already holds a copy (PyTorch
+// brings its own librccl.so.1) the loader hands back that one.
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load(std::string *err) {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { *err = std::string("RCCL is not available: ") + dlerror(); return false; }
+#define RCCL_SYM(f) f = reinterpret_cast<decltype(f)>(dlsym(lib, "nccl" #f)); if (!f) { *err = "librccl lacks nccl" #f; return false; }
+        RCCL_SYM(CommInitAll) RCCL_SYM(CommDestroy) RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd) RCCL_SYM(Send) RCCL_SYM(Recv)
+        RCCL_SYM(GetErrorString)
+#undef RCCL_SYM
+        return true;
+    }
+};
+// RCCL 2.26 (ROCm 7.0) drops the second half of a point-to-point message above 1 GiB: pieces of 512 MiB
+constexpr size_t RCCL_PIECE = (size_t)512 << 20;
+
 }  // namespace
 
 struct debwt_multi {
@@ -78,6 +109,9 @@ struct debwt_multi {
     std::string err;
     bool built = false;
     int key_mode = -1;                      // DEBWT_KEYS_EXCHANGE / DEBWT_KEYS_RESCAN, -1: debwt_shard_key_mode decides
+    int exchange_backend = DEBWT_EXCHANGE_PEER_COPY;
+    Rccl rccl;
+    std::vector<ncclComm_t> comm;           // one communicator per shard (ncclCommInitAll), created by the first RCCL build
     debwt_multi_stats st{};
     // what the threads publish for each other
     std::vector<std::vector<uint64_t>> hist, offs, boffs;
@@ -95,17 +129,48 @@ void set_err(debwt_multi *m, int r, const char *what) {
     if (m->err.empty()) m->err = std::string("shard ") + std::to_string(r) + ": " + what + ": " + debwt_last_error(m->ctx[r]);
 }
 
-// rank r pulls: for every source s, `cnt(s)` elements of `esz` bytes from src_ptr(s) + src_off(s) into dst, in source
-// order; returns the number of elements received, or -1
+// The exchange between two stages, called by every shard thread: shard d receives from every source s the cnt_of(s, d)
+// elements of `esz` bytes that start at element off_of(s, d) of ptr_of(s), in source order, into dst (may be NULL where
+// the shard receives nothing).  Returns the number of elements received, or -1.
+//   peer copies: the receiver pulls with device-to-device copies -- world x (world - 1) independent copies over xGMI;
+//   RCCL:        every shard posts its sends and receives in one group per 512-MiB piece (an alltoallv).
 template <class PtrOf, class OffOf, class CntOf>
-long long pull(debwt_multi *m, int r, void *dst, size_t esz, PtrOf ptr_of, OffOf off_of, CntOf cnt_of) {
+long long xchg(debwt_multi *m, int r, void *dst, size_t esz, PtrOf ptr_of, OffOf off_of, CntOf cnt_of) {
     (void)hipSetDevice(m->dev[r]);
+    const int G = m->G;
     uint64_t o = 0;
-    for (int s = 0; s < m->G; s++) {
-        const uint64_t c = cnt_of(s);
-        if (c && hipMemcpyAsync((char *)dst + o * esz, (const char *)ptr_of(s) + off_of(s) * esz, c * esz, hipMemcpyDefault,
-                                m->stream[r]) != hipSuccess) return -1;
-        o += c;
+    if (m->exchange_backend == DEBWT_EXCHANGE_PEER_COPY) {
+        for (int s = 0; s < G; s++) {
+            const uint64_t c = cnt_of(s, r);
+            if (c && hipMemcpyAsync((char *)dst + o * esz, (const char *)ptr_of(s) + off_of(s, r) * esz, c * esz, hipMemcpyDefault,
+                                    m->stream[r]) != hipSuccess) return -1;
+            o += c;
+        }
+        if (hipStreamSynchronize(m->stream[r]) != hipSuccess) return -1;
+        return (long long)o;
+    }
+    // every shard derives the same number of pieces from the published counts
+    size_t pieces = 0;
+    for (int s = 0; s < G; s++)
+        for (int d = 0; d < G; d++) pieces = std::max(pieces, (size_t)((cnt_of(s, d) * esz + RCCL_PIECE - 1) / RCCL_PIECE));
+    std::vector<uint64_t> roff(G);                                 // where source s lands in dst (bytes)
+    for (int s = 0; s < G; s++) { roff[s] = o * esz; o += cnt_of(s, r); }
+    for (size_t k = 0; k < pieces; k++) {
+        ncclResult_t e = m->rccl.GroupStart();
+        for (int d = 0; d < G && e == ncclSuccess; d++) {
+            const size_t bytes = cnt_of(r, d) * esz, a = std::min(bytes, k * RCCL_PIECE), b = std::min(bytes, (k + 1) * RCCL_PIECE);
+            if (b > a) e = m->rccl.Send((const char *)ptr_of(r) + off_of(r, d) * esz + a, b - a, ncclUint8, d, m->comm[r], m->stream[r]);
+        }
+        for (int s = 0; s < G && e == ncclSuccess; s++) {
+            const size_t bytes = cnt_of(s, r) * esz, a = std::min(bytes, k * RCCL_PIECE), b = std::min(bytes, (k + 1) * RCCL_PIECE);
+            if (b > a) e = m->rccl.Recv((char *)dst + roff[s] + a, b - a, ncclUint8, s, m->comm[r], m->stream[r]);
+        }
+        const ncclResult_t e2 = m->rccl.GroupEnd();
+        if (e != ncclSuccess || e2 != ncclSuccess) {
+            std::lock_guard<std::mutex> lk(m->rv.m);
+            if (m->err.empty()) m->err = std::string("RCCL exchange: ") + m->rccl.GetErrorString(e != ncclSuccess ? e : e2);
+            return -1;
+        }
     }
     if (hipStreamSynchronize(m->stream[r]) != hipSuccess) return -1;
     return (long long)o;
@@ -146,7 +211,7 @@ void shard_thread(debwt_multi *m, int r) {
     if (!rv.sync(rc)) return;
     size_t rounds = 0;
     for (int s = 0; s < G; s++) rounds = std::max(rounds, m->cuts[s].size() - 1);
-    if (r == 0) { m->st.rounds = (uint32_t)rounds; m->st.key_mode = (uint32_t)keys; }
+    if (r == 0) { m->st.rounds = (uint32_t)rounds; m->st.key_mode = (uint32_t)keys; m->st.exchange_backend = (uint32_t)m->exchange_backend; }
 
     // 2. the keys of the shard's ranges: read from the shard's own copy of the text (key rescan) ...
     if (!exchange) STEP(debwt_kmer_sort_rle(c), "kmer_sort_rle");
@@ -167,8 +232,8 @@ void shard_thread(debwt_multi *m, int r) {
         uint64_t nrecv = 0;
         for (int s = 0; s < G; s++) nrecv += m->offs[s][r + 1] - m->offs[s][r];
         rc = m->xb[r].ensure((nrecv + 64) * 8) ? 0 : DEBWT_ENOMEM;
-        if (!rc && pull(m, r, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s) { return m->offs[s][r]; },
-                        [&](int s) { return m->offs[s][r + 1] - m->offs[s][r]; }) < 0) rc = DEBWT_EDEVICE;
+        if (!rc && xchg(m, r, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s, int d) { return m->offs[s][d]; },
+                            [&](int s, int d) { return m->offs[s][d + 1] - m->offs[s][d]; }) < 0) rc = DEBWT_EDEVICE;
         if (r == 0) { uint64_t moved = 0; for (int s = 1; s < G; s++) moved += m->offs[s][1] - m->offs[s][0]; m->st.key_bytes_in += moved * 8; }
         if (!rv.sync(rc)) return;                                   // every pull is done: the send buffers are free again
         if (t + 1 < m->cuts[r].size()) STEP(debwt_shard_sort_range(c, (uint32_t)t, (uint64_t *)m->xb[r].p, nrecv), "shard_sort_range");
@@ -189,8 +254,8 @@ void shard_thread(debwt_multi *m, int r) {
         first_block[s + 1] = first_block[s] + (uint32_t)m->nblocks[s];
     }
     rc = m->allfacts[r].ensure((allf + 1) * 8) ? 0 : DEBWT_ENOMEM;
-    if (!rc && pull(m, r, m->allfacts[r].p, 8, [&](int s) { return m->facts[s].p; }, [&](int) { return (uint64_t)0; },
-                    [&](int s) { return m->nfacts[s]; }) < 0) rc = DEBWT_EDEVICE;
+    if (!rc && xchg(m, r, m->allfacts[r].p, 8, [&](int s) { return m->facts[s].p; }, [&](int, int) { return (uint64_t)0; },
+                        [&](int s, int) { return m->nfacts[s]; }) < 0) rc = DEBWT_EDEVICE;
     if (!rc) STEP(debwt_shard_classify_global(c, (const uint64_t *)m->allfacts[r].p, allf, qbase, btotal), "shard_classify_global");
 
     // 4. SP code of the slices, symbols gathered everywhere
@@ -203,8 +268,8 @@ void shard_thread(debwt_multi *m, int r) {
     if (!rc) STEP(debwt_shard_sp_emit(c, sp_off, (uint8_t *)m->sp[r].p, m->sp[r].cap), "shard_sp_emit");
     if (!rv.sync(rc)) return;
     rc = m->allsp[r].ensure(sp_total + 64) ? 0 : DEBWT_ENOMEM;
-    if (!rc && pull(m, r, m->allsp[r].p, 1, [&](int s) { return m->sp[s].p; }, [&](int) { return (uint64_t)0; },
-                    [&](int s) { return m->slen[s]; }) < 0) rc = DEBWT_EDEVICE;
+    if (!rc && xchg(m, r, m->allsp[r].p, 1, [&](int s) { return m->sp[s].p; }, [&](int, int) { return (uint64_t)0; },
+                        [&](int s, int) { return m->slen[s]; }) < 0) rc = DEBWT_EDEVICE;
     if (!rc) STEP(debwt_shard_sp_import(c, (const uint8_t *)m->allsp[r].p, sp_total), "shard_sp_import");
 
     // 5. blue entries of the slice -> the owners of their blocks
@@ -215,8 +280,8 @@ void shard_thread(debwt_multi *m, int r) {
     uint64_t brecv = 0;
     for (int s = 0; s < G; s++) brecv += m->boffs[s][r + 1] - m->boffs[s][r];
     rc = m->xb[r].ensure((brecv + 64) * 8) ? 0 : DEBWT_ENOMEM;
-    if (!rc && pull(m, r, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s) { return m->boffs[s][r]; },
-                    [&](int s) { return m->boffs[s][r + 1] - m->boffs[s][r]; }) < 0) rc = DEBWT_EDEVICE;
+    if (!rc && xchg(m, r, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s, int d) { return m->boffs[s][d]; },
+                        [&](int s, int d) { return m->boffs[s][d + 1] - m->boffs[s][d]; }) < 0) rc = DEBWT_EDEVICE;
     if (r == 0) { uint64_t moved = 0; for (int s = 1; s < G; s++) moved += m->boffs[s][1] - m->boffs[s][0]; m->st.blue_bytes_in = moved * 8; }
     if (!rv.sync(rc)) return;
     STEP(debwt_shard_blue_place(c, (uint64_t *)m->xb[r].p, brecv), "shard_blue_place");
@@ -236,10 +301,12 @@ void shard_thread(debwt_multi *m, int r) {
     if (!rc) STEP(debwt_shard_fetch(c, nullptr, m->hrows[r].data(), &m->drow[r]), "shard_fetch");
     m->hrows[r].resize(m->nhash[r]);
     if (!rv.sync(rc)) return;
+    if (r == 0) rc = (m->parts.ensure(maxw * G * 8) && m->out.ensure(((m->n + 31) / 32 + 1) * 8)) ? 0 : DEBWT_ENOMEM;
+    if (m->exchange_backend == DEBWT_EXCHANGE_RCCL && !rv.sync(rc)) return;      // (a gather: everybody sends, the first GPU receives)
+    if (!rc && (r == 0 || m->exchange_backend == DEBWT_EXCHANGE_RCCL) &&
+        xchg(m, r, r == 0 ? m->parts.p : nullptr, 8, [&](int s) { return m->part[s].p; }, [&](int, int) { return (uint64_t)0; },
+                 [&](int, int d) { return d == 0 ? maxw : (uint64_t)0; }) < 0) rc = DEBWT_EDEVICE;
     if (r == 0) {
-        rc = (m->parts.ensure(maxw * G * 8) && m->out.ensure(((m->n + 31) / 32 + 1) * 8)) ? 0 : DEBWT_ENOMEM;
-        if (!rc && pull(m, 0, m->parts.p, 8, [&](int s) { return m->part[s].p; }, [&](int) { return (uint64_t)0; },
-                        [&](int) { return maxw; }) < 0) rc = DEBWT_EDEVICE;
         std::vector<uint64_t> poff(G), pbase(G), prows(G);
         for (int s = 0; s < G; s++) { poff[s] = maxw * s; pbase[s] = m->rowbase[s]; prows[s] = m->rows[s]; }
         if (!rc) STEP(debwt_concat_rows(c, (const uint64_t *)m->parts.p, (uint32_t)G, poff.data(), pbase.data(), prows.data(), m->n,
@@ -312,6 +379,7 @@ extern "C" void debwt_multi_destroy(debwt_multi *m) {
         if (m->ctx[r]) debwt_destroy(m->ctx[r]);
     }
     m->parts.release(); m->out.release();
+    for (ncclComm_t cm : m->comm) if (cm) (void)m->rccl.CommDestroy(cm);
     if (m->own.words) debwt_free_packed(&m->own);
     delete m;
 }
@@ -345,6 +413,23 @@ extern "C" int debwt_multi_load_fasta(debwt_multi *m, const char *path, int thre
 extern "C" int debwt_multi_set_key_mode(debwt_multi *m, int key_mode) {
     if (!m || key_mode < -1 || key_mode > DEBWT_KEYS_RESCAN) return DEBWT_EINVAL;
     m->key_mode = key_mode;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_multi_set_exchange(debwt_multi *m, int backend) {
+    if (!m || (backend != DEBWT_EXCHANGE_PEER_COPY && backend != DEBWT_EXCHANGE_RCCL)) return DEBWT_EINVAL;
+    if (backend == DEBWT_EXCHANGE_RCCL) {
+        for (int a = 0; a < m->G; a++)
+            for (int b = a + 1; b < m->G; b++)
+                if (m->dev[a] == m->dev[b]) { m->err = "RCCL needs one GPU per shard (a device ordinal repeats)"; return DEBWT_EINVAL; }
+        if (!m->rccl.load(&m->err)) return DEBWT_EDEVICE;
+        if (m->comm.empty()) {
+            m->comm.assign(m->G, nullptr);
+            const ncclResult_t e = m->rccl.CommInitAll(m->comm.data(), m->G, m->dev.data());
+            if (e != ncclSuccess) { m->comm.clear(); m->err = std::string("ncclCommInitAll: ") + m->rccl.GetErrorString(e); return DEBWT_EDEVICE; }
+        }
+    }
+    m->exchange_backend = backend;
     return DEBWT_OK;
 }
 

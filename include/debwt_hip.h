@@ -112,6 +112,19 @@ int debwt_pack_fasta_opts(const char *path, int threads, unsigned flags, uint64_
                           char *errbuf, size_t errlen);
 int debwt_load_fasta_opts(debwt_ctx *ctx, const char *path, int threads, unsigned flags, uint64_t seed);
 
+/* Device memory for a text of up to n symbols in nrec records, allocated before the text is there: a one-shot host (the
+ * reference is one: src/main.c:16-173) calls this on a helper thread while it still reads and packs its input, so that the
+ * seconds the driver takes to hand out a few hundred GB (it clears what another process released) pass behind the
+ * ingest instead of inside the first build.  branching: expected fraction of positions that are branching nodes, sizes the
+ * data-dependent buffers (<= 0: 0.12); everything grows later if the text needs more.  Optional: without it the same
+ * buffers are allocated by debwt_load_text and the stages.  Not re-entrant with other calls on the context.
+ * DEBWT_RESERVE_ONE_SHOT: the context will build once.  When the first buffers arrive at the driver's clearing rate (the
+ * memory was another process's a moment ago) the text is cut into more, smaller key ranges than a context that is reused
+ * would take -- less workspace to wait for, a few more passes over the text (the choice stays with the context like a
+ * debwt_set_range_cap). */
+#define DEBWT_RESERVE_ONE_SHOT 1u
+int debwt_reserve(debwt_ctx *ctx, uint64_t n, uint64_t nrec, double branching, unsigned flags);
+
 /* Texts whose node instances (one 8-byte key per base) do not fit HBM at once, or number 2^32 or more, are built
  * in key ranges: prefix ranges of the k-mer space holding at most `max_instances` keys each, sorted and classified
  * one after the other over the resident 2-bit text -- the single-GPU form of SURVEY 8e's bucket sharding (the
@@ -270,6 +283,7 @@ typedef struct {
     uint64_t blue_bytes_in;          /* bytes of blue entries shard 0 pulled from the other shards */
     float ms_build;                  /* wall time of debwt_multi_build */
     uint32_t key_mode;               /* DEBWT_KEYS_EXCHANGE or DEBWT_KEYS_RESCAN: how the keys reached their shards */
+    uint32_t exchange_backend;       /* DEBWT_EXCHANGE_PEER_COPY or DEBWT_EXCHANGE_RCCL: what moved the data between the shards */
 } debwt_multi_stats;
 int debwt_multi_create(const debwt_config *cfg, const int *devices, int ngpus, debwt_multi **out);   /* cfg->device unused */
 void debwt_multi_destroy(debwt_multi *m);
@@ -279,6 +293,13 @@ int debwt_multi_load_text(debwt_multi *m, const uint64_t *packed, uint64_t n, co
 int debwt_multi_load_fasta(debwt_multi *m, const char *path, int threads, unsigned flags, uint64_t seed);
 /* DEBWT_KEYS_EXCHANGE / DEBWT_KEYS_RESCAN, or -1 (the default): debwt_shard_key_mode decides at every build */
 int debwt_multi_set_key_mode(debwt_multi *m, int key_mode);
+/* What carries the exchanges between the shards (k-mer buckets, facts, SP symbols, blue entries, final row ranges):
+ * DEBWT_EXCHANGE_PEER_COPY (default): every shard pulls its segments with device-to-device copies;
+ * DEBWT_EXCHANGE_RCCL: one grouped ncclSend / ncclRecv alltoallv per exchange, one communicator per GPU of this process
+ * (ncclCommInitAll; RCCL is loaded on demand -- DEBWT_EDEVICE where it is missing -- and needs one distinct GPU per shard). */
+#define DEBWT_EXCHANGE_PEER_COPY 0
+#define DEBWT_EXCHANGE_RCCL 1
+int debwt_multi_set_exchange(debwt_multi *m, int backend);
 int debwt_multi_build(debwt_multi *m);
 int debwt_multi_fetch_bwt(debwt_multi *m, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row);
 int debwt_multi_get_stats(const debwt_multi *m, debwt_multi_stats *out, debwt_stats *shard0);

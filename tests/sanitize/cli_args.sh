@@ -22,6 +22,9 @@ expect 1 $X -o $D/o --gpus 2 --devices 0,1,2 $F
 expect 1 $X -o $D/o --gpus 1 --devices 0, $F
 expect 1 $X -o $D/o --gpus 300 $F
 expect 1 $X -o $D/o --gpus 2 --keys sideways $F
+expect 0 $X -o $D/o --gpus 2 --exchange rccl $F
+expect 0 $X -o $D/o --gpus 2 --exchange peer --keys exchange $F
+expect 1 $X -o $D/o --gpus 2 --exchange pigeon $F
 expect 1 $X -o $D/o --gpus 2 $D/missing.fa
 L=$(python3 -c "print(','.join(['0']*400))"); expect 1 $X -o $D/o --devices $L $F
 expect 0 $X -o $D/o --gpus 2 $F          # (a failed run has removed OUT: the reference's create+remove probe, src/main.c:55-58)

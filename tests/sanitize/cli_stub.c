@@ -20,6 +20,28 @@ int debwt_load_fasta_opts(debwt_ctx *c, const char *path, int threads, unsigned 
     if (strstr(path, "missing")) return DEBWT_EINVAL;
     c->loaded = 1; return 0;
 }
+int debwt_reserve(debwt_ctx *c, uint64_t n, uint64_t nrec, double branching, unsigned flags) { (void)c; (void)nrec; (void)branching; (void)flags; return n ? 0 : DEBWT_EINVAL; }
+int debwt_pinned_alloc(size_t bytes, void **out) { *out = malloc(bytes); return *out ? 0 : DEBWT_ENOMEM; }
+void debwt_pinned_free(void *p) { free(p); }
+int debwt_pack_fasta_opts(const char *path, int threads, unsigned flags, uint64_t seed, debwt_packed_text *out, char *errbuf,
+                          size_t errlen) {
+    (void)threads; (void)flags; (void)seed;
+    memset(out, 0, sizeof *out);
+    if (strstr(path, "missing")) { if (errlen) { strncpy(errbuf, "stub: no such file", errlen - 1); errbuf[errlen - 1] = 0; } return DEBWT_EINVAL; }
+    out->nwords = (N_ROWS + 63) / 32 + 2; out->words = calloc(out->nwords, 8); out->n = N_ROWS; out->nrec = N_REC;
+    out->sep = calloc(N_REC, 8);
+    return out->words && out->sep ? 0 : DEBWT_ENOMEM;
+}
+void debwt_free_packed(debwt_packed_text *p) { free(p->words); free(p->sep); p->words = NULL; p->sep = NULL; }
+int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n, const uint64_t *sep, uint64_t nrec) {
+    (void)sep; if (!packed || n != N_ROWS || nrec != N_REC) return DEBWT_EINVAL;
+    c->loaded = 1; return 0;
+}
+int debwt_build_to_host(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar) {
+    if (!c->loaded) return DEBWT_ESTATE;
+    memset(bwt, 0x1B, ((N_ROWS + 31) / 32) * 8); hash_rows[0] = 5; hash_rows[1] = 9; *dollar = 77; return 0;
+}
+int debwt_multi_set_exchange(debwt_multi *m, int backend) { (void)m; return backend == 0 || backend == 1 ? 0 : DEBWT_EINVAL; }
 int debwt_build(debwt_ctx *c) { return c->loaded ? 0 : DEBWT_ESTATE; }
 int debwt_get_stats(const debwt_ctx *c, debwt_stats *st) { (void)c; memset(st, 0, sizeof *st); st->n = N_ROWS; st->nrec = N_REC; return 0; }
 int debwt_fetch_bwt(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar) {

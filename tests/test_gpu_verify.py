@@ -176,6 +176,38 @@ def test_multi_gpu_host_from_one_process(api, oracle, devices, case, k, cap, tun
     m.close()
 
 
+@pytest.mark.parametrize("ngpus", [1, 2])
+def test_multi_gpu_host_exchanges_over_rccl(api, oracle, ngpus):
+    """The C host with its exchanges carried by RCCL (ncclCommInitAll in the one process, one grouped ncclSend / ncclRecv
+    alltoallv per exchange; librccl loaded on demand): a communicator group of ONE on this box's GPU -- every message is a
+    send to itself -- and of two where the box has two GPUs; a device ordinal that repeats is refused (RCCL wants
+    distinct GPUs), peer copies stay available."""
+    import torch
+    from debwt_amd import synth
+    if torch.cuda.device_count() < ngpus:
+        pytest.skip("this box has fewer GPUs than shards")
+    recs = synth.pan_genome(300_000, 3)
+    ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(recs), 32)
+    m = api.MultiDeBWT(list(range(ngpus)), k=32)
+    m.load_records(recs)
+    m.set_exchange("rccl")
+    for mode in ("exchange", "rescan"):
+        m.set_key_mode(mode)
+        m.build()
+        w, h, dr = m.fetch()
+        assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od, mode
+        assert m.stats()[0]["exchange_backend"] == 1
+    m.set_exchange("peer")
+    m.build()
+    assert np.array_equal(m.fetch()[0], ow) and m.stats()[0]["exchange_backend"] == 0
+    m.close()
+    if ngpus == 1:
+        m2 = api.MultiDeBWT([0, 0], k=32)
+        with pytest.raises(api.DebwtError):
+            m2.set_exchange("rccl")
+        m2.close()
+
+
 def _run_bench_direct(extra, timeout=900, env_extra=None):
     """`python bench.py --gpus N ...` exactly as the driver types it for N = 1: no launcher in front."""
     import json
