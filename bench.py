@@ -120,7 +120,88 @@ def emit_line(line):
     os.write(1, (json.dumps(line) + "\n").encode())
 
 
-def launch_ranks(n_ranks):
+def run_c_host(args):
+    """--host c: ONE process, one host thread per GPU inside the library (debwt_multi_build -- what `cli/deBWT --gpus N`
+    runs), the same collection, the same checks, the same line with "host": "c".  With --backend gloo (the one-GPU test
+    box) all shards sit on GPU 0."""
+    import ctypes
+    import numpy as np
+    from debwt_amd import api, _lib
+    from debwt_amd import synth_native as SN
+    L = _lib.lib()
+    ndev = ctypes.c_int(0)
+    ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(ndev))
+    devices = list(range(args.gpus)) if (ndev.value >= args.gpus and args.backend == "nccl") else [0] * args.gpus
+    t0 = time.perf_counter()
+    syn = SN.Synth.named(args.workload)
+    n, nrec = syn.n, syn.nrec
+    sep = syn.sep()
+    text = SN.PinnedArray(syn.nwords)
+    census = syn.words_into(text.ptr)
+    t_gen = time.perf_counter() - t0
+    m = api.MultiDeBWT(devices, k=args.k, tune=args.tune)
+    if args.exchange == "rccl":
+        m.set_exchange("rccl")
+    m.set_key_mode({"auto": "auto", "exchange": "exchange", "rescan": "rescan"}.get(args.mode, "auto"))
+    t0 = time.perf_counter()
+    m.load_packed(text.a, n, sep)
+    t_load = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m.build()
+    first_build_s = time.perf_counter() - t0
+    for _ in range(max(args.warmup - 1, 0)):
+        m.build()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.build()                                          # synchronous: returns when every shard's stream has drained
+    dt = time.perf_counter() - t0
+    ms, s0 = m.stats()
+    check = None
+    if not args.no_check:
+        rep = m.verify_device()                            # inverse BWT of the concatenated result on the first GPU
+        check = {"inverse_bwt_ok": bool(rep["ok"]),
+                 "inverse_bwt": {k_: (round(v, 2) if isinstance(v, float) else v) for k_, v in rep.items() if k_ != "ok"}}
+        if n < 4_000_000_000:                              # the rows on the host as well: census and row lists
+            w, h, dr = m.fetch()
+            cnt = np.zeros(4, dtype=np.int64)
+            for a in range(0, len(w), 1 << 22):
+                x = w[a:a + (1 << 22)]
+                for sh_ in range(0, 64, 2):
+                    cnt += np.bincount(((x >> np.uint64(sh_)) & np.uint64(3)).astype(np.uint8), minlength=4)[:4]
+            cnt[0] -= (-n) % 32                            # unused tail bits of the last word are zero
+            want = census.astype(np.int64).copy(); want[3] += nrec
+            check.update({"census_equals_text": bool((cnt == want).all()),
+                          "hash_rows_ascending": bool((np.diff(h.astype(np.int64)) > 0).all()) if nrec > 2 else True,
+                          "hash_rows": int(len(h)), "dollar_row": int(dr)})
+    keys = s0["radix_pass_keys"]
+    mean_pass_ms = s0["radix_pass_ms"] / max(s0["radix_pass_launches"], 1)
+    achieved = 16.0 * keys / (mean_pass_ms * 1e-3) / 1e9 if mean_pass_ms > 0 else 0.0
+    line = {
+        "metric": METRIC, "value": round(n / (dt / args.steps) / 1e9, 4), "unit": "Gbp/s", "n_gpus": args.gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "host": "c",
+        "config": {"workload": f"{args.workload} ({WORKLOAD_NOTE.get(args.workload, 'custom')})", "k": args.k, "bases": n,
+                   "records": nrec, "bases_per_gpu": n // args.gpus,
+                   "parallelism": f"one process, one host thread per GPU (debwt_multi_build): {args.gpus} k-mer-prefix shards on devices "
+                                  f"{devices}, text replicated in the HBM of every GPU, result concatenated on the first"},
+        "exchange": {"backend": "RCCL: grouped ncclSend/ncclRecv per exchange (ncclCommInitAll in the one process)"
+                     if ms["exchange_backend"] == 1 else "peer copies: every shard pulls its segments with hipMemcpyAsync device-to-device",
+                     "keys": "exchange" if ms["key_mode"] == 0 else "rescan", "key_rounds": ms["rounds"],
+                     "key_bytes_into_shard0": ms["key_bytes_in"], "blue_bytes_into_shard0": ms["blue_bytes_in"]},
+        "roofline": {"bound": "hbm", "kernel": "rs_scatter_kernel<0,0,1> of shard 0 (one 8-bit radix pass over the keys of a key range)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": None, "bytes_per_launch": 16 * keys, "mean_launch_ms": round(mean_pass_ms, 4),
+                     "launches_timed": s0["radix_pass_launches"]},
+        "first_build_s": round(first_build_s, 3), "setup_s": {"generate_text": round(t_gen, 2), "load_to_hbm": round(t_load, 3)},
+        "check": check, "cpu_baseline": None,
+    }
+    emit_line(line)
+    m.close()
+    text.free()
+    return 0
+
+
+def launch_ranks(n_ranks, with_c_host=False, timeout=420.0):
     """`python bench.py --gpus N` run directly (no launcher, WORLD_SIZE unset): start the N ranks as CHILD processes
     of this one -- `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` -- before anything here
     has touched the GPU (no torch import yet, and never an exec of a process that has), hand rank 0's one JSON line
@@ -134,6 +215,7 @@ def launch_ranks(n_ranks):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    held = None                                              # rank 0's line, kept back until the C host has had its turn
     for ln in p.stdout:
         # the ranks share one pipe: another rank's output (gloo prints its connection messages to stdout in pieces) may
         # stand in front of rank 0's object or between it and its newline: take the object from where it starts to where it ends
@@ -146,14 +228,51 @@ def launch_ranks(n_ranks):
                 obj = None
         if obj is not None:
             rest = ln[:at] + ln[at + end:]
-            sys.stdout.write(ln[at:at + end] + "\n")
-            sys.stdout.flush()
+            if with_c_host and held is None:
+                held = obj
+            else:
+                sys.stdout.write(ln[at:at + end] + "\n")
+                sys.stdout.flush()
             if rest.strip():
                 sys.stderr.write(rest if rest.endswith("\n") else rest + "\n")
         else:
             sys.stderr.write(ln)
         sys.stderr.flush()
-    return p.wait()
+    rc = p.wait()
+    if held is not None:
+        # The ranks have exited and released their GPUs: the same collection through the C host (one process, one thread per
+        # GPU: what cli/deBWT --gpus runs), as a CHILD of this process, which has not touched a GPU.  Extra information: a
+        # failure or a timeout of it is recorded in the line and costs the run nothing.
+        if rc == 0:
+            argv = [a for a in sys.argv[1:]]
+            for flag in ("--host",):
+                if flag in argv:
+                    i = argv.index(flag); del argv[i:i + 2]
+            steps = max(1, min(3, held.get("steps", 1)))
+            for flag, val in (("--steps", str(steps)), ("--warmup", "1")):
+                if flag in argv:
+                    i = argv.index(flag); argv[i + 1] = val
+                else:
+                    argv += [flag, val]
+            child = [sys.executable, os.path.abspath(__file__), "--host", "c"] + argv
+            try:
+                r = subprocess.run(child, env=env, capture_output=True, text=True, timeout=timeout)
+                sys.stderr.write(r.stderr[-4000:])
+                lines = [x for x in r.stdout.splitlines() if x.startswith('{"metric"')]
+                if r.returncode == 0 and lines:
+                    j = json.loads(lines[-1])
+                    held["host_c"] = {k_: j[k_] for k_ in ("value", "unit", "ms_per_step", "steps", "warmup", "host", "exchange",
+                                                          "first_build_s", "check", "config") if k_ in j}
+                else:
+                    held["host_c"] = {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
+            except subprocess.TimeoutExpired:
+                held["host_c"] = {"error": f"not back within {timeout} s"}
+            except Exception as e:                            # noqa: BLE001
+                held["host_c"] = {"error": f"{type(e).__name__}: {e}"}
+            held["host"] = "python (one process per GPU, torch.distributed); host_c: the C host on the same collection"
+        sys.stdout.write(json.dumps(held) + "\n")
+        sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -168,6 +287,14 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--h2h-reps", type=int, default=-1,
                     help="host-to-host steps (N = 1; load + build + fetch, mean over them); default = --steps, 0 = skip")
+    ap.add_argument("--host", choices=["python", "c", "both"], default=None,
+                    help="which host drives the GPUs.  python: one process per GPU, torch.distributed (RCCL all_to_all); c: ONE "
+                         "process, one host thread per GPU inside the library (debwt_multi_build, what cli/deBWT --gpus runs), "
+                         "exchanges by --exchange; both (default for N > 1 when bench.py starts its own ranks): the python ranks "
+                         "give `value`, then the C host runs as a child process and its line becomes the key `host_c`")
+    ap.add_argument("--exchange", choices=["peer", "rccl"], default="peer",
+                    help="--host c: device-to-device copies (default) or grouped ncclSend/ncclRecv (needs one GPU per shard)")
+    ap.add_argument("--host-c-timeout", type=float, default=420.0, help=argparse.SUPPRESS)
     ap.add_argument("--no-reserve", action="store_true", help="no debwt_reserve beside the text generation (A/B of the cold path)")
     ap.add_argument("--h2h-plain", action="store_true", help="host-to-host steps with build + fetch one after the other (A/B)")
     ap.add_argument("--cpu-configs", action="store_true",
@@ -190,8 +317,10 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.host == "c":
+        sys.exit(run_c_host(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus))
+        sys.exit(launch_ranks(args.gpus, with_c_host=args.host in (None, "both"), timeout=args.host_c_timeout))
 
     from debwt_amd import dist as D
     rank, local_rank, world = D.env_world()
@@ -479,6 +608,7 @@ def main():
 
         timer = threading.Timer(args.other_mode_timeout, bail)
         timer.daemon = True
+        t_extra = time.perf_counter()
         timer.start()
         try:
             if os.environ.get("DEBWT_BENCH_FAIL_OTHER_MODE", "") == str(rank):   # tests: this rank's extra build raises
@@ -493,6 +623,9 @@ def main():
                                  f"'{other}' was timed over {k2} steps after one warm-up")
             timer.cancel()
         except Exception as e:                                # noqa: BLE001
+            if time.perf_counter() - t_extra >= args.other_mode_timeout:
+                # past the deadline: the other ranks' watchdogs have ended them and this is the collective noticing -- a timeout
+                threading.Event().wait()
             state["why"] = f"rank {rank} failed: {type(e).__name__}: {e}"
             state["failed"] = True
             sys.stderr.write(f"bench.py: extra build of the '{other}' key path failed on rank {rank}: {e}\n")

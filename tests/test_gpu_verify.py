@@ -239,6 +239,22 @@ def test_bench_two_ranks_started_by_bench_itself_gloo():
     assert all(isinstance(j["key_modes_ms"][m], float) for m in ("exchange", "rescan")), j["key_modes_ms"]
 
 
+def test_bench_c_host_two_shards_on_one_gpu():
+    """bench.py --gpus 2 --host c: ONE process, debwt_multi_build over two shards (both on this box's GPU with --backend
+    gloo), the line says which host and which exchange its number belongs to; and the default N > 1 run (python ranks first,
+    then the C host as a child process) carries the C host's line under `host_c`."""
+    j = _run_bench_direct(["--gpus", "2", "--backend", "gloo", "--host", "c", "--workload", "chr1_250M", "--steps", "2", "--warmup", "1",
+                           "--no-cpu-baseline"])
+    assert j["host"] == "c" and j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0
+    assert j["check"]["inverse_bwt_ok"] and j["check"]["census_equals_text"], j["check"]
+    assert "peer copies" in j["exchange"]["backend"] and j["exchange"]["keys"] in ("exchange", "rescan")
+    j = _run_bench_direct(["--gpus", "2", "--backend", "gloo", "--workload", "ecoli_4.6M", "--steps", "1", "--warmup", "1",
+                           "--no-cpu-baseline", "--no-other-mode"])
+    assert j["n_gpus"] == 2 and j["check"]["inverse_bwt_ok"] and "python" in j["host"]
+    hc = j["host_c"]
+    assert hc.get("host") == "c" and hc["value"] > 0 and hc["check"]["inverse_bwt_ok"], hc
+
+
 def test_bench_extra_key_mode_cannot_cost_the_result():
     """The second key path of --mode auto is extra information: when it does not come back in time (here: a watchdog of
     a millisecond) every rank leaves with exit code 0 and rank 0 has printed the finished line first."""
