@@ -61,6 +61,8 @@ WORKLOAD_NOTE = {
     "ecoli_4.6M": "BASELINE configs[0]: E. coli-sized single record",
     "uniform_3.1G": "distribution U: uniform 3.1 Gbp in 24 records",
     "real_3.1G": "distribution R: 3.1 Gbp in 24 records with an Alu-like family, satellite arrays, homopolymer tracts",
+    "real10x3G": "distribution R at the headline size: 10 genomes x 3.0 Gbp in 240 records, each with an Alu-like family "
+                 "(10^6 copies), satellite arrays and homopolymer tracts, SNP 1e-3 between the genomes",
 }
 
 

@@ -73,6 +73,8 @@ WORKLOADS = {
     # distribution R: repeat families + one Alu-like family (10^6 copies per 3.1 Gbp, 12 % divergence) + 3 % satellite
     # arrays and homopolymer / microsatellite tracts
     "real_3.1G": (3_100_000_000, 1, 24, {"lowcx_fraction": 0.03, "alu_copies": 1_000_000}),
+    # distribution R at the size the metric is quoted on: ten such genomes (SNPs at 1e-3 between them), 240 records
+    "real10x3G": (3_000_000_000, 10, 24, {"lowcx_fraction": 0.03, "alu_copies": 1_000_000}),
     # small shapes of the same kinds (tests)
     "pan_small": (300_000, 4, 3, {}),
     "real_small": (1_500_000, 2, 3, {"lowcx_fraction": 0.03, "alu_copies": 500}),
