@@ -541,6 +541,7 @@ static bool special_wants_device(debwt_ctx *c) {
     // holds by now -- else the host threads build the tables, as for any collection before round 3
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    if (const char *f = getenv("DEBWT_SPECIAL_FAKE_FREE_BYTES")) free_b = (size_t)strtoull(f, nullptr, 10);   // tests: this branch
     const u64 need = c->NS * 72 + c->nrec * 64 + (64ull << 20);
     const u64 have = free_b + c->sx.cap + c->sppos.cap + c->sprec.cap + c->tail_d.cap;
     return need + (have >> 4) < have;                          // and 1/16 of it stays free
@@ -557,7 +558,7 @@ static int special_branch_bitmap(debwt_ctx *c) {
     return DEBWT_OK;
 }
 
-static int special_device_build(debwt_ctx *c) {
+static int special_device_build(debwt_ctx *c, bool release_arena = true) {
     const u64 N = c->nrec, NS = c->NS, n = c->n;
     const int K = c->K;
     int rc;
@@ -680,6 +681,14 @@ static int special_device_build(debwt_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(c->head_keys.p, r, N * 8, hipMemcpyDeviceToDevice, c->stream));
     if ((rc = special_branch_bitmap(c))) return rc;
     if ((rc = sync_check(c))) return rc;
+    if (release_arena) {
+        // The arena (59 bytes per special suffix) and the positions / records of the sorted items have done their work: a
+        // read set whose module workspace is a large share of the HBM gives it back before the key ranges and the later
+        // stages allocate theirs (they have no host path to fall back to); small arenas stay for the next build.
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (c->sx.cap + c->sppos.cap + c->sprec.cap) > total_b / 16)
+            for (DevBuf *b : {&c->sx, &c->sppos, &c->sprec}) { HIPCHK(c, hipFree(b->p)); b->p = nullptr; b->cap = 0; }
+    }
     c->special_dev = true;
     c->st.ms_host_special = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     c->st.special_path = 2;
@@ -794,7 +803,7 @@ static int sort_range(debwt_ctx *c, size_t i, u64 *imported) {
         const std::vector<uint64_t> &key = c->special.key;          // ascending (suffix order implies key order)
         u64 s0 = 0, s1 = c->NS;
         if ((c->shard_world > 1 || P > 1) && c->special_dev) {
-            d_bounds = reinterpret_cast<u64 *>(c->sx.as<u8>() + c->sx.cap - 64);      // spare words at the end of the arena
+            d_bounds = c->dollar.as<u64>() + 5;                       // spare words behind the '$' row and the census
             k_sp_bounds<<<1, 64, 0, c->stream>>>(c->spkey.as<u64>(), c->NS, r.key_lo >> 2, r.key_hi >> 2, d_bounds);
             HIPCHK(c, hipMemcpyAsync(&c->h_scalars[24], d_bounds, 16, hipMemcpyDeviceToHost, c->stream));
         } else if (c->shard_world > 1 || P > 1) {
@@ -2238,8 +2247,13 @@ extern "C" int debwt_special_compare(debwt_ctx *c, uint64_t mismatch[6]) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     join_special(c);
     if (c->nrec >= (1ull << 27) || c->NS >= (1ull << 32)) return DEBWT_ERANGE;
-    int rc = special_device_build(c);
-    c->special_dev = false;                                   // a build that follows chooses its own path
+    // the device tables overwrite those of a build in progress: the context goes back to "loaded" (a build that follows starts
+    // over and chooses its own path), and the counters of the last build stay what they were
+    const debwt_stats keep = c->st;
+    c->stage = ST_LOADED;
+    int rc = special_device_build(c, false);
+    c->special_dev = false;
+    c->st = keep;
     if (rc) return rc;
     SpecialTables t;
     build_special_tables(c->h_text, c->n, c->h_sep.data(), c->nrec, c->K, &t);

@@ -288,9 +288,9 @@ int fail(char *err, size_t errlen, const std::string &msg) {
     return -1;
 }
 
-// FASTQ, which the reference's reader accepts as well (klib kseq_read, src/kseq.h:177-201: '@' header, sequence lines up
-// to the line that starts with '+', then quality characters until there are as many as bases, quality of another length
-// = error): the records are rewritten as header-less FASTA (">\n" + the sequence lines) into `out`, which the chunked
+// FASTQ, which the reference's reader accepts as well (klib kseq_read, src/kseq.h:177-201: '@' or '>' header, sequence
+// lines up to a line that starts with '+', '@' or '>'; after '+' quality characters until there are as many as bases,
+// quality of another length = error; a record that ends at the next header has no qualities): the records are rewritten as header-less FASTA (">\n" + the sequence lines) into `out`, which the chunked
 // FASTA parser then takes.  One serial walk over the lines (memchr speed): a quality line may start with '@' or '>', so
 // record starts cannot be recognised from the middle of the file.  Returns the FASTA length, or -1 with a message.
 long fastq_to_fasta(const char *buf, size_t len, char *out, char *err, size_t errlen) {
@@ -307,23 +307,27 @@ long fastq_to_fasta(const char *buf, size_t len, char *out, char *err, size_t er
     };
     while (i < len) {
         if (buf[i] == '\n' || buf[i] == '\r') { i++; continue; }               // blank lines between records
-        if (buf[i] != '@') {
+        if (buf[i] != '@' && buf[i] != '>') {
             char m[120];
-            snprintf(m, sizeof m, "FASTQ record %llu does not start with '@' (byte %zu)", (unsigned long long)rec + 1, i);
+            snprintf(m, sizeof m, "FASTQ record %llu does not start with '@' or '>' (byte %zu)", (unsigned long long)rec + 1, i);
             fail(err, errlen, m);
             return -1;
         }
         i = std::min(len, line_end(i) + 1);                                     // header line: the name is not used
         out[o++] = '>'; out[o++] = '\n';
         size_t bases = 0;
-        while (i < len && buf[i] != '+') {                                      // sequence lines
+        // sequence lines, up to a line that starts with '+' (qualities follow) or with '@' / '>' (the next record: this one
+        // has no quality section -- kseq_read ends a sequence at any of the three, src/kseq.h:188) or the end of the input
+        while (i < len && buf[i] != '+' && buf[i] != '@' && buf[i] != '>') {
             const size_t e = line_end(i);
             bases += payload(i, e);
             memcpy(out + o, buf + i, e - i); o += e - i;
             out[o++] = '\n';
             i = std::min(len, e + 1);
         }
-        if (i >= len) { fail(err, errlen, "FASTQ input ends inside a record (no '+' line)"); return -1; }
+        rec++;
+        if (i >= len || buf[i] != '+') continue;                                // a record without qualities
+        rec--;
         i = std::min(len, line_end(i) + 1);                                     // the '+' line
         size_t qual = 0;
         while (i < len && qual < bases) {                                       // quality lines

@@ -321,6 +321,10 @@ def build_sharded(d, ws=None, mode=None, device=None):
     device = ws.device
     est_x, est_r = ctypes.c_double(), ctypes.c_double()
     choice = L.debwt_shard_key_mode(d.n, world, LINK_GBYTES_PER_S, ctypes.byref(est_x), ctypes.byref(est_r))
+    if ws.mode == "auto" and world > 1:
+        # the link rate behind the choice is measured per rank (measure_link) and a probe may fail on one rank alone: every
+        # rank takes rank 0's choice, or the ranks would issue different collectives and hang
+        choice = int(_all_gather_small(np.array([choice], dtype=np.int64))[0, 0])
     keys = ws.mode if ws.mode != "auto" else ("exchange" if choice == 0 else "rescan")
     exchange = keys == "exchange"               # the keys travel
     sliced = keys != "scan"                     # SP code and blue entries by text slice, then exchanged

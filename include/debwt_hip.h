@@ -88,8 +88,9 @@ int debwt_load_ascii(debwt_ctx *ctx, const char *seq, const uint64_t *reclen, ui
 
 /* FASTA ingest (replaces the reference's single-threaded kseq.h + zlib reader, src/collect#$.c:34-90): the file is
  * mapped (gzip: inflated), parsed and packed by `threads` host threads (the reference's -t) into the text format
- * above.  FASTQ (first byte '@') is read as the reference's reader reads it (src/kseq.h:177-201: sequence lines up to the
- * '+' line, as many quality characters as bases; the qualities are dropped).  Characters other than ACGTacgt and white
+ * above.  FASTQ (first byte '@') is read as the reference's reader reads it (src/kseq.h:177-201: sequence lines up to a
+ * line that starts with '+', '@' or '>'; after '+' as many quality characters as bases, which are dropped; records
+ * without a quality section and '>' records may be mixed in).  Characters other than ACGTacgt and white
  * space, sequence before the first header, a quality string of another length than its sequence and records of 32 bases
  * or fewer (src/collect#$.c:41-45) are errors.  debwt_pack_fasta is host-only (no GPU needed);
  * debwt_load_fasta = debwt_pack_fasta + debwt_load_text with the packed copy owned by ctx. */
@@ -341,7 +342,8 @@ int debwt_special_digest(const uint64_t *packed, uint64_t n, const uint64_t *sep
 
 /* Needs a GPU and a loaded text: builds the same tables on the device (the path collections of many records take,
  * SURVEY 8f-1) and by the host module, and counts the elements that differ: mismatch[0..5] = suffix order of the
- * special suffixes, their keys, their BWT symbols, the special branches, the head nodes, the tail nodes. */
+ * special suffixes, their keys, their BWT symbols, the special branches, the head nodes, the tail nodes.  A build in
+ * progress is discarded (the context is back at "text loaded"); the counters of the last build are left alone. */
 int debwt_special_compare(debwt_ctx *ctx, uint64_t mismatch[6]);
 
 /* Verification tool standing in for the dead LFsearch path (src/LFsearch.c:14-48): inverse BWT

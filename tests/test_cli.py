@@ -146,4 +146,4 @@ def test_cli_multi_gpu_outputs_equal_reference_files(tmp_path, name, k, gpus, ke
     sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()      # noqa: E731
     assert sha(out) == entry["sha256"]["bwt"] and sha(out + ".#") == entry["sha256"]["hash"]
     assert sha(out + ".$") == entry["sha256"]["dollar"]
-    assert f"{gpus} GPUs, keys {'exchanged' if keys == 'exchange' else 'rescanned'}" in r.stdout
+    assert f"{gpus} GPUs, exchanges by peer-to-peer copies, keys {'exchanged' if keys == 'exchange' else 'rescanned'}" in r.stdout

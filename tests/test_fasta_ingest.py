@@ -81,7 +81,7 @@ def test_pack_fasta_headers_longer_than_a_chunk(tmp_path):
     (b">a\n" + b"A" * 32 + b"\n", "Length <= 32"),
     (b"@r\nACGT\n+\nIIII\n", "Length <= 32"),                                       # FASTQ is read; 4 bases are too few
     (b"@r\n" + b"A" * 40 + b"\n+\n" + b"I" * 39 + b"\n", "quality characters"),      # truncated quality string
-    (b"@r\n" + b"A" * 40 + b"\n", "no '+' line"),
+    (b"@r\n" + b"A" * 30 + b"\n", "Length <= 32"),                                    # an '@' record without qualities is a record
     (b"@r\n" + b"A" * 40 + b"\n+\n" + b"I" * 40 + b"\nACGT\n", "does not start with '@'"),
     (b"", "empty"),
 ])
@@ -238,6 +238,26 @@ def test_pack_fastq_matches_numpy_packer(tmp_path, threads, shape):
           "lower": {"lower": True}, "blank": {"blank": True}}[shape]
     _write_fastq(p, recs, **kw)
     _check(p, recs, threads)
+
+
+def test_pack_fastq_records_without_qualities_and_fasta_records_mixed_in(tmp_path):
+    """kseq_read ends a sequence at a line that starts with '+', '@' or '>' (src/kseq.h:188): an '@' record without a
+    quality section and '>' records inside a FASTQ file are records like any other; the last record may end the file
+    without qualities."""
+    rng = np.random.default_rng(14)
+    recs = [rng.integers(0, 4, size=int(rng.integers(40, 200))).astype(np.uint8) for _ in range(60)]
+    p = str(tmp_path / "mixed.fq")
+    with open(p, "wb") as f:
+        for i, r in enumerate(recs):
+            s = bytes(ASC[c] for c in r)
+            kind = i % 4 if i + 1 < len(recs) else 1
+            f.write((b">" if kind == 2 else b"@") + b"rec%d\n" % i)
+            for a in range(0, len(s), 61):
+                f.write(s[a:a + 61] + b"\n")
+            if kind in (0, 3):                           # with qualities (first character legal but nasty)
+                f.write(b"+\n" + (b"@" if kind == 0 else b">") + b"I" * (len(s) - 1) + b"\n")
+    for threads in (1, 7):
+        _check(p, recs, threads)
 
 
 def test_pack_fastq_with_ambiguity_letters(tmp_path):

@@ -115,6 +115,46 @@ def test_many_record_goldens_take_the_parallel_special_region_path(api, entry):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("entry", [e for e in MANIFEST if e["records"] >= 2000 and e["k"] == 32], ids=golden_id)
+def test_special_region_module_falls_back_to_host_when_its_workspace_does_not_fit(api, entry, monkeypatch):
+    """The device module is refused when its workspace (72 bytes per special suffix) does not fit beside the build
+    (special_wants_device; DEBWT_SPECIAL_FAKE_FREE_BYTES stands in for hipMemGetInfo): the host threads build the tables
+    and the result is the reference's all the same; with the real figure the device module runs."""
+    recs = golden_records(entry)
+    sha = entry["sha256"]
+    for fake, want_path in (("1000000", (0, 1)), (None, (2,))):
+        if fake:
+            monkeypatch.setenv("DEBWT_SPECIAL_FAKE_FREE_BYTES", fake)
+        else:
+            monkeypatch.delenv("DEBWT_SPECIAL_FAKE_FREE_BYTES", raising=False)
+        d, (words, hrows, drow), st = _run(api, recs, 32)
+        assert st["special_path"] in want_path, st
+        assert _sha(words) == sha["bwt"] and _sha(hrows) == sha["hash"]
+        d.close()
+
+
+def test_special_compare_leaves_the_last_build_alone(api):
+    """debwt_special_compare overwrites the special-region tables of a build in progress: the context is back at "text
+    loaded" afterwards (stage calls out of order are refused, a new build is right) and the counters of the last build stay."""
+    from debwt_amd import synth
+    recs = synth.read_set(3000, 60, 300, 200_000, seed=11)
+    d = api.DeBWT(k=32)
+    d.load_records(recs)
+    d.build()
+    want = d.fetch()
+    d.kmer_sort_rle()
+    st = d.stats()
+    assert d.special_compare() == [0] * 6
+    st2 = d.stats()
+    assert st2["special_path"] == st["special_path"] and st2["ms_host_special"] == st["ms_host_special"]
+    with pytest.raises(api.DebwtError):
+        d.classify()                                     # the sort of the interrupted build is gone
+    d.build()
+    got = d.fetch()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    d.close()
+
+
 def test_hundred_thousand_records_equal_oracle(api, oracle):
     """10^5 reads (beyond what the reference's O(N)-per-record insert, src/INandOut.c:91-108, finishes in test time):
     3.1e6 special suffixes through the parallel special-region path against the oracle, whose special-region code is

@@ -208,6 +208,27 @@ def test_multi_gpu_host_exchanges_over_rccl(api, oracle, ngpus):
         m2.close()
 
 
+def test_million_reads_property(api):
+    """10^6 reads of 60..140 bases (3.1 * 10^7 special suffixes: the special-region module on the device): symbol census of
+    the BWT against the text's, '#' rows ascending and complete, inverse BWT on the device -- the size the oracle cannot
+    reach in test time."""
+    from debwt_amd import synth
+    recs = synth.read_set(1_000_000, 60, 140, 5_000_000, seed=21)
+    d = api.DeBWT(k=32)
+    d.load_records(recs)
+    d.build()
+    st = d.stats()
+    assert st["special_path"] == 2 and st["nrec"] == 1_000_000, st
+    census = np.bincount(np.concatenate(recs), minlength=4).astype(np.int64)
+    census[3] += len(recs)
+    assert np.array_equal(d.bwt_census().astype(np.int64), census)
+    _, hrows, drow = d.fetch_small()
+    assert len(hrows) == len(recs) - 1 and bool((np.diff(hrows.astype(np.int64)) > 0).all())
+    rep = d.verify_device()
+    assert rep["inverse_bwt_ok"], rep
+    d.close()
+
+
 def _run_bench_direct(extra, timeout=900, env_extra=None):
     """`python bench.py --gpus N ...` exactly as the driver types it for N = 1: no launcher in front."""
     import json
