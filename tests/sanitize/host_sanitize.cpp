@@ -120,8 +120,9 @@ int main() {
         PackedText p{};
         std::string cut = fq.substr(0, fq.size() - 5);                                     // quality string cut short
         CHECK(pack_fasta_buffer(cut.data(), cut.size(), 2, &p, err, sizeof err) != 0);
-        cut = fq.substr(0, fq.find('+'));                                                  // no '+' line
-        CHECK(pack_fasta_buffer(cut.data(), cut.size(), 2, &p, err, sizeof err) != 0);
+        cut = fq.substr(0, fq.find('+'));                                  // no '+' line: a record without qualities (kseq)
+        CHECK(pack_fasta_buffer(cut.data(), cut.size(), 2, &p, err, sizeof err) == 0 && p.nrec == 1);
+        free_packed_text(&p);
     }
     for (const char *bad : {"ACGT\n", ">a\nACGTACGT\n", ">a\nACGTXACGTACGTACGTACGTACGTACGTACGTACGTACGT\n", "@r\nACGT\n+\nIIII\n", "@\n", "@r\nACGT", "", ">only header\n"}) {
         PackedText p{};
