@@ -1155,18 +1155,61 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     const int qshift = 64 - qbits;
     const bool route_sort = c->shard_world == 1 && c->Q > 0 && c->n < (1ull << (qshift - 3)) &&
                             c->B < 0xFFFFFFF0ull - (1ull << 20) &&      // the radix passes index with 32 bits
-                            !(c->cfg.reserved & 32);
+                            !(c->cfg.reserved & 32) &&
+                            !((c->cfg.reserved & 262144) && c->ranges.size() > 1);   // bit 18: by key range, as for >= 2^32 entries (tests)
+    // 2^32 blue entries and more (ten genomes with an Alu-like family: 5.6 G) are beyond the 32-bit positions of the radix
+    // passes as ONE array, but the blocks -- and so the blue slots -- of a key range are contiguous and fewer than 2^32: the
+    // routed entries of a slice are bucketed by key range (the pass that routes entries to their shard on several GPUs) and
+    // appended to their range's slots; every range is then sorted by block id on its own, over the bits in which its block
+    // ids differ.  (The cursor-atomic fill this replaces took 2.3 s of a 5.0 s build, profiles/r04_bench_real10x3G_first.json.)
+    const size_t P = c->ranges.size();
+    bool route_ranges = !route_sort && c->shard_world == 1 && P > 1 && P <= RS_RADIX && c->Q > 0 && c->n < (1ull << (qshift - 3)) &&
+                        !(c->cfg.reserved & 32);
+    for (size_t i = 0; route_ranges && i < P; i++) route_ranges = c->ranges[i].B < 0xFFFFFFF0ull - (1ull << 20);
+    std::vector<u64> rfill(P, 0), roffs(P + 1, 0);
+    if (route_ranges) {
+        std::vector<u32> qb(P + 1);
+        for (size_t i = 0; i < P; i++) qb[i] = (u32)c->ranges[i].qbase;
+        qb[P] = (u32)c->Q;
+        ENSURE(c, c->qbounds, (P + 1) * 4);
+        HIPCHK(c, hipMemcpyAsync(c->qbounds.p, qb.data(), (P + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));              // qb is host memory
+    }
     c->route_direct = false;
     for (u64 g0 = 0; g0 < ngroups; g0 += SP_SLICE_GROUPS) {
         const u64 g1 = std::min(ngroups, g0 + SP_SLICE_GROUPS);
         // route_sort: pass 1 keeps the block ids of the slice's multi-in positions, pass 2 writes the routed entries
-        if (route_sort && (rc = sp_block_ids_begin(c, g0, g1 - g0))) return rc;
+        if ((route_sort || route_ranges) && (rc = sp_block_ids_begin(c, g0, g1 - g0))) return rc;
         if ((rc = sp_flags(c, g0, g1))) return rc;
         if (route_sort) {
             if (Bseen + c->B_slice > c->B) { c->err = "multi-in positions exceed the block total"; return DEBWT_EINTERNAL; }
             if ((rc = sp_emit(c, S, c->blue.as<u64>() + Bseen, qshift))) return rc;
+        } else if (route_ranges) {
+            // the slice's entries as emitted, and bucketed: in the key buffers (free since the ranges were classified) when
+            // those are large enough
+            u64 *ta = c->keysA.as<u64>(), *tb = c->keysB.as<u64>();
+            size_t tb_cap = c->keysB.cap / 8;
+            if (c->keysA.cap < c->B_slice * 8 + 64) { ENSURE(c, c->blue_tmp, c->B_slice * 8 + 64); ta = c->blue_tmp.as<u64>(); }
+            if (c->keysB.cap < c->B_slice * 8 + 64) { ENSURE(c, c->mi_list, c->B_slice * 8 + 64); tb = c->mi_list.as<u64>(); tb_cap = c->mi_list.cap / 8; }
+            if ((rc = sp_emit(c, S, ta, qshift))) return rc;
+            if (c->B_slice) {
+                ENSURE(c, c->rs_over, radix_over_bytes(c->B_slice));
+                RsDigit dg{};
+                dg.mode = 2; dg.bounds = c->qbounds.as<u32>(); dg.nb = (u32)P; dg.tshift = qshift;
+                hipError_t e = radix_partition_by_shard(c->stream, ta, nullptr, c->B_slice, tb, dg, (u32)P, radix_ws(c), roffs.data(),
+                                                        false, tb_cap);
+                if (e != hipSuccess) { c->err = std::string("blue entries by key range: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
+                for (size_t i = 0; i < P; i++) {
+                    const u64 cnt = roffs[i + 1] - roffs[i];
+                    if (!cnt) continue;
+                    if (rfill[i] + cnt > c->ranges[i].B) { c->err = "multi-in positions exceed a key range's block total"; return DEBWT_EINTERNAL; }
+                    HIPCHK(c, hipMemcpyAsync(c->blue.as<u64>() + c->ranges[i].Bbase + rfill[i], tb + roffs[i], cnt * 8,
+                                             hipMemcpyDeviceToDevice, c->stream));
+                    rfill[i] += cnt;
+                }
+            }
         } else if ((rc = sp_emit(c, S))) return rc;
-        if (c->B_slice && !route_sort) {
+        if (c->B_slice && !route_sort && !route_ranges) {
             if (c->abs32)
                 k_blue_fill<1><<<grid_for(c->B_slice, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
                     c->mi_list.as<ulonglong2>(), c->B_slice, c->htab.as<HSlot>(), c->hbits, c->blk_start.as<u64>(),
@@ -1179,6 +1222,24 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
         S += c->S_local; Bseen += c->B_slice;
     }
     if (Bseen != c->Btotal) { c->err = "multi-in positions differ from the block total"; return DEBWT_EINTERNAL; }
+    if (route_ranges) {
+        for (size_t i = 0; i < P; i++) {
+            const debwt_ctx::KeyRange &r = c->ranges[i];
+            if (rfill[i] != r.B) { c->err = "multi-in positions differ from a key range's block total"; return DEBWT_EINTERNAL; }
+            if (!r.B) continue;
+            u64 *reg = c->blue.as<u64>() + r.Bbase, *res = reg;
+            const int span = r.Q > 1 ? bits_for(r.qbase ^ (r.qbase + r.Q - 1)) : 0;     // bits in which the range's block ids differ
+            if (span) {
+                ENSURE(c, c->rs_over, radix_over_bytes(r.B));
+                u64 *tmp = c->keysA.as<u64>();
+                if (c->keysA.cap < r.B * 8 + 64) { ENSURE(c, c->blue_tmp, r.B * 8 + 64); tmp = c->blue_tmp.as<u64>(); }
+                hipError_t e = hipSuccess;
+                res = radix_sort_bits(c->stream, reg, tmp, r.B, qshift, std::min(64, qshift + span), radix_ws(c), &e);
+                if (e != hipSuccess) { c->err = std::string("blue entry sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
+            }
+            k_blue_strip<<<grid_for(r.B, 256), 256, 0, c->stream>>>(res, reg, r.B, qshift);
+        }
+    }
     if (route_sort && c->B) {
         // scratch of B words: a key buffer when it is large enough (free since the ranges were classified)
         u64 *tmp;
