@@ -111,7 +111,9 @@ struct debwt_ctx {
     bool abs32 = true;          // fill cursors hold absolute blue slots
 
     hipStream_t copy_stream = nullptr;   // debwt_build_to_host: finished row ranges leave on this stream under the blue sort
-    hipEvent_t ev_copy = nullptr;
+    hipEvent_t ev_copy = nullptr, ev_copy2 = nullptr;
+    std::vector<u64> census;             // 12-mer prefix census of the loaded text, taken piece by piece behind its upload
+    bool census_valid = false;
     hipEvent_t ev[8]{};         // stage boundaries
     hipEvent_t ev_pass[16][2]{};
     int n_pass_events = 0;
@@ -314,6 +316,7 @@ extern "C" void debwt_destroy(debwt_ctx *c) {
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &p : c->ev_pass) for (auto &e : p) if (e) (void)hipEventDestroy(e);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->ev_copy2) (void)hipEventDestroy(c->ev_copy2);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -347,11 +350,45 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     ENSURE(c, c->text, tw * 8);
     ENSURE(c, c->sepbits, bw * 8);
     ENSURE(c, c->sep, nrec * 8);
-    HIPCHK(c, hipMemsetAsync(c->text.p, 0, tw * 8, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->text.p, packed, (size_t)((n + 63) >> 5) * 8, hipMemcpyHostToDevice, c->stream));
+    const size_t words = (size_t)((n + 63) >> 5);
     HIPCHK(c, hipMemcpyAsync(c->sep.p, sep, nrec * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->sepbits.p, 0, bw * 8, c->stream));
     k_set_sepbits<<<grid_for(nrec, 256), 256, 0, c->stream>>>(c->sep.as<u64>(), nrec, c->sepbits.as<u64>());
+    HIPCHK(c, hipMemsetAsync(c->text.as<u64>() + words, 0, (tw - words) * 8, c->stream));
+    c->census_valid = false;
+    if (n >= (1ull << 31)) {
+        // A text of this size will be built in key ranges, cut on the census of its 12-mer prefixes (plan_ranges): the text
+        // travels in pieces on a second stream and the census of a piece runs while the next one is on its way (8 ms at
+        // 30 Gbp that no longer stand between the load and the first key range).
+        if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!c->ev_copy) HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+        if (!c->ev_copy2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy2, hipEventDisableTiming));
+        ENSURE(c, c->shard_hist, SHARD_BINS * 8);
+        HIPCHK(c, hipMemsetAsync(c->shard_hist.p, 0, SHARD_BINS * 8, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_copy, c->stream));                       // the separator bitmap and the zeroed census
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));            // (the buffers may still be in use by the load before)
+        const size_t piece = (size_t)1 << 24;                                   // 128 MB = 2^29 positions
+        const size_t npieces = (words + piece - 1) / piece;
+        for (size_t k = 0; k <= npieces; k++) {
+            if (k < npieces) {
+                const size_t a = k * piece, b = std::min(words, a + piece);
+                HIPCHK(c, hipMemcpyAsync(c->text.as<u64>() + a, packed + a, (b - a) * 8, hipMemcpyHostToDevice, c->copy_stream));
+                HIPCHK(c, hipEventRecord((k & 1) ? c->ev_copy2 : c->ev_copy, c->copy_stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, (k & 1) ? c->ev_copy2 : c->ev_copy, 0));
+            }
+            if (k >= 1) {                                                       // census of piece k - 1: its last word needs piece k's first
+                const u64 p0 = (u64)(k - 1) * piece * 32, p1 = std::min<u64>(n, (u64)k * piece * 32);
+                if (p1 > p0)
+                    k_prefix_hist_words<<<1024, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), p0, p1, c->K,
+                                                                              c->shard_hist.as<u64>());
+            }
+        }
+        c->census.resize(SHARD_BINS);
+        HIPCHK(c, hipMemcpyAsync(c->census.data(), c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
+        c->census_valid = true;                                                 // (once the stream has drained, below)
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->text.p, packed, words * 8, hipMemcpyHostToDevice, c->stream));
+    }
     // workspace that depends only on n (the key buffers are sized per key range in debwt_kmer_sort_rle)
     ENSURE(c, c->head_keys, nrec * 8);
     ENSURE(c, c->spkey, c->NS * 8);
@@ -505,14 +542,17 @@ static int plan_ranges(debwt_ctx *c) {
         c->ranges.push_back(r);
         return DEBWT_OK;
     }
-    ENSURE(c, c->shard_hist, SHARD_BINS * 8);
-    HIPCHK(c, hipMemsetAsync(c->shard_hist.p, 0, SHARD_BINS * 8, c->stream));
-    k_prefix_hist_words<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), 0, c->n, c->K,
-                                                              c->shard_hist.as<u64>());
     std::vector<u64> hist(SHARD_BINS);
-    HIPCHK(c, hipMemcpyAsync(hist.data(), c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
-    int rc = sync_check(c);
-    if (rc) return rc;
+    int rc;
+    if (c->census_valid) hist = c->census;                      // taken behind the upload of the text (debwt_load_text)
+    else {
+        ENSURE(c, c->shard_hist, SHARD_BINS * 8);
+        HIPCHK(c, hipMemsetAsync(c->shard_hist.p, 0, SHARD_BINS * 8, c->stream));
+        k_prefix_hist_words<<<2048, DEBWT_BLOCK, 0, c->stream>>>(c->text.as<u64>(), c->sepbits.as<u64>(), 0, c->n, c->K,
+                                                                  c->shard_hist.as<u64>());
+        HIPCHK(c, hipMemcpyAsync(hist.data(), c->shard_hist.p, SHARD_BINS * 8, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = sync_check(c))) return rc;
+    }
     if ((rc = cut_ranges(c, hist.data(), 0, SHARD_BINS, range_cap, c->Mfull))) return rc;
     c->plan_valid = true;
     return DEBWT_OK;
