@@ -1033,6 +1033,10 @@ struct BlueSub {
     u32 *count; u32 cap;                              // entries reserved / capacity
 };
 
+#ifndef BLUE_BINS_DIV_1024
+#define BLUE_BINS_DIV_1024 128         // rows per range the sample-sort split of the 513..1024-row class aims at: 8 ranges (measured
+                                       // at 10 x 300 Mbp, blue stage: 4 ranges 35.8 ms, 8: 32.8, 16: 33.7, 32: 35.3, 64: 41.6)
+#endif
 #ifndef BLUE_SAMPLE_SPLIT
 #define BLUE_SAMPLE_SPLIT 1
 #endif
@@ -1064,7 +1068,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ?
     __shared__ u32 sub_n, sub_i, sub_base;
     // sample-sort split of a large block (workgroup classes): 64 sampled rows, BINS - 1 splitters (measured at 30 Gbp:
     // 8, 16 or 32 ranges per block all give a blue stage of 0.48-0.50 s; 64 ranges overflow the sub-block table)
-    constexpr int BINS = (SPLIT && NT == 256) ? CAP / 32 : 1, SAMPLES = BINS > 1 ? 4 * BINS : 64;
+    constexpr int BINS = (SPLIT && NT == 256) ? (CAP == 1024 ? CAP / BLUE_BINS_DIV_1024 : CAP / 32) : 1, SAMPLES = BINS > 1 ? 4 * BINS : 64;
+    static_assert(SAMPLES <= NT || BINS == 1, "one thread per sampled row");
     __shared__ u64 spl_w[BINS], spl_x[BINS];
     // the sampled windows of the split live in the census words, which are not in use before the first round
     static_assert(BINS == 1 || (size_t)CAP * sizeof(u32) >= (size_t)SAMPLES * 2 * sizeof(u64), "samples alias the census words");
