@@ -37,8 +37,8 @@ HBM (rank 0), barrier + device synchronisation on both sides, slowest rank.  Ext
   cpu_baseline  -- the reference's own stage functions (oracle/_ref, compiled from /root/reference/src in the build
                    container) on this box's host cores on a bounded prefix of record 0 (rank 0, N = 1 only);
   cpu_port      -- the single-threaded CPU oracle on a prefix of the same record;
-  cpu_baseline_at_configs -- the reference on the whole ecoli_4.6M collection (BASELINE configs[0]; --cpu-configs: also
-                   chr1_250M, configs[1]).
+  cpu_baseline_at_configs -- the reference on the whole ecoli_4.6M and chr1_250M collections (BASELINE configs[0] and [1];
+                   --no-cpu-configs leaves out the second, a minute of CPU).
 """
 import argparse
 import json
@@ -299,8 +299,9 @@ def main():
     ap.add_argument("--host-c-timeout", type=float, default=420.0, help=argparse.SUPPRESS)
     ap.add_argument("--no-reserve", action="store_true", help="no debwt_reserve beside the text generation (A/B of the cold path)")
     ap.add_argument("--h2h-plain", action="store_true", help="host-to-host steps with build + fetch one after the other (A/B)")
-    ap.add_argument("--cpu-configs", action="store_true",
-                    help="also time the reference on the whole chr1_250M collection (BASELINE configs[1]; minutes of CPU)")
+    ap.add_argument("--cpu-configs", action="store_true", help=argparse.SUPPRESS)          # (the default now)
+    ap.add_argument("--no-cpu-configs", action="store_true",
+                    help="do not time the reference on the whole chr1_250M collection (BASELINE configs[1]; a minute of CPU)")
     ap.add_argument("--other-mode-timeout", type=float, default=180.0, help=argparse.SUPPRESS)
     ap.add_argument("--no-other-mode", action="store_true",
                     help="N>1 with --mode auto: do not also time the key path the cost model did not choose")
@@ -579,7 +580,7 @@ def main():
             # the reference on WHOLE BASELINE configurations (configs[0] always; configs[1] = minutes of CPU,
             # on request -- profiles/ holds the run): same stage functions, same thread count
             at = {}
-            for wl in ["ecoli_4.6M"] + (["chr1_250M"] if args.cpu_configs else []):
+            for wl in ["ecoli_4.6M"] + ([] if args.no_cpu_configs else ["chr1_250M"]):
                 s2 = SN.Synth.named(wl)
                 at[wl] = cpu_reference(s2.codes(0, 0, int(s2._lens[0])), args.k, threads)
                 s2.close()
