@@ -13,7 +13,9 @@
 #define RS_MAXCHUNKS 16384              // most workgroups (chunks) of a pass; see rs_plan
 #endif
 #define RS_MINCHUNKS 2048               // 8 per CU
+#ifndef RS_CHUNK_TILES
 #define RS_CHUNK_TILES 64               // tiles a chunk should hold when there are more than RS_MINCHUNKS chunks
+#endif
 #define RS_RADIX 256
 
 struct RadixWorkspace {

@@ -64,6 +64,7 @@ __device__ __forceinline__ bool rs_load_key(const u64 *__restrict__ in, const Te
 // Text pass: the tile's text and separator words are staged in LDS once (RS_TILE positions = RS_TILE/32 text words
 // and RS_TILE/64 bitmap words, plus the word before for the predecessor symbol and the words behind for the
 // windows), so a key costs LDS reads instead of five same-address global loads per lane.
+#define RH_ITEMS (RS_ITEMS < 16 ? RS_ITEMS : 16)          // positions a lane of the histogram kernels takes per window
 #define RS_STEXT (RS_TILE / 32 + 3)
 #define RS_SSEP (RS_TILE / 64 + 2)
 struct TextStage {
@@ -148,11 +149,13 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict
         TextStage st{stext, ssep, 0, 0};
         for (u64 tile = beg; tile < end; tile += RS_TILE) {
             rs_stage_text(ts, ts.pos0 + tile, st);
-            u64 k[RS_ITEMS];
-            u32 vm = rs_staged_keys<RS_ITEMS>(ts, st, tile + (u64)threadIdx.x * RS_ITEMS, end, k);
+            for (u32 part = 0; part < RS_ITEMS / RH_ITEMS; part++) {              // (a lane rolls at most 16 positions off one window)
+                u64 k[RH_ITEMS];
+                u32 vm = rs_staged_keys<RH_ITEMS>(ts, st, tile + (u64)part * (RS_BLOCK * RH_ITEMS) + (u64)threadIdx.x * RH_ITEMS, end, k);
 #pragma unroll
-            for (u32 r = 0; r < RS_ITEMS; r++)
-                if ((vm >> r) & 1u) atomicAdd(&h[rs_digit<!AUX>(dg, k[r])], 1u);
+                for (u32 r = 0; r < RH_ITEMS; r++)
+                    if ((vm >> r) & 1u) atomicAdd(&h[rs_digit<!AUX>(dg, k[r])], 1u);
+            }
         }
     }
     __syncthreads();
@@ -175,14 +178,16 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_ranges_kernel(TextKeySrc ts,
     TextStage st{stext, ssep, 0, 0};
     for (u64 tile = beg; tile < end; tile += RS_TILE) {
         rs_stage_text(ts, ts.pos0 + tile, st);
-        u64 k[RS_ITEMS];
-        u32 vm = rs_staged_keys<RS_ITEMS>(ts, st, tile + (u64)threadIdx.x * RS_ITEMS, end, k);
+        for (u32 part = 0; part < RS_ITEMS / RH_ITEMS; part++) {
+            u64 k[RH_ITEMS];
+            u32 vm = rs_staged_keys<RH_ITEMS>(ts, st, tile + (u64)part * (RS_BLOCK * RH_ITEMS) + (u64)threadIdx.x * RH_ITEMS, end, k);
 #pragma unroll
-        for (u32 r = 0; r < RS_ITEMS; r++)
-            if ((vm >> r) & 1u) {
-                const u32 g = rob[(u32)(k[r] >> bin_shift) & 4095u];
-                if (g < (u32)nranges) atomicAdd(&h[g][(u32)(k[r] >> sh.s[g]) & 255u], 1u);
-            }
+            for (u32 r = 0; r < RH_ITEMS; r++)
+                if ((vm >> r) & 1u) {
+                    const u32 g = rob[(u32)(k[r] >> bin_shift) & 4095u];
+                    if (g < (u32)nranges) atomicAdd(&h[g][(u32)(k[r] >> sh.s[g]) & 255u], 1u);
+                }
+        }
     }
     __syncthreads();
     for (int g = 0; g < nranges; g++)
