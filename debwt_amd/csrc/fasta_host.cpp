@@ -418,6 +418,66 @@ int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out,
     return 0;
 }
 
+// BGZF (bgzip, the block gzip of htslib -- and any gzip file whose members all carry the 'BC' extra subfield): every member
+// says how long it is (BSIZE) and how much it holds (ISIZE, its last four bytes), so the members are found by a walk over
+// their headers and inflated independently, each into its place in the output, by `threads` threads (raw inflate + the
+// member's CRC32, as gzread checks it).  Returns 1 when the file is not of that shape (the caller inflates it serially:
+// a plain gzip stream is one member), 0 on success, -1 on a damaged member.
+static int inflate_bgzf(const unsigned char *z, size_t zlen, int threads, char **out_buf, size_t *out_len) {
+    std::vector<size_t> off, uoff, dlen;
+    size_t p = 0, total = 0;
+    while (p < zlen) {
+        if (zlen - p < 28 || z[p] != 0x1f || z[p + 1] != 0x8b || z[p + 2] != 8 || z[p + 3] != 4) return 1;   // FEXTRA and nothing else
+        const size_t xlen = z[p + 10] | ((size_t)z[p + 11] << 8);
+        size_t q = p + 12, bsize = 0;
+        const size_t xend = q + xlen;
+        if (xend + 8 > zlen) return 1;
+        while (q + 4 <= xend) {
+            const size_t slen = z[q + 2] | ((size_t)z[q + 3] << 8);
+            if (z[q] == 'B' && z[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = (z[q + 4] | ((size_t)z[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (!bsize || p + bsize > zlen || bsize < 12 + xlen + 8) return 1;
+        const size_t isize = z[p + bsize - 4] | ((size_t)z[p + bsize - 3] << 8) | ((size_t)z[p + bsize - 2] << 16) | ((size_t)z[p + bsize - 1] << 24);
+        off.push_back(p + 12 + xlen); dlen.push_back(bsize - (12 + xlen) - 8); uoff.push_back(total);
+        total += isize;
+        p += bsize;
+    }
+    if (off.empty()) return 1;
+    char *buf = (char *)malloc(total + 1);
+    if (!buf) return -1;
+    const size_t nb = off.size();
+    if (threads < 1) threads = 1;
+    const size_t T = std::min<size_t>((size_t)threads, nb);
+    std::vector<int> bad(T, 0);
+    auto work = [&](size_t t) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { bad[t] = 1; return; }
+        for (size_t b = nb * t / T; b < nb * (t + 1) / T && !bad[t]; b++) {
+            const size_t want = (b + 1 < nb ? uoff[b + 1] : total) - uoff[b];
+            inflateReset(&zs);
+            zs.next_in = const_cast<Bytef *>(z + off[b]); zs.avail_in = (uInt)dlen[b];
+            zs.next_out = (Bytef *)buf + uoff[b]; zs.avail_out = (uInt)want;
+            const int r = want ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+            const unsigned char *tr = z + off[b] + dlen[b];                              // CRC32, ISIZE
+            const uLong crc = tr[0] | ((uLong)tr[1] << 8) | ((uLong)tr[2] << 16) | ((uLong)tr[3] << 24);
+            if ((want && (r != Z_STREAM_END || zs.avail_out != 0)) || crc32(crc32(0L, Z_NULL, 0), (const Bytef *)buf + uoff[b], (uInt)want) != crc)
+                bad[t] = 1;
+        }
+        inflateEnd(&zs);
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (int b : bad) if (b) { free(buf); return -1; }
+    *out_buf = buf; *out_len = total;
+    return 0;
+}
+
 int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, size_t errlen, IngestOpts opts) {
     auto t0 = std::chrono::steady_clock::now();
     int fd = open(path, O_RDONLY);
@@ -428,7 +488,26 @@ int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, s
     if (pread(fd, magic, 2, 0) != 2) { close(fd); return fail(err, errlen, "unreadable input"); }
     int rc;
     if (magic[0] == 0x1f && magic[1] == 0x8b) {
-        // gzip: inflate is serial; the parse behind it is not
+        {   // block gzip first: its members inflate in parallel
+            void *zm = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (zm != MAP_FAILED) {
+                char *buf = nullptr;
+                size_t len = 0;
+                const int br = inflate_bgzf((const unsigned char *)zm, (size_t)st.st_size, threads, &buf, &len);
+                munmap(zm, (size_t)st.st_size);
+                if (br < 0) { close(fd); return fail(err, errlen, "gzip stream is damaged"); }
+                if (br == 0) {
+                    close(fd);
+                    out->seconds_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    auto t1 = std::chrono::steady_clock::now();
+                    rc = pack_fasta_buffer(buf, len, threads, out, err, errlen, opts);
+                    out->seconds_pack = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+                    free(buf);
+                    return rc;
+                }
+            }
+        }
+        // a plain gzip stream (one member): inflate is serial; the parse behind it is not
         close(fd);
         gzFile f = gzopen(path, "rb");
         if (!f) return fail(err, errlen, "can not open ref file");

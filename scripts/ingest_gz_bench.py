@@ -1,0 +1,47 @@
+"""Ingest rate of plain, gzip and block-gzip (BGZF) FASTA on the host threads: python scripts/ingest_gz_bench.py [Mbp=1000] [threads]
+(host only: no GPU is used)"""
+import os, struct, sys, time, zlib, gzip
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from debwt_amd import api, synth_native as SN
+mbp = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else SN.default_threads()
+syn = SN.Synth(mbp * 1_000_000, 1, 24)
+asc = np.frombuffer(b"ACGT", dtype=np.uint8)
+d = "/dev/shm/debwt_gzbench"; os.makedirs(d, exist_ok=True)
+fa = f"{d}/x.fa"
+with open(fa, "wb") as f:
+    a = 0
+    for j, ln in enumerate(syn._lens):
+        f.write(b">chr%d\n" % j)
+        s = asc[syn.codes(0, a, a + int(ln))].tobytes()
+        for o in range(0, len(s), 1 << 24): f.write(s[o:o + (1 << 24)])
+        f.write(b"\n"); a += int(ln)
+data = open(fa, "rb").read()
+t0 = time.time()
+with open(f"{d}/x.plain.fa.gz", "wb") as f:
+    co = zlib.compressobj(1, zlib.DEFLATED, 31)
+    for o in range(0, len(data), 1 << 24): f.write(co.compress(data[o:o + (1 << 24)]))
+    f.write(co.flush())
+t1 = time.time()
+with open(f"{d}/x.bgzf.fa.gz", "wb") as f:
+    B = 65280
+    for a in list(range(0, len(data), B)) + [len(data)]:
+        chunk = data[a:a + B] if a < len(data) else b""
+        co = zlib.compressobj(1, zlib.DEFLATED, -15); body = co.compress(chunk) + co.flush()
+        f.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1))
+        f.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+print(f"{mbp} Mbp FASTA: {len(data) / 1e9:.2f} GB; gzip -1 written in {t1 - t0:.0f} s, BGZF in {time.time() - t1:.0f} s; {threads} host threads", flush=True)
+ref = None
+for name in ("x.fa", "x.plain.fa.gz", "x.bgzf.fa.gz"):
+    best = None
+    for _ in range(2):
+        t0 = time.time(); w, n, sep, s_read, s_pack = api.pack_fasta(f"{d}/{name}", threads); dt = time.time() - t0
+        best = min(best, (dt, s_read, s_pack)) if best else (dt, s_read, s_pack)
+    if ref is None: ref = (w.copy(), n)
+    same = n == ref[1] and np.array_equal(w, ref[0])
+    print(f"{name:16s} file {os.path.getsize(f'{d}/{name}') / 1e9:6.2f} GB: read/inflate {best[1]:6.2f} s + parse/pack {best[2]:5.2f} s = "
+          f"{len(data) / 1e9 / (best[1] + best[2]):6.2f} GB/s of FASTA text ({mbp / 1e3 / (best[1] + best[2]):.2f} Gbp/s), same text: {same}", flush=True)
+for name in os.listdir(d): os.remove(f"{d}/{name}")
+os.rmdir(d)

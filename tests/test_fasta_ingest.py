@@ -260,6 +260,43 @@ def test_pack_fastq_records_without_qualities_and_fasta_records_mixed_in(tmp_pat
         _check(p, recs, threads)
 
 
+def _write_bgzf(path, data, block=65280):
+    """Block gzip as bgzip writes it: one gzip member per block, each with the 'BC' extra subfield that holds its length,
+    an empty member at the end."""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for a in list(range(0, len(data), block)) + [len(data)]:
+            chunk = data[a:a + block] if a < len(data) else b""
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = co.compress(chunk) + co.flush()
+            bsize = 12 + 6 + len(body) + 8
+            f.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+            f.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
+@pytest.mark.parametrize("threads", [1, 3, 16])
+def test_pack_block_gzip_in_parallel(tmp_path, threads):
+    """BGZF input: the members are found by their headers and inflated by the ingest threads in parallel -- the same packed
+    text as from the plain file; python's gzip module reads the file too (it is ordinary multi-member gzip); a member with
+    a wrong CRC is an error."""
+    rng = np.random.default_rng(15)
+    recs = [rng.integers(0, 4, size=int(rng.integers(40, 90_000))).astype(np.uint8) for _ in range(40)]
+    plain = str(tmp_path / "b.fa")
+    _write(plain, recs, width=70)
+    data = open(plain, "rb").read()
+    p = str(tmp_path / "b.fa.gz")
+    _write_bgzf(p, data)
+    assert gzip.open(p, "rb").read() == data
+    _check(p, recs, threads)
+    raw = bytearray(open(p, "rb").read())
+    raw[len(raw) // 2] ^= 0x55                                   # damage inside a member
+    bad = str(tmp_path / "bad.fa.gz")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(api.DebwtError):
+        api.pack_fasta(bad, threads)
+
+
 def test_pack_fastq_with_ambiguity_letters(tmp_path):
     rng = np.random.default_rng(13)
     recs = [rng.integers(0, 4, size=150).astype(np.uint8) for _ in range(50)]
