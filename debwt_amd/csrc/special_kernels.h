@@ -52,14 +52,14 @@ struct SxText {
 
 // ---- 1. ranks of the record starts ----------------------------------------------------------------------------------
 
-__global__ void k_sx_init(u32 *__restrict__ ord, u32 *__restrict__ gid, u32 *__restrict__ act, u64 N) {
+__global__ __launch_bounds__(256) void k_sx_init(u32 *__restrict__ ord, u32 *__restrict__ gid, u32 *__restrict__ act, u64 N) {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N) return;
     ord[j] = (u32)j; gid[j] = 0; act[j] = (u32)j;
 }
 
 // window of round w for the a-th active place; first sort key = low 32 bits of the window | a
-__global__ void k_sx_round_keys(SxText T, const u32 *__restrict__ ord, const u32 *__restrict__ act, u64 na, u64 w,
+__global__ __launch_bounds__(256) void k_sx_round_keys(SxText T, const u32 *__restrict__ ord, const u32 *__restrict__ act, u64 na, u64 w,
                                 int bA, u64 *__restrict__ valbuf, u64 *__restrict__ keyA) {
     const u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= na) return;
@@ -70,7 +70,7 @@ __global__ void k_sx_round_keys(SxText T, const u32 *__restrict__ ord, const u32
 }
 // second / third sort key of a round, in the order the pass before left (the passes are stable and sort the key bits
 // above the payload only, so the payload -- the active element -- rides along): high 31 bits of the window, tie group
-__global__ void k_sx_rekey(const u64 *__restrict__ src, const u64 *__restrict__ valbuf, const u32 *__restrict__ gid,
+__global__ __launch_bounds__(256) void k_sx_rekey(const u64 *__restrict__ src, const u64 *__restrict__ valbuf, const u32 *__restrict__ gid,
                            const u32 *__restrict__ act, u64 na, int bA, int which, u64 *__restrict__ dst) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= na) return;
@@ -78,7 +78,7 @@ __global__ void k_sx_rekey(const u64 *__restrict__ src, const u64 *__restrict__ 
     dst[i] = ((which ? (u64)gid[act[a]] : (valbuf[a] >> 32)) << bA) | a;
 }
 // records, windows and groups in the order (group, window)
-__global__ void k_sx_gather(const u64 *__restrict__ sorted, int bA, const u64 *__restrict__ valbuf,
+__global__ __launch_bounds__(256) void k_sx_gather(const u64 *__restrict__ sorted, int bA, const u64 *__restrict__ valbuf,
                             const u32 *__restrict__ ord, const u32 *__restrict__ gid, const u32 *__restrict__ act, u64 na,
                             u32 *__restrict__ rec_s, u64 *__restrict__ val_s, u32 *__restrict__ gid_s) {
     const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,7 +100,7 @@ struct SxHeadF {
 };
 __global__ void k_sx_sentinel(u32 *__restrict__ headpos, const u32 *__restrict__ total, u32 value) { headpos[*total] = value; }
 // new order and groups at the active places; which places stay active (their group still holds several records)
-__global__ void k_sx_apply(const u32 *__restrict__ rec_s, const u32 *__restrict__ ordv, const u32 *__restrict__ headpos,
+__global__ __launch_bounds__(256) void k_sx_apply(const u32 *__restrict__ rec_s, const u32 *__restrict__ ordv, const u32 *__restrict__ headpos,
                            const u32 *__restrict__ act, u64 na, u32 *__restrict__ ord, u32 *__restrict__ gid,
                            u8 *__restrict__ stay) {
     const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,7 +117,7 @@ struct SxStayF {
     __device__ u32 recount(u64 f) const { return stay[f]; }
     __device__ void emit(u64 f, u32 off, u32 c) const { if (c) act_new[off] = act[f]; }
 };
-__global__ void k_sx_rank_of(const u32 *__restrict__ ord, u64 N, u32 *__restrict__ rank) {
+__global__ __launch_bounds__(256) void k_sx_rank_of(const u32 *__restrict__ ord, u64 N, u32 *__restrict__ rank) {
     const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < N) rank[ord[p]] = (u32)p;
 }
@@ -128,7 +128,7 @@ __global__ void k_sx_rank_of(const u32 *__restrict__ ord, u64 N, u32 *__restrict
 // first sort key of every item, and its padded key once for all passes: in enumeration order the separator positions and
 // the text windows are read in sequence; the passes then fetch one word per item instead of three scattered ones
 // (item record: .x = padded key, .y = text position | BWT symbol << 62)
-__global__ void k_it_pass1(SxText T, const u32 *__restrict__ rank, u64 NS, int bR, int bP, u64 *__restrict__ key,
+__global__ __launch_bounds__(256) void k_it_pass1(SxText T, const u32 *__restrict__ rank, u64 NS, int bR, int bP, u64 *__restrict__ key,
                            ulonglong2 *__restrict__ item) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NS) return;
@@ -141,7 +141,7 @@ __global__ void k_it_pass1(SxText T, const u32 *__restrict__ rank, u64 NS, int b
     item[i] = make_ulonglong2(T.item_key(r, d), p | ((u64)text_symbol(T.text, p - 1) << 62));   // always a base before: records are longer than K
 }
 // the next pass's key bits above the item id, in the order the pass before left: low / high 31 bits of the padded key
-__global__ void k_it_rekey(const ulonglong2 *__restrict__ item, const u64 *__restrict__ src, u64 NS, int hi, int bP,
+__global__ __launch_bounds__(256) void k_it_rekey(const ulonglong2 *__restrict__ item, const u64 *__restrict__ src, u64 NS, int hi, int bP,
                            u64 *__restrict__ dst) {
     const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= NS) return;
@@ -149,7 +149,7 @@ __global__ void k_it_rekey(const ulonglong2 *__restrict__ item, const u64 *__res
     const u64 k62 = item[i].x;
     dst[q] = ((hi ? (k62 >> 31) : (k62 & 0x7FFFFFFFull)) << bP) | i;
 }
-__global__ void k_it_out(SxText T, const ulonglong2 *__restrict__ item, const u64 *__restrict__ sorted, int bP, u64 NS,
+__global__ __launch_bounds__(256) void k_it_out(SxText T, const ulonglong2 *__restrict__ item, const u64 *__restrict__ sorted, int bP, u64 NS,
                          u64 *__restrict__ spkey, u8 *__restrict__ spchr, u64 *__restrict__ sppos, u32 *__restrict__ sprec,
                          u8 *__restrict__ spd) {
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,7 +184,7 @@ struct SxBranchF {
     __device__ void emit(u64 s, u32 off, u32 c) const { grp[s] = off + c - 1u; }
 };
 // a group whose members do not all continue with the same symbol K ahead is a branch (src/collect#$.c:540-593)
-__global__ void k_br_diff(SxText T, const u64 *__restrict__ sppos, const u32 *__restrict__ grp, u64 NS,
+__global__ __launch_bounds__(256) void k_br_diff(SxText T, const u64 *__restrict__ sppos, const u32 *__restrict__ grp, u64 NS,
                           u8 *__restrict__ gflag) {
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0 || s >= NS) return;
@@ -199,7 +199,7 @@ struct SxBranchEmitF {
 };
 // node at the start of every record (| 3: the fake predecessor of a record start) and node in front of every
 // separator (| 1: multi-out fact), src/collect#$.c:468-533
-__global__ void k_heads_tails(SxText T, u64 *__restrict__ head_keys, u64 *__restrict__ tail_facts) {
+__global__ __launch_bounds__(256) void k_heads_tails(SxText T, u64 *__restrict__ head_keys, u64 *__restrict__ tail_facts) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= T.nrec) return;
     head_keys[r] = ((text_window(T.text, T.rec_start(r)) >> (64 - 2 * T.K)) << 2) | 3ull;
