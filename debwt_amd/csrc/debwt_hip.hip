@@ -57,6 +57,7 @@ struct debwt_ctx {
         red, red_q, mi_j0, mi_freq, bstart, cursor, blue, spkey, sprow, spchr, branch, pflag, spsym, spn, bwt,
         hmask, hash_rows, dollar, large_q, large_k0, large_en, rowsym, momask, mimask, rbits, rs_over, rs_skew, mi_list, htab, fact_work, facts_all, shard_hist, dest_tab, qbounds, qcursor, qlist, qwave;
     DevBuf brbits;              // the special branches as a bitmap over the text positions (collections of many records)
+    DevBuf blue_done;           // one byte per multi-in block: finished by k_blue_classify
     bool branch_bitmap = false;
     DevBuf sx, sppos, sprec, tail_d;   // special-region module on the device: scratch arena, positions / records of the sorted items, tail facts
     bool special_dev = false;   // the tables of this build were made on the device (spkey / spchr / branch / head_keys / tail_d)
@@ -260,7 +261,8 @@ static std::vector<DevBuf *> all_buffers(debwt_ctx *c) {
             &c->mi_list, &c->htab, &c->fact_work, &c->facts_all, &c->shard_hist, &c->dest_tab, &c->qbounds, &c->qcursor,
             &c->sx, &c->sppos, &c->sprec, &c->tail_d, &c->brbits,
             &c->blk_j0, &c->blk_freq, &c->blk_start, &c->facts_acc, &c->large_tmp, &c->blue_tmp, &c->sub_start, &c->sub_j0,
-            &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf, &c->vidx, &c->vtmp, &c->qlist, &c->qwave};
+            &c->sub_freq, &c->sub_depth, &c->range_hist, &c->rs_rle, &c->ls_buf, &c->vidx, &c->vtmp, &c->qlist, &c->qwave,
+            &c->blue_done};
 }
 
 extern "C" const char *debwt_strerror(int code) {
@@ -1464,18 +1466,35 @@ static int blue_sort_part(debwt_ctx *c, const BlueQueue &bq, u64 q0, u64 nq, u64
     // 86 + 156 ms for blocks + queued ranges; now 6.5 + 67 and 22 + 78 ms)
     k_blue_refine<64, 256, 128><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, 128u, c->spn.as<u64>(), c->S,
                                                          c->mchar.as<u8>(), nullptr, nullptr, sub);
+    // blocks of 257 rows and more in a collection of many genomes: by classes around sampled splitters first
+    // (k_blue_classify); what that finishes is marked in `done` and skipped by the kernels behind it, which take the blocks it
+    // left (cfg.reserved bit 19: those kernels alone; bit 20: by classes whatever the number of such blocks -- tests)
+    const bool split1024 = c->n1024 >= 1024;
+    const u8 *done = nullptr;
+    if ((split1024 || (c->cfg.reserved & 1048576)) && sub.cap && !(c->cfg.reserved & 524288)) {
+        ENSURE(c, c->blue_done, c->Q + 64);
+        u8 *dn = c->blue_done.as<u8>() + q0;
+        HIPCHK(c, hipMemsetAsync(dn, 0, Q, c->stream));
+        const u32 gc = (u32)std::min<u64>(Q, 1u << 14);
+        k_blue_classify<BLUE_WAVE_CAP, BLUE_WAVE_CAP><<<gc, 256, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, 256u, c->spn.as<u64>(),
+                                                                                 c->S, c->mchar.as<u8>(), sub, dn);
+        k_blue_classify<1024, BLUE_WAVE_CAP><<<gc, 256, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, (u32)BLUE_WAVE_CAP,
+                                                                        c->spn.as<u64>(), c->S, c->mchar.as<u8>(), sub, dn);
+        k_blue_classify<BLUE_LDS_CAP, BLUE_WAVE_CAP><<<(u32)std::min<u64>(Q, 1u << 12), 256, 0, c->stream>>>(
+            c->blue.as<u64>(), bst, bfr, bj0, Q, 1024u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(), sub, dn);
+        done = dn;
+    }
     k_blue_refine<256, BLUE_WAVE_CAP, 128><<<(u32)std::min<u64>(Q, 1u << 14), 256, 0, c->stream>>>(
-        c->blue.as<u64>(), bst, bfr, bj0, Q, 256u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, sub);
+        c->blue.as<u64>(), bst, bfr, bj0, Q, 256u, c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, sub, done);
     u32 g2 = (u32)std::min<u64>(Q, 1u << 12);
     // collections of many genomes put most rows into blocks of 513..1024 rows: those get a kernel of their own
     // with half the LDS footprint (four workgroups per CU instead of two); otherwise one kernel for 513..2048
-    const bool split1024 = c->n1024 >= 1024;
     if (split1024)
         k_blue_refine<256, 1024, BLUE_WAVE_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, (u32)BLUE_WAVE_CAP,
-                                                                      c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, sub);
+                                                                      c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, sub, done);
     k_blue_refine<256, BLUE_LDS_CAP, BLUE_WAVE_CAP><<<g2, 256, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q,
                                                                   split1024 ? 1024u : (u32)BLUE_WAVE_CAP, c->spn.as<u64>(), c->S,
-                                                                  c->mchar.as<u8>(), nullptr, nullptr, sub);
+                                                                  c->mchar.as<u8>(), nullptr, nullptr, sub, done);
     // heavy-tail blocks (satellite / poly-A nodes), before the queue is drained: split in HBM into ranges the LDS
     // kernels take (queued like the tie groups); what a split cannot separate goes through the bitonic network
     if (nl && (rc = sort_large_blocks(c, sub, l0, nl))) return rc;

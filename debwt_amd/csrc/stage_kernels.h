@@ -1054,7 +1054,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ?
                                                      const u32 *__restrict__ mi_freq, const u64 *__restrict__ mi_j0,
                                                      u32 Q, u32 lo_excl, const u64 *__restrict__ spn, u64 S,
                                                      u8 *__restrict__ mchar, const u32 *__restrict__ depth0,
-                                                     const u32 *__restrict__ Qdev, BlueSub sub) {
+                                                     const u32 *__restrict__ Qdev, BlueSub sub,
+                                                     const u8 *__restrict__ done = nullptr) {
+    // done (optional): blocks k_blue_classify has finished (one byte per table entry) are skipped
     __shared__ u64 se[CAP];     // entries
     __shared__ u64 sw[CAP];     // current window, first 21 symbols
     __shared__ u64 sx[CAP];     //                 next 21 symbols
@@ -1087,7 +1089,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ?
     for (u64 q0 = (u64)blockIdx.x * E; q0 < Q; q0 += (u64)gridDim.x * E) {
       const u64 ql = q0 + (tid & 63u);
       const u32 ml = ((tid & 63u) < E && ql < Q) ? mi_freq[ql] : 0u;
-      u64 todo = __ballot(ml > lo_excl && ml <= (u32)CAP);
+      u64 todo = __ballot(ml > lo_excl && ml <= (u32)CAP && !(done && done[ql]));
       for (; todo; todo &= todo - 1) {
         const u32 q = (u32)(q0 + (u32)__builtin_ctzll(todo));
         const u32 m = mi_freq[q];
@@ -1386,6 +1388,145 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ?
                 mchar[j0 + x] = (u8)(e & 15);
             }
         __syncthreads();
+      }
+    }
+}
+
+// Blocks of a collection of many genomes by CLASSES around sampled splitters (what rs_local_unfit_kernel does for the key
+// sort): a block of 513..1024 rows is a repeat family's node in every genome -- a hundred copies times ten genomes -- and
+// the rows of one copy share their first 42 SP symbols and, in 99 % of the cases, their BWT symbol.  256 evenly spaced rows
+// are sorted by their first pair of windows and their distinct pairs become splitters; every row finds its class by
+// bisection -- "equal to splitter i" or "between splitters i-1 and i" -- a class counter gives it a place in its class and
+// a class mask collects the BWT symbols of the class.  A class with one symbol is finished wherever its rows land inside
+// it; a class with several is queued for the wave kernels as a block of its own -- one pair of windows deeper when it is
+// a class of equals.  The rows go straight to their class's slots in HBM: no rounds, no network, no hand-off of every
+// range.  A block with a class above `SPLIT` rows that needs sorting (or when the queue is full) is left to
+// k_blue_refine, which skips the blocks marked in `done`.
+template <int CAP, int SPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAP <= 1024 ? 4 : 2)))
+void k_blue_classify(u64 *__restrict__ blue, const u64 *__restrict__ bstart, const u32 *__restrict__ mi_freq,
+                     const u64 *__restrict__ mi_j0, u32 Q, u32 lo_excl, const u64 *__restrict__ spn, u64 S,
+                     u8 *__restrict__ mchar, BlueSub sub, u8 *__restrict__ done) {
+    constexpr int NT = 256, EPT = CAP / NT, NS = 256;
+    __shared__ u64 se[CAP], sw[CAP], sx[CAP];
+    __shared__ u64 pw[NS], px[NS];            // the sample, then its distinct pairs
+    __shared__ u32 ccnt[2 * NS], cmsk[2 * NS];   // class 2 i: between splitters i - 1 and i; 2 i + 1: equal to splitter i
+    __shared__ u32 wtmp[DEBWT_WAVES + 1];
+    __shared__ u32 flag, sub_base;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 E = (u64)Q >= (u64)gridDim.x * 64 ? 64u : 1u;
+    for (u64 q0 = (u64)blockIdx.x * E; q0 < Q; q0 += (u64)gridDim.x * E) {
+      const u64 ql = q0 + lane;
+      const u32 ml = (lane < E && ql < Q) ? mi_freq[ql] : 0u;
+      u64 todo = __ballot(ml > lo_excl && ml <= (u32)CAP);
+      for (; todo; todo &= todo - 1) {
+        const u32 q = (u32)(q0 + (u32)__builtin_ctzll(todo));
+        const u32 m = mi_freq[q];
+        const u64 b0 = bstart[q], j0 = mi_j0[q];
+        __syncthreads();                                       // the block before is out of LDS
+        if (tid == 0) flag = 0;
+        ccnt[tid] = 0; ccnt[tid + NT] = 0; cmsk[tid] = 0; cmsk[tid + NT] = 0;
+        __syncthreads();
+        u32 mask = 0;
+        for (u32 x = tid; x < m; x += NT) {
+            const u64 e = blue[b0 + x];
+            se[x] = e; mask |= 1u << (e & 15);
+            const u64 pos = e >> 4;
+            const bool live = pos < S;
+            sw[x] = live ? sp_window(spn, pos) : 0ull;
+            sx[x] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
+        }
+        if (mask) atomicOr(&flag, mask);
+        __syncthreads();
+        if ((flag & (flag - 1)) == 0) {                        // one BWT symbol in the whole block: any order is the order
+            for (u32 x = tid; x < m; x += NT) mchar[j0 + x] = (u8)(se[x] & 15);
+            if (tid == 0) done[q] = 1;
+            continue;
+        }
+        // the sample, sorted by (first window, second window), one row per thread
+        u64 vw, vx;
+        { const u32 i = (u32)(((u64)tid * m) >> 8); vw = sw[i]; vx = sx[i]; }
+#pragma unroll
+        for (int lk = 1; lk <= 8; lk++) {
+            const u32 kk = 1u << lk;
+#pragma unroll
+            for (int lj = lk - 1; lj >= 0; lj--) {
+                const u32 d = 1u << lj;
+                u64 qw, qx;
+                if (lj < 6) { qw = __shfl_xor(vw, (int)d, 64); qx = __shfl_xor(vx, (int)d, 64); }
+                else { pw[tid] = vw; px[tid] = vx; __syncthreads(); qw = pw[tid ^ d]; qx = px[tid ^ d]; __syncthreads(); }
+                const bool take_min = ((tid & d) == 0) == ((tid & kk) == 0);
+                const bool pless = qw != vw ? qw < vw : qx < vx;
+                if (take_min == pless) { vw = qw; vx = qx; }
+            }
+        }
+        pw[tid] = vw; px[tid] = vx;
+        __syncthreads();
+        const bool head = tid == 0 || pw[tid - 1] != vw || px[tid - 1] != vx;
+        const u64 bm = __ballot(head);
+        if (lane == 0) wtmp[w] = (u32)__popcll(bm);
+        __syncthreads();
+        u32 sbase = 0, U = 0;
+#pragma unroll
+        for (u32 i = 0; i < DEBWT_WAVES; i++) { const u32 c = wtmp[i]; sbase += i < w ? c : 0u; U += c; }
+        const u32 sidx = sbase + (u32)__popcll(bm & lanemask_lt());
+        if (head && sidx < NS - 1) { pw[sidx] = vw; px[sidx] = vx; }   // sidx <= tid: the slots of later threads are untouched
+        if (U > NS - 1) U = NS - 1;
+        __syncthreads();
+        // class and place in the class of every row
+        u32 cr[EPT];
+#pragma unroll
+        for (int r = 0; r < EPT; r++) {
+            const u32 x = (u32)r * NT + tid;
+            cr[r] = 0xFFFFFFFFu;
+            if (x < m) {
+                const u64 rw = sw[x], rx = sx[x];
+                u32 lo = 0;                                    // splitters below the row
+#pragma unroll
+                for (u32 step = NS / 2; step; step >>= 1) {
+                    const u32 c = lo + step;
+                    if (c <= U) {
+                        const u64 cw = pw[c - 1];
+                        if (cw != rw ? cw < rw : px[c - 1] < rx) lo = c;
+                    }
+                }
+                const u32 cls = 2u * lo + ((lo < U && pw[lo] == rw && px[lo] == rx) ? 1u : 0u);
+                cr[r] = (cls << 16) | atomicAdd(&ccnt[cls], 1u);
+                atomicOr(&cmsk[cls], 1u << (se[x] & 15));
+            }
+        }
+        __syncthreads();
+        // class starts; classes that still need sorting (several rows, several symbols) become blocks of the queue
+        const u32 v0 = ccnt[2 * tid], v1 = ccnt[2 * tid + 1];
+        const u32 k0 = cmsk[2 * tid], k1 = cmsk[2 * tid + 1];
+        const bool u0 = v0 > 1 && (k0 & (k0 - 1)) != 0, u1 = v1 > 1 && (k1 & (k1 - 1)) != 0;
+        u32 total, qtot;
+        const u32 cbase = block_scan_excl(v0 + v1, wtmp, &total);
+        const u32 qbase_ = block_scan_excl((u0 ? 1u : 0u) + (u1 ? 1u : 0u), wtmp, &qtot);
+        const bool too_big = (u0 && v0 > (u32)SPLIT) || (u1 && v1 > (u32)SPLIT);
+        if (tid == 0) sub_base = qtot ? atomicAdd(sub.count, qtot) : 0u;
+        const bool give_up = __syncthreads_or((int)too_big) != 0;
+        if (give_up || (qtot && (u64)sub_base + qtot > (u64)sub.cap)) continue;     // k_blue_refine's (nothing was moved)
+        ccnt[2 * tid] = cbase; ccnt[2 * tid + 1] = cbase + v0;
+        if (u0) {
+            const u32 e = sub_base + qbase_;
+            sub.start[e] = b0 + cbase; sub.freq[e] = v0; sub.j0[e] = j0 + cbase; sub.depth[e] = 0u;
+        }
+        if (u1) {
+            const u32 e = sub_base + qbase_ + (u0 ? 1u : 0u);
+            sub.start[e] = b0 + cbase + v0; sub.freq[e] = v1; sub.j0[e] = j0 + cbase + v0; sub.depth[e] = 1u;   // 42 symbols are equal
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < EPT; r++)
+            if (cr[r] != 0xFFFFFFFFu) {
+                const u32 x = (u32)r * NT + tid;
+                const u32 pos = ccnt[cr[r] >> 16] + (cr[r] & 0xFFFFu);
+                const u64 e = se[x];
+                blue[b0 + pos] = e;
+                mchar[j0 + pos] = (u8)(e & 15);
+            }
+        if (tid == 0) done[q] = 1;
       }
     }
 }

@@ -333,6 +333,37 @@ def test_hip_block_size_classes(api, oracle):
     d.close()
 
 
+@pytest.mark.parametrize("tune", [1048576, 1048576 + 128, 524288])
+def test_blue_blocks_by_classes(api, oracle, tune):
+    """Blocks of 257..2048 rows sorted by classes around sampled splitters (k_blue_classify; tune bit 20 takes that kernel
+    for any number of such blocks, bit 19 never): copies that tie beyond 42 SP symbols with several BWT symbols (queued one
+    pair of windows deeper), copies that differ early, a block of one symbol, and -- with the queue switched off (bit 7) --
+    every block left to the kernel behind it."""
+    rng = np.random.default_rng(31)
+    parts = []
+    for copies, tail in ((700, 3), (900, 40), (600, 400), (1000, 0), (550, 90), (300, 30), (450, 200), (1500, 60), (1900, 5)):
+        unit = rng.integers(0, 4, size=60).astype(np.uint8)
+        variants = [rng.integers(0, 4, size=max(tail, 1)).astype(np.uint8) for _ in range(7)]
+        for i in range(copies):
+            parts.append(rng.integers(0, 4, size=1).astype(np.uint8) if tail else np.array([i % 2], dtype=np.uint8))
+            parts.append(unit)
+            if tail:
+                v = variants[i % 7].copy()
+                if tail > 50 and i % 3 == 0:
+                    v[tail // 2] = (v[tail // 2] + 1) & 3
+                parts.append(v)
+            parts.append(rng.integers(0, 4, size=int(rng.integers(3, 9))).astype(np.uint8))
+    recs = [np.concatenate(parts), rng.integers(0, 4, size=500).astype(np.uint8)]
+    ow, oh, od, ost = oracle.build_bwt(oracle.sym_from_codes(recs), 32)
+    d = api.DeBWT(k=32, tune=tune)
+    d.load_records(recs)
+    for _ in range(2):
+        d.build()
+        words, hrows, drow = d.fetch()
+        assert np.array_equal(words, ow) and np.array_equal(hrows, oh) and drow == od, tune
+    d.close()
+
+
 @pytest.mark.parametrize("tune", [0, 1024, 128])
 def test_hip_large_block_path(api, oracle, tune):
     """A node with more occurrences than one workgroup's LDS holds: split in HBM into ranges for the LDS kernels (0),
