@@ -1425,6 +1425,9 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
     return DEBWT_OK;
 }
 
+#ifndef BLUE_QUEUE_LEVELS
+#define BLUE_QUEUE_LEVELS 1            // (measured at 10 x 300 Mbp: 1, 2, 3, 4, 6 levels all give a blue stage of 19.6-20.0 ms)
+#endif
 // the sub-block table of a blue sort (BlueSub): the deep tie groups of the larger size classes wait there for the
 // wave-per-block kernels
 struct BlueQueue { BlueSub sub; u32 *count; u32 cap; };
@@ -1501,6 +1504,17 @@ static int blue_sort_part(debwt_ctx *c, const BlueQueue &bq, u64 q0, u64 nq, u64
     // the queued groups: blocks of their own that start `depth` windows in (<= 128 rows from the 512 class,
     // <= 512 rows from the 2048 class and from the split of the large blocks: LS_QUEUE_CAP)
     const u32 gs = std::min<u32>(sub_cap, 1u << 16);
+    if (done) {
+        // the queued groups of 129..512 rows by classes as well, one pair of windows deeper each time (two levels): what is
+        // finished leaves the queue, what still ties is queued again for the wave kernels below
+        u32 *snap = sub_count + 1;                                 // (a spare word behind the counter)
+        for (int level = 0; level < BLUE_QUEUE_LEVELS; level++) {
+            k_copy_u32<<<1, 1, 0, c->stream>>>(sub_count, snap);
+            k_blue_classify<BLUE_WAVE_CAP, BLUE_WAVE_CAP><<<std::min<u32>(gs, 1u << 14), 256, 0, c->stream>>>(
+                c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 128u, c->spn.as<u64>(),
+                c->S, c->mchar.as<u8>(), sub, nullptr, c->sub_depth.as<u32>(), snap, c->sub_freq.as<u32>());
+        }
+    }
     k_blue_refine<64, 128, 0><<<gs, 64, 0, c->stream>>>(
         c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, 0u,
         c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);

@@ -1404,9 +1404,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ?
 // k_blue_refine, which skips the blocks marked in `done`.
 template <int CAP, int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAP <= 1024 ? 4 : 2)))
-void k_blue_classify(u64 *__restrict__ blue, const u64 *__restrict__ bstart, const u32 *__restrict__ mi_freq,
-                     const u64 *__restrict__ mi_j0, u32 Q, u32 lo_excl, const u64 *__restrict__ spn, u64 S,
-                     u8 *__restrict__ mchar, BlueSub sub, u8 *__restrict__ done) {
+void k_blue_classify(u64 *__restrict__ blue, const u64 *bstart, const u32 *mi_freq, const u64 *mi_j0, u32 Q, u32 lo_excl, const u64 *__restrict__ spn, u64 S,
+                     u8 *__restrict__ mchar, BlueSub sub, u8 *__restrict__ done,
+                     const u32 *depth0 = nullptr, const u32 *__restrict__ Qsnap = nullptr, u32 *consume = nullptr) {
+    // Queue mode (depth0, Qsnap, consume given): the table is the sub-block queue itself -- entries that start depth0 pairs of
+    // windows in; only the *Qsnap entries that were complete before the launch are walked (the kernel appends while it
+    // runs), and a finished entry is taken out of the queue (consume[q] = 0: the wave kernels behind skip it).
     constexpr int NT = 256, EPT = CAP / NT, NS = 256;
     __shared__ u64 se[CAP], sw[CAP], sx[CAP];
     __shared__ u64 pw[NS], px[NS];            // the sample, then its distinct pairs
@@ -1414,6 +1417,7 @@ void k_blue_classify(u64 *__restrict__ blue, const u64 *__restrict__ bstart, con
     __shared__ u32 wtmp[DEBWT_WAVES + 1];
     __shared__ u32 flag, sub_base;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (Qsnap) { const u32 qs = *Qsnap; Q = qs < Q ? qs : Q; }
     const u32 E = (u64)Q >= (u64)gridDim.x * 64 ? 64u : 1u;
     for (u64 q0 = (u64)blockIdx.x * E; q0 < Q; q0 += (u64)gridDim.x * E) {
       const u64 ql = q0 + lane;
@@ -1423,6 +1427,7 @@ void k_blue_classify(u64 *__restrict__ blue, const u64 *__restrict__ bstart, con
         const u32 q = (u32)(q0 + (u32)__builtin_ctzll(todo));
         const u32 m = mi_freq[q];
         const u64 b0 = bstart[q], j0 = mi_j0[q];
+        const u32 d0 = depth0 ? depth0[q] : 0u;
         __syncthreads();                                       // the block before is out of LDS
         if (tid == 0) flag = 0;
         ccnt[tid] = 0; ccnt[tid + NT] = 0; cmsk[tid] = 0; cmsk[tid + NT] = 0;
@@ -1431,16 +1436,16 @@ void k_blue_classify(u64 *__restrict__ blue, const u64 *__restrict__ bstart, con
         for (u32 x = tid; x < m; x += NT) {
             const u64 e = blue[b0 + x];
             se[x] = e; mask |= 1u << (e & 15);
-            const u64 pos = e >> 4;
+            const u64 pos = (e >> 4) + (u64)d0 * (2 * SP_WIN);
             const bool live = pos < S;
             sw[x] = live ? sp_window(spn, pos) : 0ull;
             sx[x] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
         }
         if (mask) atomicOr(&flag, mask);
         __syncthreads();
-        if ((flag & (flag - 1)) == 0) {                        // one BWT symbol in the whole block: any order is the order
+        if ((flag & (flag - 1)) == 0 || (u64)d0 * (2 * SP_WIN) >= S + 2 * SP_WIN) {   // one BWT symbol (or nothing left to compare): any order is the order
             for (u32 x = tid; x < m; x += NT) mchar[j0 + x] = (u8)(se[x] & 15);
-            if (tid == 0) done[q] = 1;
+            if (tid == 0) { if (done) done[q] = 1; if (consume) consume[q] = 0; }
             continue;
         }
         // the sample, sorted by (first window, second window), one row per thread
@@ -1510,11 +1515,11 @@ void k_blue_classify(u64 *__restrict__ blue, const u64 *__restrict__ bstart, con
         ccnt[2 * tid] = cbase; ccnt[2 * tid + 1] = cbase + v0;
         if (u0) {
             const u32 e = sub_base + qbase_;
-            sub.start[e] = b0 + cbase; sub.freq[e] = v0; sub.j0[e] = j0 + cbase; sub.depth[e] = 0u;
+            sub.start[e] = b0 + cbase; sub.j0[e] = j0 + cbase; sub.depth[e] = d0; sub.freq[e] = v0;
         }
         if (u1) {
             const u32 e = sub_base + qbase_ + (u0 ? 1u : 0u);
-            sub.start[e] = b0 + cbase + v0; sub.freq[e] = v1; sub.j0[e] = j0 + cbase + v0; sub.depth[e] = 1u;   // 42 symbols are equal
+            sub.start[e] = b0 + cbase + v0; sub.j0[e] = j0 + cbase + v0; sub.depth[e] = d0 + 1u; sub.freq[e] = v1;   // 42 more symbols are equal
         }
         __syncthreads();
 #pragma unroll
@@ -1526,10 +1531,12 @@ void k_blue_classify(u64 *__restrict__ blue, const u64 *__restrict__ bstart, con
                 blue[b0 + pos] = e;
                 mchar[j0 + pos] = (u8)(e & 15);
             }
-        if (tid == 0) done[q] = 1;
+        if (tid == 0) { if (done) done[q] = 1; if (consume) consume[q] = 0; }
       }
     }
 }
+
+__global__ void k_copy_u32(const u32 *__restrict__ src, u32 *__restrict__ dst) { *dst = *src; }
 
 #define BLUE_LDS_CAP 2048
 #ifndef LS_QUEUE_CAP
