@@ -89,6 +89,41 @@ int main() {
         remove(path);
         CHECK(pack_fasta_file("/nonexistent/x.fa", 2, &p, err, sizeof err) != 0);
     }
+    {   // block gzip (BGZF: members with the 'BC' subfield, inflated in parallel), whole and with a damaged member
+        std::string fa = fasta_of(recs, 70, false, false);
+        const char *path = "/tmp/debwt_sanitize_bgzf.fa.gz";
+        std::string z;
+        const size_t B = 4000;
+        for (size_t a = 0; a <= fa.size(); a += B) {
+            const size_t len = a < fa.size() ? std::min(B, fa.size() - a) : 0;
+            std::vector<unsigned char> body(len + len / 8 + 64);
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            CHECK(deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK);
+            zs.next_in = (Bytef *)fa.data() + a; zs.avail_in = (uInt)len; zs.next_out = body.data(); zs.avail_out = (uInt)body.size();
+            CHECK(deflate(&zs, Z_FINISH) == Z_STREAM_END);
+            const size_t blen = body.size() - zs.avail_out;
+            deflateEnd(&zs);
+            const unsigned bsize = (unsigned)(12 + 6 + blen + 8) - 1;
+            const unsigned char hd[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (unsigned char)(bsize & 255), (unsigned char)(bsize >> 8)};
+            z.append((const char *)hd, 18); z.append((const char *)body.data(), blen);
+            const uLong crc = crc32(crc32(0L, Z_NULL, 0), (const Bytef *)fa.data() + a, (uInt)len);
+            for (int i = 0; i < 4; i++) z.push_back((char)((crc >> (8 * i)) & 255));
+            for (int i = 0; i < 4; i++) z.push_back((char)((len >> (8 * i)) & 255));
+            if (!len) break;
+        }
+        FILE *f = fopen(path, "wb"); CHECK(f && fwrite(z.data(), 1, z.size(), f) == z.size()); fclose(f);
+        for (int threads : {1, 5}) {
+            PackedText p{};
+            CHECK(pack_fasta_file(path, threads, &p, err, sizeof err) == 0);
+            CHECK(p.n == ref.n && !memcmp(p.words, ref.words, ref.nwords * 8));
+            free_packed_text(&p);
+        }
+        z[z.size() / 2] ^= 0x5a;
+        f = fopen(path, "wb"); CHECK(f && fwrite(z.data(), 1, z.size(), f) == z.size()); fclose(f);
+        PackedText p{};
+        CHECK(pack_fasta_file(path, 3, &p, err, sizeof err) != 0);
+        remove(path);
+    }
     {   // IUPAC letters: refused by default, replaced deterministically (independent of threads) with the option
         std::vector<std::string> r2 = recs;
         const char *iupac = "NRYKMSWBDHV";
