@@ -957,7 +957,7 @@ static int classify_local(debwt_ctx *c) {
     {
         u32 *cnt = cp_area(c, 6) + CP_MAXCHUNKS + 8;              // a free word behind the area's scan total
         HIPCHK(c, hipMemsetAsync(cnt, 0, 4, c->stream));
-        if (Q) k_count_blocks<<<grid_for(Q, 256), 256, 0, c->stream>>>(c->mi_freq.as<u32>(), Q, 512u, 1024u, cnt);
+        if (Q) k_count_blocks<<<std::min<u32>(grid_for(Q, 256), 512u), 256, 0, c->stream>>>(c->mi_freq.as<u32>(), Q, 512u, 1024u, cnt);
         HIPCHK(c, hipMemcpyAsync(&c->h_scalars[11], cnt, 4, hipMemcpyDeviceToHost, c->stream));
     }
     if ((rc = sync_check(c))) return rc;

@@ -486,10 +486,15 @@ __global__ void k_append_blocks(const u32 *__restrict__ mi_j0, const u32 *__rest
 }
 // blocks of a range with lo < rows <= hi (sizes the launch plan of the blue sort)
 __global__ void k_count_blocks(const u32 *__restrict__ mi_freq, u64 Q, u32 lo, u32 hi, u32 *__restrict__ counter) {
-    u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = q < Q && mi_freq[q] > lo && mi_freq[q] <= hi;
-    const u64 m = __ballot(in);
-    if (m && (threadIdx.x & 63u) == 0) atomicAdd(counter, (u32)__popcll(m));
+    // grid-stride: one atomic per wave of a few hundred workgroups, not one per 64 blocks (80,000 on one word took 0.9 ms)
+    u32 n = 0;
+    for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += (u64)gridDim.x * blockDim.x) {
+        const u32 f = mi_freq[q];
+        n += (f > lo && f <= hi) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+    if (n && (threadIdx.x & 63u) == 0) atomicAdd(counter, n);
 }
 // large blocks of a range: local block ids -> context-wide ids
 __global__ void k_offset_u32(u32 *__restrict__ v, u64 n, u32 add) {
