@@ -1358,8 +1358,8 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
             for (; w1 < work.size() && (desc.empty() || rows + work[w1].m <= LS_BATCH_ROWS) && wgs < 0x7FFF0000ull; w1++) {
                 const Work &wk = work[w1];
                 u32 nb = 8;
-                while (nb < LS_MAXBINS && (u64)nb * 384 < wk.m) nb <<= 1;
-                u32 ns = std::min<u32>(LS_SAMPLES, std::max<u32>(64u, nb * 8u));
+                while (nb < LS_MAXBINS && (u64)nb * LS_BIN_ROWS < wk.m) nb <<= 1;
+                u32 ns = std::min<u32>(LS_SAMPLES, std::max<u32>(64u, nb * LS_OVERSAMPLE));
                 desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs, wk.depth, wk.pivot});
                 rows += (wk.m + 1u) & ~1u;
                 wgs += (wk.m + 255u) / 256u;

@@ -1556,7 +1556,15 @@ static_assert(LS_QUEUE_CAP <= BLUE_WAVE_CAP, "the queue is drained by the kernel
 // to it: the rows that tie with a splitter form a range of their own -- and is moved there; ranges of <= BLUE_LDS_CAP
 // rows are queued as blocks of their own for the LDS kernels, larger ones go back to the host: split again, one pair
 // of windows deeper when it is a range of ties.
+#ifndef LS_SAMPLES
 #define LS_SAMPLES 4096
+#endif
+#ifndef LS_BIN_ROWS
+#define LS_BIN_ROWS 384                // rows per range the number of ranges of a block aims at
+#endif
+#ifndef LS_OVERSAMPLE
+#define LS_OVERSAMPLE 8u               // samples per range
+#endif
 #define LS_MAXBINS 1024                // splitters + 1
 #define LS_MAXR (2 * LS_MAXBINS)       // ranges: below splitter 0, equal to it, between 0 and 1, equal to 1, ...
 struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0, depth, pivot; };  // row0: first scratch row; wg0: first 256-row
