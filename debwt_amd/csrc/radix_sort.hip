@@ -722,6 +722,23 @@ __device__ __forceinline__ void rl_cex(u64 &a, u64 &b, bool up) {      // (a,b) 
     a = lo; b = hi;
 }
 
+// the 16 keys of a lane ascending: a 60-comparator network in 10 layers (the best known for 16 inputs; checked on all
+// 2^16 zero-one inputs) instead of the bitonic sorter's 80
+__device__ __forceinline__ void rl_sort16(u64 (&k)[16]) {
+#define RL_CE(a, b) rl_cex(k[a], k[b], true)
+    RL_CE(0, 13); RL_CE(1, 12); RL_CE(2, 15); RL_CE(3, 14); RL_CE(4, 8); RL_CE(5, 6); RL_CE(7, 11); RL_CE(9, 10);
+    RL_CE(0, 5); RL_CE(1, 7); RL_CE(2, 9); RL_CE(3, 4); RL_CE(6, 13); RL_CE(8, 14); RL_CE(10, 15); RL_CE(11, 12);
+    RL_CE(0, 1); RL_CE(2, 3); RL_CE(4, 5); RL_CE(6, 8); RL_CE(7, 9); RL_CE(10, 11); RL_CE(12, 13); RL_CE(14, 15);
+    RL_CE(0, 2); RL_CE(1, 3); RL_CE(4, 10); RL_CE(5, 11); RL_CE(6, 7); RL_CE(8, 9); RL_CE(12, 14); RL_CE(13, 15);
+    RL_CE(1, 2); RL_CE(3, 12); RL_CE(4, 6); RL_CE(5, 7); RL_CE(8, 10); RL_CE(9, 11); RL_CE(13, 14);
+    RL_CE(1, 4); RL_CE(2, 6); RL_CE(5, 8); RL_CE(7, 10); RL_CE(9, 13); RL_CE(11, 14);
+    RL_CE(2, 4); RL_CE(3, 6); RL_CE(9, 12); RL_CE(11, 13);
+    RL_CE(3, 5); RL_CE(6, 8); RL_CE(7, 9); RL_CE(10, 12);
+    RL_CE(3, 4); RL_CE(5, 6); RL_CE(7, 8); RL_CE(9, 10); RL_CE(11, 12);
+    RL_CE(6, 7); RL_CE(8, 9);
+#undef RL_CE
+}
+
 // bitonic network over 2^LG keys held 16 per thread in registers (blocked layout: steps at distance < 16 never leave
 // the thread, distances < 1024 are lane shuffles, larger ones go through LDS).  Threads with !active (whole waves)
 // hold padding only and just keep the barriers.
@@ -853,16 +870,7 @@ __global__ __launch_bounds__(NT) void rs_local_kernel(u64 *__restrict__ keys, u6
     // sorted after RL_MAX_ROUNDS rounds goes through the full bitonic network below.
     bool sorted = false;
     if (NT == 64) {
-#pragma unroll
-        for (int lk = 1; lk <= 4; lk++) {
-#pragma unroll
-            for (int lj = lk - 1; lj >= 0; lj--) {
-                const int jj = 1 << lj;
-#pragma unroll
-                for (int r = 0; r < KPT; r++)
-                    if ((r & jj) == 0) rl_cex(k[r], k[r | jj], (r & (1 << lk)) == 0);
-            }
-        }
+        rl_sort16(k);
         for (int round = 0; round < RL_MAX_ROUNDS; round++) {
             u64 nxt = __shfl_down(k[0], 1, 64);
             bool ok = tid == 63 || k[KPT - 1] <= nxt;
@@ -935,16 +943,7 @@ __device__ __forceinline__ void rlw_sort(u64 (&k)[16], const u32 lane) {
         sorted = __ballot(bad != 0) == 0ull;
     }
     if (!sorted) {
-#pragma unroll
-        for (int lk = 1; lk <= 4; lk++) {
-#pragma unroll
-            for (int lj = lk - 1; lj >= 0; lj--) {
-                const int jj = 1 << lj;
-#pragma unroll
-                for (int r = 0; r < KPT; r++)
-                    if ((r & jj) == 0) rl_cex(k[r], k[r | jj], (r & (1 << lk)) == 0);
-            }
-        }
+        rl_sort16(k);
         for (int round = 0; round < RL_MAX_ROUNDS; round++) {
             const u64 nxt = __shfl_down(k[0], 1, 64);
             const bool ok = lane == 63 || k[KPT - 1] <= nxt;
