@@ -288,6 +288,9 @@ __global__ __launch_bounds__(RS_RADIX) void rs_scan_tot_kernel(u32 *__restrict__
 #ifndef RS_HALFWAVE
 #define RS_HALFWAVE 1
 #endif
+#ifndef RS_RANK_SWIZZLE
+#define RS_RANK_SWIZZLE 1
+#endif
 #define RS_SUB (RS_HALFWAVE ? 32u : 64u)
 #define SC_UNITS (SC_NT / RS_SUB)
 // offset of item (unit of this thread, round 0) inside a tile
@@ -366,6 +369,22 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
         if (!FULL && (u32)r >= nrounds) { pk[r] = 0; continue; }       // (workgroup-uniform) no keys in this round
         const bool valid = FULL || ((vmask >> r) & 1u);
         const u32 d = rs_digit<FIXED0>(dg, key[r]);
+#if RS_RANK_SWIZZLE
+        // the mask half of a digit's word is its low half when bit 4 of the digit is clear, its high half when set: the
+        // 32-bit ORs of a round then spread over all 32 banks (bank = 2 (d mod 16) + bit 4) instead of the 16 even ones
+        const u32 hs = (d >> 4) & 1u;
+        if (valid) __hip_atomic_fetch_or(reinterpret_cast<u32 *>(&wword[d]) + hs, lbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();
+        const u64 cm = valid ? __hip_atomic_load(&wword[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+        const u32 m = hs ? (u32)(cm >> 32) : (u32)cm, base = hs ? (u32)cm : (u32)(cm >> 32);
+        const u32 before = (u32)__popc(m & (lbit - 1u));
+        pk[r] = (base + before) | (d << 16);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) {
+            const u32 nc = base + (u32)__popc(m);
+            __hip_atomic_store(&wword[d], hs ? (u64)nc : (u64)nc << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#else
         if (valid) __hip_atomic_fetch_or(reinterpret_cast<u32 *>(&wword[d]), lbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_wave_barrier();
         const u64 cm = valid ? __hip_atomic_load(&wword[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
@@ -375,6 +394,7 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
         __builtin_amdgcn_wave_barrier();
         if (valid && before == 0)
             __hip_atomic_store(&wword[d], (u64)(base + (u32)__popc(m)) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         __builtin_amdgcn_sched_barrier(0);    // keep a round's arithmetic inside the round (register pressure)
     }
 #else
@@ -405,7 +425,8 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
     if (tid < RS_RADIX) {
 #pragma unroll
         for (u32 i = 0; i < SC_UNITS; i++) {
-            c[i] = RS_HALFWAVE ? reinterpret_cast<const u32 *>(&sh.skeys[i * RS_RADIX + tid])[1] : (u32)sh.wavecnt[i][tid];
+            c[i] = RS_HALFWAVE ? reinterpret_cast<const u32 *>(&sh.skeys[i * RS_RADIX + tid])[RS_RANK_SWIZZLE ? 1u - ((tid >> 4) & 1u) : 1u]
+                               : (u32)sh.wavecnt[i][tid];
             len += c[i];
         }
     }
