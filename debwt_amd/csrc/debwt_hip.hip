@@ -1188,6 +1188,7 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
     // the whole text on this context (also every shard of a "replicated scan" sharded build), slice by slice
     if ((rc = sp_prepare(c))) return rc;
     const u64 ngroups = (c->n + 31) >> 5;
+    const u64 slice_groups = (c->cfg.reserved & 4194304) ? 4096ull : SP_SLICE_GROUPS;   // bit 22: slices of 2^17 positions (tests)
     u64 S = 0, Bseen = 0;
     // Blue fill without atomics when a routed entry (block id | SP index | pred) fits 64 bits: the entries of all
     // slices are collected in `blue`, sorted by block id, stripped.  Otherwise (or cfg.reserved bit 5: tests) one
@@ -1218,8 +1219,8 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
         HIPCHK(c, hipStreamSynchronize(c->stream));              // qb is host memory
     }
     c->route_direct = false;
-    for (u64 g0 = 0; g0 < ngroups; g0 += SP_SLICE_GROUPS) {
-        const u64 g1 = std::min(ngroups, g0 + SP_SLICE_GROUPS);
+    for (u64 g0 = 0; g0 < ngroups; g0 += slice_groups) {
+        const u64 g1 = std::min(ngroups, g0 + slice_groups);
         // route_sort: pass 1 keeps the block ids of the slice's multi-in positions, pass 2 writes the routed entries
         if ((route_sort || route_ranges) && (rc = sp_block_ids_begin(c, g0, g1 - g0))) return rc;
         if ((rc = sp_flags(c, g0, g1))) return rc;

@@ -761,6 +761,26 @@ def test_blue_entries_routed_by_key_range(api, entry):
     assert len(blues[0]) == len(blues[1]) and np.array_equal(np.sort(blues[0]), np.sort(blues[1]))
 
 
+@pytest.mark.parametrize("entry", [e for e in MANIFEST if e["k"] == 32 and e["n"] > 300_000], ids=golden_id)
+def test_sp_stage_in_slices(api, entry):
+    """The SP stage slice by slice (what a text above 2^31 positions takes; tune bit 22 cuts slices of 2^17 positions so that
+    the goldens have several): the reference's bytes, and SP symbols and blue table equal to the unsliced build's."""
+    recs = golden_records(entry)
+    sha = entry["sha256"]
+    sp, blue = [], []
+    for tune in (4194304, 0):
+        d = api.DeBWT(k=32, tune=tune)
+        d.load_records(recs)
+        d.kmer_sort_rle(); d.classify(); d.sp_generate()
+        sp.append(d.fetch_array(api.ARR_SP_SYMBOLS).copy()); blue.append(d.fetch_array(api.ARR_BLUE).copy())
+        d.blue_sort(); d.bwt_assemble()
+        words, hrows, drow = d.fetch()
+        assert _sha(words) == sha["bwt"] and _sha(hrows) == sha["hash"], tune
+        d.close()
+    assert np.array_equal(sp[0], sp[1])
+    assert len(blue[0]) == len(blue[1]) and np.array_equal(np.sort(blue[0]), np.sort(blue[1]))
+
+
 @pytest.mark.parametrize("cap", [1 << 20, 3_000_000, 1 << 23])
 def test_multi_range_equals_single_range_midsize(api, cap):
     from debwt_amd import synth
