@@ -291,6 +291,9 @@ __global__ __launch_bounds__(RS_RADIX) void rs_scan_tot_kernel(u32 *__restrict__
 #ifndef RS_RANK_SWIZZLE
 #define RS_RANK_SWIZZLE 1
 #endif
+#ifndef RS_RANK_UNIFORM
+#define RS_RANK_UNIFORM 1
+#endif
 #define RS_SUB (RS_HALFWAVE ? 32u : 64u)
 #define SC_UNITS (SC_NT / RS_SUB)
 // offset of item (unit of this thread, round 0) inside a tile
@@ -373,6 +376,26 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
         // the mask half of a digit's word is its low half when bit 4 of the digit is clear, its high half when set: the
         // 32-bit ORs of a round then spread over all 32 banks (bank = 2 (d mod 16) + bit 4) instead of the 16 even ones
         const u32 hs = (d >> 4) & 1u;
+#if RS_RANK_UNIFORM
+        // Both units of the wave hold one digit each in this round (keys of a low-complexity stretch: the passes over the
+        // oversize buckets of a real genome): 32 ORs into one word would be executed one after the other.  The peer mask
+        // is then the mask of the unit's valid lanes -- no OR, one read, one store.
+        const u32 du = (u32)(lane < 32u ? __builtin_amdgcn_readlane((int)d, 0) : __builtin_amdgcn_readlane((int)d, 32));
+        const u64 vm = FULL ? ~0ull : __ballot(valid);
+        if (vm == ~0ull && __ballot(d != du) == 0ull) {
+            const u64 cm = __hip_atomic_load(&wword[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u32 base = hs ? (u32)cm : (u32)(cm >> 32);
+            const u32 before = tid & 31u;
+            pk[r] = (base + before) | (d << 16);
+            __builtin_amdgcn_wave_barrier();
+            if (before == 0) {
+                const u32 nc = base + 32u;
+                __hip_atomic_store(&wword[d], hs ? (u64)nc : (u64)nc << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+        }
+#endif
         if (valid) __hip_atomic_fetch_or(reinterpret_cast<u32 *>(&wword[d]) + hs, lbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_wave_barrier();
         const u64 cm = valid ? __hip_atomic_load(&wword[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
