@@ -380,9 +380,10 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
         // Both units of the wave hold one digit each in this round (keys of a low-complexity stretch: the passes over the
         // oversize buckets of a real genome): 32 ORs into one word would be executed one after the other.  The peer mask
         // is then the mask of the unit's valid lanes -- no OR, one read, one store.
-        const u32 du = (u32)(lane < 32u ? __builtin_amdgcn_readlane((int)d, 0) : __builtin_amdgcn_readlane((int)d, 32));
-        const u64 vm = FULL ? ~0ull : __ballot(valid);
-        if (vm == ~0ull && __ballot(d != du) == 0ull) {
+        // (whole tiles only: the first pass of a key range, which ranks what it collected, is bound by its instructions and
+        // loses 1.3 ms per range to the test)
+        const u32 du = FULL ? (u32)(lane < 32u ? __builtin_amdgcn_readlane((int)d, 0) : __builtin_amdgcn_readlane((int)d, 32)) : 0u;
+        if (FULL && __ballot(d != du) == 0ull) {
             const u64 cm = __hip_atomic_load(&wword[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const u32 base = hs ? (u32)cm : (u32)(cm >> 32);
             const u32 before = tid & 31u;
