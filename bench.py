@@ -61,6 +61,8 @@ WORKLOAD_NOTE = {
     "ecoli_4.6M": "BASELINE configs[0]: E. coli-sized single record",
     "uniform_3.1G": "distribution U: uniform 3.1 Gbp in 24 records",
     "real_3.1G": "distribution R: 3.1 Gbp in 24 records with an Alu-like family, satellite arrays, homopolymer tracts",
+    "pan10x600M": "distribution P, 10 genomes x 600 Mbp in 240 records: the largest size whose 8 shards fit next to each other on one GPU",
+    "real10x600M": "distribution R, 10 genomes x 600 Mbp in 240 records (Alu-like family, satellites, homopolymer tracts at the 3 Gbp densities)",
     "real10x3G": "distribution R at the headline size: 10 genomes x 3.0 Gbp in 240 records, each with an Alu-like family "
                  "(10^6 copies), satellite arrays and homopolymer tracts, SNP 1e-3 between the genomes",
 }
@@ -145,6 +147,8 @@ def run_c_host(args):
     if args.exchange == "rccl":
         m.set_exchange("rccl")
     m.set_key_mode({"auto": "auto", "exchange": "exchange", "rescan": "rescan"}.get(args.mode, "auto"))
+    if args.serial_shards:
+        m.set_serial(True)                                 # the shards take turns on the GPU: per-shard times that are each shard's own
     t0 = time.perf_counter()
     m.load_packed(text.a, n, sep)
     t_load = time.perf_counter() - t0
@@ -197,27 +201,74 @@ def run_c_host(args):
         "first_build_s": round(first_build_s, 3), "setup_s": {"generate_text": round(t_gen, 2), "load_to_hbm": round(t_load, 3)},
         "check": check, "cpu_baseline": None,
     }
+    if args.serial_shards:
+        line["shards"] = [m.shard_report(r) for r in range(args.gpus)]
+        line["serial_shards"] = ("the shards took turns between the barriers, one on the GPU at a time (debwt_multi_set_serial): "
+                                 "`value` is then the SUM of the shards' times, not a parallel build")
     emit_line(line)
     m.close()
     text.free()
     return 0
 
 
-def launch_ranks(n_ranks, with_c_host=False, timeout=420.0):
-    """`python bench.py --gpus N` run directly (no launcher, WORLD_SIZE unset): start the N ranks as CHILD processes
-    of this one -- `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` -- before anything here
-    has touched the GPU (no torch import yet, and never an exec of a process that has), hand rank 0's one JSON line
-    through to stdout (everything else the ranks print goes to stderr) and return the launcher's exit code."""
-    import socket
+def _strip_flags(argv, flags):
+    """argv without the given value-carrying flags, in both forms (`--flag value`, `--flag=value`)."""
+    out, skip = [], False
+    for a_ in argv:
+        if skip:
+            skip = False
+            continue
+        if a_ in flags:
+            skip = True
+            continue
+        if any(a_.startswith(f + "=") for f in flags):
+            continue
+        out.append(a_)
+    return out
+
+
+_CHILD = {"p": None}                 # the child launch that is running now (launch_ranks' signal handler ends exactly it)
+
+
+def _end_tree(p, grace=15.0):
+    """End the child `p` and every process it started (exact PIDs: the children stay in this process group, so whoever
+    ends bench.py by group ends them too): SIGTERM to the launcher -- torch.distributed.run hands it on to its workers --
+    then SIGKILL to whatever is left after `grace` seconds."""
+    import psutil
+    try:
+        tree = [psutil.Process(p.pid)] + psutil.Process(p.pid).children(recursive=True)
+    except psutil.Error:
+        tree = []
+    try:
+        p.terminate()
+    except OSError:
+        pass
+    _, alive = psutil.wait_procs(tree, timeout=grace)
+    for q in alive:
+        try:
+            q.kill()
+        except psutil.Error:
+            pass
+
+
+def _run_child(cmd, env, timeout=None, on_object=None):
+    """Run one child command, relaying its stdout: JSON objects that start with {"metric" are parsed (the last one is
+    returned), everything else goes to stderr.  Returns (exit code or None on timeout, object or None)."""
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    import threading
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    held = None                                              # rank 0's line, kept back until the C host has had its turn
+    _CHILD["p"] = p
+    timed_out = {"v": False}
+
+    def _expire():
+        timed_out["v"] = True
+        _end_tree(p)
+
+    timer = threading.Timer(timeout, _expire) if timeout else None
+    if timer:
+        timer.daemon = True
+        timer.start()
+    got = None
     for ln in p.stdout:
         # the ranks share one pipe: another rank's output (gloo prints its connection messages to stdout in pieces) may
         # stand in front of rank 0's object or between it and its newline: take the object from where it starts to where it ends
@@ -230,50 +281,125 @@ def launch_ranks(n_ranks, with_c_host=False, timeout=420.0):
                 obj = None
         if obj is not None:
             rest = ln[:at] + ln[at + end:]
-            if with_c_host and held is None:
-                held = obj
-            else:
-                sys.stdout.write(ln[at:at + end] + "\n")
-                sys.stdout.flush()
+            got = obj
+            if on_object:
+                on_object(obj)
             if rest.strip():
                 sys.stderr.write(rest if rest.endswith("\n") else rest + "\n")
         else:
             sys.stderr.write(ln)
         sys.stderr.flush()
     rc = p.wait()
-    if held is not None:
-        # The ranks have exited and released their GPUs: the same collection through the C host (one process, one thread per
-        # GPU: what cli/deBWT --gpus runs), as a CHILD of this process, which has not touched a GPU.  Extra information: a
-        # failure or a timeout of it is recorded in the line and costs the run nothing.
-        if rc == 0:
-            argv = [a for a in sys.argv[1:]]
-            for flag in ("--host",):
-                if flag in argv:
-                    i = argv.index(flag); del argv[i:i + 2]
-            steps = max(1, min(3, held.get("steps", 1)))
-            for flag, val in (("--steps", str(steps)), ("--warmup", "1")):
-                if flag in argv:
-                    i = argv.index(flag); argv[i + 1] = val
-                else:
-                    argv += [flag, val]
-            child = [sys.executable, os.path.abspath(__file__), "--host", "c"] + argv
+    if timer:
+        timer.cancel()
+    _CHILD["p"] = None
+    return (None if timed_out["v"] else rc), got
+
+
+def _start_ranks(n_ranks, argv, env, timeout=None):
+    """One `python -m torch.distributed.run --nproc-per-node N bench.py <argv>` child: (exit code or None on timeout, rank
+    0's object or None)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return _run_child(cmd, env, timeout=timeout)
+
+
+def launch_ranks(n_ranks, args):
+    """`python bench.py --gpus N` run directly (no launcher, WORLD_SIZE unset): start the N ranks as CHILD processes
+    of this one -- `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` -- before anything here
+    has touched the GPU (no torch import yet, and never an exec of a process that has), hand rank 0's one JSON line
+    through to stdout (everything else the ranks print goes to stderr) and return THAT launch's exit code.
+
+    Extras (extra information, each a FRESH child launch after the ranks of the measurement have exited and released their
+    GPUs; their failures and timeouts are recorded as text in the line and never touch the exit code):
+      key_modes_ms -- --mode auto: the key path the cost model did NOT choose, `bench.py --gpus N --mode <other>` over <= 3 steps;
+      host_c       -- the same collection through the C host (one process, one thread per GPU: what cli/deBWT --gpus runs).
+    The measured line is held back while the extras run (at most --extras-timeout seconds in total); it is written to stderr
+    at once, and a SIGTERM/SIGINT to this process prints it to stdout before leaving."""
+    import signal
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    nested = os.environ.get("DEBWT_BENCH_NESTED") == "1"      # this IS an extra of another bench.py: no extras of its own
+    own = _strip_flags(sys.argv[1:], ("--host",))
+    rc, held = _start_ranks(n_ranks, own + ["--host", "python"], env)
+    if held is None:
+        return rc if rc else 1
+    want_other = (not nested and rc == 0 and args.mode == "auto" and not args.no_other_mode and held.get("exchange") is not None)
+    want_c = not nested and rc == 0 and args.host in (None, "both")
+    if not (want_other or want_c):
+        emit_line(held)
+        return rc
+
+    sys.stderr.write("bench.py: measured line (held back for the extras): " + json.dumps(held) + "\n")
+    sys.stderr.flush()
+    state = {"out": False}
+
+    def flush_held(*_sig):
+        if not state["out"]:
+            state["out"] = True
+            emit_line(held)
+        if _sig:                                              # asked to leave: the line is out; end the extra that is running
+            if _CHILD["p"] is not None:
+                _end_tree(_CHILD["p"], grace=5.0)
+            os._exit(rc)
+
+    old = {sg: signal.signal(sg, flush_held) for sg in (signal.SIGTERM, signal.SIGINT)}
+    deadline = time.perf_counter() + args.extras_timeout
+    env2 = dict(env, DEBWT_BENCH_NESTED="1")
+    base = _strip_flags(own, ("--steps", "--warmup", "--mode", "--extras-timeout", "--cpu-sample", "--port-sample"))
+    no_check = ["--no-check"] if "--no-check" in base else []
+    base = [a_ for a_ in base if a_ not in ("--no-check", "--no-cpu-baseline", "--no-other-mode")]
+    steps = str(max(1, min(3, held.get("steps", 1))))
+    try:
+        if want_other:
+            chosen = held["exchange"].get("keys", "rescan")
+            other = "exchange" if chosen == "rescan" else "rescan"
+            key_modes = {chosen: held["ms_per_step"]}
+            left = deadline - time.perf_counter()
             try:
-                r = subprocess.run(child, env=env, capture_output=True, text=True, timeout=timeout)
-                sys.stderr.write(r.stderr[-4000:])
-                lines = [x for x in r.stdout.splitlines() if x.startswith('{"metric"')]
-                if r.returncode == 0 and lines:
-                    j = json.loads(lines[-1])
+                if left <= 0:
+                    raise TimeoutError
+                rc2, j = _start_ranks(n_ranks, base + ["--host", "python", "--mode", other, "--steps", steps, "--warmup", "1",
+                                                      "--no-check", "--no-cpu-baseline"], env2, timeout=left)
+                if rc2 is None:
+                    raise TimeoutError
+                if rc2 == 0 and j is not None:
+                    key_modes[other] = j["ms_per_step"]
+                    key_modes["note"] = (f"ms per build; '{chosen}' is the cost model's choice and the timed steps of `value`, '{other}' "
+                                         f"was timed over {steps} steps after one warm-up by a fresh launch of the ranks afterwards")
+                else:
+                    key_modes[other] = f"dropped: the extra launch ended with exit code {rc2}"
+            except TimeoutError:
+                key_modes[other] = f"dropped: not back within the {args.extras_timeout} s the extras may take"
+            except Exception as e:                            # noqa: BLE001
+                key_modes[other] = f"dropped: {type(e).__name__}: {e}"
+            held["key_modes_ms"] = key_modes
+        if want_c:
+            left = deadline - time.perf_counter()
+            child = [sys.executable, os.path.abspath(__file__)] + base + ["--host", "c", "--steps", steps, "--warmup", "1", "--no-cpu-baseline"] + no_check
+            try:
+                if left <= 0:
+                    raise TimeoutError
+                rc3, j = _run_child(child, env2, timeout=left)
+                if rc3 is None:
+                    raise TimeoutError
+                if rc3 == 0 and j is not None:
                     held["host_c"] = {k_: j[k_] for k_ in ("value", "unit", "ms_per_step", "steps", "warmup", "host", "exchange",
                                                           "first_build_s", "check", "config") if k_ in j}
                 else:
-                    held["host_c"] = {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
-            except subprocess.TimeoutExpired:
-                held["host_c"] = {"error": f"not back within {timeout} s"}
+                    held["host_c"] = {"error": f"exit code {rc3}"}
+            except TimeoutError:
+                held["host_c"] = {"error": f"not back within the {args.extras_timeout} s the extras may take"}
             except Exception as e:                            # noqa: BLE001
                 held["host_c"] = {"error": f"{type(e).__name__}: {e}"}
             held["host"] = "python (one process per GPU, torch.distributed); host_c: the C host on the same collection"
-        sys.stdout.write(json.dumps(held) + "\n")
-        sys.stdout.flush()
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+        flush_held()
     return rc
 
 
@@ -294,15 +420,18 @@ def main():
                          "process, one host thread per GPU inside the library (debwt_multi_build, what cli/deBWT --gpus runs), "
                          "exchanges by --exchange; both (default for N > 1 when bench.py starts its own ranks): the python ranks "
                          "give `value`, then the C host runs as a child process and its line becomes the key `host_c`")
+    ap.add_argument("--serial-shards", action="store_true",
+                    help="--host c: the shards take turns, one on the GPU at a time, and the line carries every shard's step times "
+                         "(`shards`): load balance of N = 2, 4, 8 measured on a box with one GPU")
     ap.add_argument("--exchange", choices=["peer", "rccl"], default="peer",
                     help="--host c: device-to-device copies (default) or grouped ncclSend/ncclRecv (needs one GPU per shard)")
-    ap.add_argument("--host-c-timeout", type=float, default=420.0, help=argparse.SUPPRESS)
+    ap.add_argument("--extras-timeout", type=float, default=420.0,
+                    help="N > 1 started by bench.py itself: seconds the extras (other key path, C host) may take in total")
     ap.add_argument("--no-reserve", action="store_true", help="no debwt_reserve beside the text generation (A/B of the cold path)")
     ap.add_argument("--h2h-plain", action="store_true", help="host-to-host steps with build + fetch one after the other (A/B)")
     ap.add_argument("--cpu-configs", action="store_true", help=argparse.SUPPRESS)          # (the default now)
     ap.add_argument("--no-cpu-configs", action="store_true",
                     help="do not time the reference on the whole chr1_250M collection (BASELINE configs[1]; a minute of CPU)")
-    ap.add_argument("--other-mode-timeout", type=float, default=180.0, help=argparse.SUPPRESS)
     ap.add_argument("--no-other-mode", action="store_true",
                     help="N>1 with --mode auto: do not also time the key path the cost model did not choose")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bases of record 0 given to the reference")
@@ -320,10 +449,18 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if os.environ.get("DEBWT_BENCH_NESTED") == "1" and ("WORLD_SIZE" in os.environ or args.host == "c"):
+        # test hooks, seen by the extras only (an extra = a child launch that carries DEBWT_BENCH_NESTED): fail, or be slow
+        if os.environ.get("DEBWT_BENCH_FAIL_EXTRA"):
+            raise RuntimeError("injected failure of an extra launch (tests)")
+        time.sleep(float(os.environ.get("DEBWT_BENCH_EXTRA_SLEEP", "0")))
+    if args.host == "c" and args.launch_probe:              # the CPU suite's stand-in for the C host's line (no GPU touched)
+        emit_line({"metric": METRIC, "probe": True, "host": "c", "n_gpus": args.gpus, "value": 0.0, "ms_per_step": 0.0, "steps": args.steps})
+        return
     if args.host == "c":
         sys.exit(run_c_host(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus, with_c_host=args.host in (None, "both"), timeout=args.host_c_timeout))
+        sys.exit(launch_ranks(args.gpus, args))
 
     from debwt_amd import dist as D
     rank, local_rank, world = D.env_world()
@@ -331,7 +468,8 @@ def main():
         D.init(backend="gloo")
         total = D.sum_over_ranks(1)
         if rank == 0:
-            emit_line({"metric": METRIC, "probe": True, "n_gpus": args.gpus, "ranks_joined": int(total)})
+            emit_line({"metric": METRIC, "probe": True, "n_gpus": args.gpus, "ranks_joined": int(total), "steps": args.steps,
+                       "ms_per_step": 0.0, "mode": args.mode, "exchange": {"keys": "rescan"}})
         else:
             print(f"rank {rank} joined", flush=True)
         D.finalize()
@@ -594,57 +732,6 @@ def main():
         else:
             line["cpu_baseline"] = None
 
-    # N > 1, --mode auto: the key path the cost model did NOT choose, timed the same way over a few steps, so that a
-    # scaling run answers "exchange or rescan" by measurement (collective: every rank runs it).  It is extra information
-    # and must not be able to cost the run its result: rank 0 holds the finished line, and a watchdog on every rank ends
-    # the process with exit code 0 -- rank 0 printing the line first -- when the extra builds have not come back in time
-    # (a collective that hangs, a rank that failed alone and left the others waiting).
-    if sharded and world > 1 and args.mode == "auto" and not args.no_other_mode:
-        import threading
-        chosen = acc["info"].get("keys", "rescan")
-        other = "exchange" if chosen == "rescan" else "rescan"
-        key_modes = {chosen: round(dt * 1e3 / args.steps, 3)}
-        state = {"why": f"not back within {args.other_mode_timeout} s", "failed": False}
-
-        def bail():
-            # a true timeout ends the run with the finished line and exit code 0; a rank that RAISED ends with exit code 1
-            # (its own watchdog, or at once when it is rank 0): CI must be able to tell a failed key path from a slow one
-            if rank == 0:
-                key_modes[other] = f"dropped: {state['why']}"
-                line["key_modes_ms"] = key_modes
-                emit_line(line)
-            os._exit(1 if state["failed"] else 0)
-
-        timer = threading.Timer(args.other_mode_timeout, bail)
-        timer.daemon = True
-        t_extra = time.perf_counter()
-        timer.start()
-        try:
-            if os.environ.get("DEBWT_BENCH_FAIL_OTHER_MODE", "") == str(rank):   # tests: this rank's extra build raises
-                raise RuntimeError("injected failure of the extra key-path build")
-            ws2 = SH.Workspace(d, device, mode=other)
-            ws2.buf = shard_ws.buf                            # the same exchange buffers
-            k2 = max(1, min(3, args.steps))
-            dt2 = D.timed_steps(lambda: SH.build_sharded(d, ws2), steps=k2, warmup=1, device_sync=torch.cuda.synchronize,
-                                tensor_device=tdev)
-            key_modes[other] = round(dt2 * 1e3 / k2, 3)
-            key_modes["note"] = (f"ms per build; '{chosen}' is the cost model's choice and the timed steps of `value`, "
-                                 f"'{other}' was timed over {k2} steps after one warm-up")
-            timer.cancel()
-        except Exception as e:                                # noqa: BLE001
-            if time.perf_counter() - t_extra >= args.other_mode_timeout:
-                # past the deadline: the other ranks' watchdogs have ended them and this is the collective noticing -- a timeout
-                threading.Event().wait()
-            state["why"] = f"rank {rank} failed: {type(e).__name__}: {e}"
-            state["failed"] = True
-            sys.stderr.write(f"bench.py: extra build of the '{other}' key path failed on rank {rank}: {e}\n")
-            if rank == 0:
-                timer.cancel()
-                bail()                                        # the line (with the exception text) now, exit code 1
-            threading.Event().wait()                          # the other ranks wait in a collective: the watchdogs end the run,
-                                                              # this rank's with exit code 1
-        if rank == 0:
-            line["key_modes_ms"] = key_modes
     if rank == 0:
         emit_line(line)
     d.close()

@@ -45,6 +45,15 @@ class DebwtVerifyReport(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+MULTI_STEPS = 24
+
+
+class DebwtShardReport(ctypes.Structure):
+    _fields_ = [("ms", ctypes.c_float * MULTI_STEPS), ("bytes_in", ctypes.c_uint64 * 5), ("bytes_out", ctypes.c_uint64 * 5),
+                ("keys", ctypes.c_uint64), ("key_ranges", ctypes.c_uint64), ("blocks", ctypes.c_uint64),
+                ("blue_rows", ctypes.c_uint64), ("rows", ctypes.c_uint64), ("bin_lo", ctypes.c_uint32), ("bin_hi", ctypes.c_uint32)]
+
+
 class DebwtMultiStats(ctypes.Structure):
     _fields_ = [("n", ctypes.c_uint64), ("nrec", ctypes.c_uint64), ("ngpus", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
                 ("key_bytes_in", ctypes.c_uint64), ("blue_bytes_in", ctypes.c_uint64), ("ms_build", ctypes.c_float),
@@ -68,6 +77,7 @@ SYMBOLS = [
     "debwt_multi_load_text", "debwt_multi_load_fasta", "debwt_multi_build", "debwt_multi_fetch_bwt", "debwt_multi_get_stats",
     "debwt_multi_verify", "debwt_multi_shard", "debwt_pinned_alloc", "debwt_pinned_free", "debwt_shard_key_mode",
     "debwt_multi_set_key_mode", "debwt_special_compare", "debwt_build_to_host", "debwt_multi_set_exchange", "debwt_reserve",
+    "debwt_multi_set_serial", "debwt_multi_get_shard_report", "debwt_multi_step_name",
 ]
 
 
@@ -217,6 +227,12 @@ def lib():
     L.debwt_multi_get_stats.argtypes = [vp, ctypes.POINTER(DebwtMultiStats), ctypes.POINTER(DebwtStats)]
     L.debwt_multi_shard.restype = vp
     L.debwt_multi_shard.argtypes = [vp, ctypes.c_int]
+    L.debwt_multi_set_serial.restype = ctypes.c_int
+    L.debwt_multi_set_serial.argtypes = [vp, ctypes.c_int]
+    L.debwt_multi_get_shard_report.restype = ctypes.c_int
+    L.debwt_multi_get_shard_report.argtypes = [vp, ctypes.c_int, ctypes.POINTER(DebwtShardReport)]
+    L.debwt_multi_step_name.restype = ctypes.c_char_p
+    L.debwt_multi_step_name.argtypes = [ctypes.c_int]
     L.debwt_multi_verify.restype = ctypes.c_int
     L.debwt_multi_verify.argtypes = [vp, ctypes.POINTER(DebwtVerifyReport)]
     L.debwt_verify_device.restype = ctypes.c_int

@@ -285,6 +285,27 @@ class MultiDeBWT:
         self._chk(self._L.debwt_multi_get_stats(self._h, ctypes.byref(ms), ctypes.byref(s0)))
         return ms.as_dict(), s0.as_dict()
 
+    def set_serial(self, on=True):
+        """The shards of a build take turns between the barriers, one on its GPU at a time (debwt_multi_set_serial): how the
+        per-shard times of N = 2, 4, 8 are measured on a box with one GPU."""
+        self._chk(self._L.debwt_multi_set_serial(self._h, 1 if on else 0))
+
+    def shard_report(self, shard):
+        """What shard `shard` did in the last build: wall ms per step (by name), bytes in/out per exchange, its sizes, and the
+        device-side stage times and counters of its context."""
+        rep = _lib.DebwtShardReport()
+        self._chk(self._L.debwt_multi_get_shard_report(self._h, int(shard), ctypes.byref(rep)))
+        names = [self._L.debwt_multi_step_name(i).decode() for i in range(_lib.MULTI_STEPS)]
+        xn = ("keys", "facts", "sp", "blue", "rows")
+        st = _lib.DebwtStats()
+        self._L.debwt_get_stats(self._shard_ctx(shard), ctypes.byref(st))
+        return {"shard": int(shard), "bins": [int(rep.bin_lo), int(rep.bin_hi)], "keys": int(rep.keys),
+                "key_ranges": int(rep.key_ranges), "blocks": int(rep.blocks), "blue_rows": int(rep.blue_rows), "rows": int(rep.rows),
+                "ms": {nm: round(float(rep.ms[i]), 3) for i, nm in enumerate(names) if rep.ms[i] > 0},
+                "bytes_in": {x: int(rep.bytes_in[i]) for i, x in enumerate(xn)},
+                "bytes_out": {x: int(rep.bytes_out[i]) for i, x in enumerate(xn)},
+                "ctx": st.as_dict()}
+
     def verify_device(self):
         rep = _lib.DebwtVerifyReport()
         self._chk(self._L.debwt_multi_verify(self._h, ctypes.byref(rep)))

@@ -214,6 +214,18 @@ int sync_check(debwt_ctx *c) {
     return DEBWT_OK;
 }
 
+// Copies between a CALLER's host buffer and the device are queued on the context's streams: whoever returns early with an
+// error must not leave them in flight -- the caller is free to release the buffer as soon as the call is back.
+struct DrainOnError {
+    debwt_ctx *c;
+    bool armed = true;
+    ~DrainOnError() {
+        if (!armed) return;
+        if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+    }
+};
+
 inline u32 grid_for(u64 n, u32 block) { return (u32)((n + block - 1) / block); }
 
 RadixWorkspace radix_ws(debwt_ctx *c) {
@@ -353,6 +365,7 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     ENSURE(c, c->sepbits, bw * 8);
     ENSURE(c, c->sep, nrec * 8);
     const size_t words = (size_t)((n + 63) >> 5);
+    DrainOnError drain{c};                                 // from here on `packed` and `sep` are being read by queued copies
     HIPCHK(c, hipMemcpyAsync(c->sep.p, sep, nrec * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->sepbits.p, 0, bw * 8, c->stream));
     k_set_sepbits<<<grid_for(nrec, 256), 256, 0, c->stream>>>(c->sep.as<u64>(), nrec, c->sepbits.as<u64>());
@@ -401,6 +414,7 @@ extern "C" int debwt_load_text(debwt_ctx *c, const uint64_t *packed, uint64_t n,
     ENSURE(c, c->hash_rows, nrec * 8 + 64);
     int rc = sync_check(c);
     if (rc) return rc;
+    drain.armed = false;                                   // (both streams have drained: the text copies are ordered before c->stream)
     c->stage = ST_LOADED;
     memset(&c->st, 0, sizeof c->st);
     c->st.n = n; c->st.nrec = nrec; c->st.n_main = M;
@@ -1614,6 +1628,9 @@ extern "C" int debwt_bwt_assemble(debwt_ctx *c) {
 // needs more grows them when it gets there).  Not to be called while another call on the context is running.
 extern "C" int debwt_reserve(debwt_ctx *c, uint64_t n, uint64_t nrec, double branching, unsigned flags) {
     if (!c || n < 34 || nrec == 0 || n <= nrec * (uint64_t)c->K || (flags & ~DEBWT_RESERVE_ONE_SHOT)) return DEBWT_EINVAL;
+    // before the text is there, and only then: the buffers below are re-allocated WITHOUT their contents, so a context that
+    // holds a loaded text (or a result) would go on with a stale census over uninitialised memory
+    if (c->stage >= ST_LOADED) { c->err = "debwt_reserve: the context already holds a text (reserve comes before the load)"; return DEBWT_ESTATE; }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (branching <= 0) branching = 0.12;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -1720,6 +1737,7 @@ extern "C" int debwt_build_to_host(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_r
     if (c->Q && (rc = blue_queue(c, &bq))) return rc;
     const u64 rows = shard_rows(c), nw = (rows + 31) >> 5;
     u64 bdone = 0;                                                    // 8192-row blocks assembled and on their way
+    DrainOnError drain{c};                                            // copies into the caller's `bwt` are queued range by range
     for (size_t i = 0; i < c->ranges.size(); i++) {
         const debwt_ctx::KeyRange &r = c->ranges[i];
         if ((rc = blue_sort_part(c, bq, r.qbase, r.Q, r.l0, r.nl))) return rc;
@@ -1743,7 +1761,9 @@ extern "C" int debwt_build_to_host(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_r
         HIPCHK(c, hipMemcpyAsync(hash_rows, c->hash_rows.p, (c->nrec - 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(dollar_row, c->dollar.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-    return sync_check(c);
+    if ((rc = sync_check(c))) return rc;
+    drain.armed = false;
+    return DEBWT_OK;
 }
 
 extern "C" int debwt_fetch_bwt(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row) {

@@ -9,8 +9,26 @@
 #include "../../include/debwt_hip.h"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>          // types and prototypes only: the library is loaded on demand (dlopen), never linked
 #include <dlfcn.h>
+// RCCL: types and prototypes only -- the library is loaded on demand (dlopen), never linked; where its header is not
+// installed the handful of declarations this file needs is stated here (RCCL's public API, values as in rccl.h)
+#if defined(__has_include) && __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommAbort(ncclComm_t comm);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+const char *ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -47,17 +65,29 @@ struct DevMem {
 // barrier is latched by the thread that closes it: a thread that runs ahead and fails before a slow waiter of the
 // barrier before has woken up must not change what that waiter returns (it would leave alone while the others wait for
 // it at the next barrier).
+//
+// Serial mode (debwt_multi_set_serial; measurement of the shards one by one on a box with fewer GPUs than shards): between
+// two barriers the shards take turns in shard order -- enter(r) waits until the shards before r have reached the barrier --
+// so that only one of them is on the GPU at a time and the wall time of its steps is its own.
 struct Rendezvous {
     std::mutex m;
     std::condition_variable cv;
     int n = 1, waiting = 0, phase = 0;
     int failed = 0;
     bool ok_of_phase[2] = {true, true};
+    bool serial = false;
+    int turn = 0;
+    void enter(int r) {
+        if (!serial) return;
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return turn == r; });
+    }
     bool sync(int rc) {
         std::unique_lock<std::mutex> lk(m);
         if (rc && !failed) failed = rc;
         const int ph = phase;
-        if (++waiting == n) { waiting = 0; ok_of_phase[ph & 1] = failed == 0; phase++; cv.notify_all(); }
+        if (serial) { turn++; cv.notify_all(); }
+        if (++waiting == n) { waiting = 0; turn = 0; ok_of_phase[ph & 1] = failed == 0; phase++; cv.notify_all(); }
         else cv.wait(lk, [&] { return phase != ph; });
         return ok_of_phase[ph & 1];
     }
@@ -75,17 +105,27 @@ struct Rccl {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    bool ready = false;                     // every symbol resolved: only then is any of the pointers used
     bool load(std::string *err) {
-        if (lib) return true;
+        if (ready) return true;
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;
         }
-        if (!lib) { *err = std::string("RCCL is not available: ") + dlerror(); return false; }
-#define RCCL_SYM(f) f = reinterpret_cast<decltype(f)>(dlsym(lib, "nccl" #f)); if (!f) { *err = "librccl lacks nccl" #f; return false; }
+        if (!lib) { const char *e = dlerror(); *err = std::string("RCCL is not available: ") + (e ? e : "dlopen failed"); return false; }
+        const char *missing = nullptr;
+#define RCCL_SYM(f) f = reinterpret_cast<decltype(f)>(dlsym(lib, "nccl" #f)); if (!f && !missing) missing = "nccl" #f;
         RCCL_SYM(CommInitAll) RCCL_SYM(CommDestroy) RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd) RCCL_SYM(Send) RCCL_SYM(Recv)
-        RCCL_SYM(GetErrorString)
+        RCCL_SYM(GetErrorString) RCCL_SYM(CommAbort)
 #undef RCCL_SYM
+        if (missing) {                      // a half-loaded library is no library: the next call starts over
+            *err = std::string("librccl lacks ") + missing;
+            dlclose(lib);
+            lib = nullptr;
+            return false;
+        }
+        ready = true;
         return true;
     }
 };
@@ -112,7 +152,9 @@ struct debwt_multi {
     int exchange_backend = DEBWT_EXCHANGE_PEER_COPY;
     Rccl rccl;
     std::vector<ncclComm_t> comm;           // one communicator per shard (ncclCommInitAll), created by the first RCCL build
+    bool comm_dead = false;                 // an exchange failed inside its group: the communicators were aborted (abort_comms)
     debwt_multi_stats st{};
+    std::vector<debwt_shard_report> rep;    // per shard: wall ms per step, bytes per exchange, sizes (debwt_multi_get_shard_report)
     // what the threads publish for each other
     std::vector<std::vector<uint64_t>> hist, offs, boffs;
     std::vector<std::vector<uint32_t>> cuts;
@@ -156,6 +198,7 @@ long long xchg(debwt_multi *m, int r, void *dst, size_t esz, PtrOf ptr_of, OffOf
     std::vector<uint64_t> roff(G);                                 // where source s lands in dst (bytes)
     for (int s = 0; s < G; s++) { roff[s] = o * esz; o += cnt_of(s, r); }
     for (size_t k = 0; k < pieces; k++) {
+        { std::lock_guard<std::mutex> lk(m->rv.m); if (m->comm_dead) return -1; }
         ncclResult_t e = m->rccl.GroupStart();
         for (int d = 0; d < G && e == ncclSuccess; d++) {
             const size_t bytes = cnt_of(r, d) * esz, a = std::min(bytes, k * RCCL_PIECE), b = std::min(bytes, (k + 1) * RCCL_PIECE);
@@ -176,18 +219,81 @@ long long xchg(debwt_multi *m, int r, void *dst, size_t esz, PtrOf ptr_of, OffOf
     return (long long)o;
 }
 
+const char *const STEP_NAMES[DEBWT_MULTI_STEPS] = {
+    "shard_histogram", "shard_plan", "kmer_sort_rle", "shard_partition_keys", "exchange_keys", "shard_sort_range", "shard_sort_end",
+    "shard_classify_local", "shard_facts_export", "exchange_facts", "shard_classify_global", "shard_sp_flags", "shard_sp_emit",
+    "exchange_sp", "shard_sp_import", "shard_blue_route", "exchange_blue", "shard_blue_place", "blue_sort", "bwt_assemble",
+    "shard_export", "exchange_rows", "concat_rows", "waiting"};
+enum { S_HIST, S_PLAN, S_RESCAN, S_PARTITION, S_XKEYS, S_SORT_RANGE, S_SORT_END, S_CLASSIFY_LOCAL, S_FACTS_EXPORT, S_XFACTS,
+       S_CLASSIFY_GLOBAL, S_SP_FLAGS, S_SP_EMIT, S_XSP, S_SP_IMPORT, S_BLUE_ROUTE, S_XBLUE, S_BLUE_PLACE, S_BLUE_SORT, S_ASSEMBLE,
+       S_EXPORT, S_XROWS, S_CONCAT, S_WAITING };
+enum { X_KEYS, X_FACTS, X_SP, X_BLUE, X_ROWS };
+
+// wall time of one step of one shard: from here to the end of the scope, with the device drained at both ends in serial
+// mode (there the shard is alone on its GPU, so the time is the step's own)
+struct StepTimer {
+    debwt_multi *m; int r, step;
+    std::chrono::steady_clock::time_point t0;
+    StepTimer(debwt_multi *m_, int r_, int step_) : m(m_), r(r_), step(step_), t0(std::chrono::steady_clock::now()) {}
+    ~StepTimer() {
+        if (m->rv.serial) (void)hipDeviceSynchronize();
+        m->rep[r].ms[step] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+
+// an RCCL exchange that failed on one shard: the peers sit in their groups, or will, waiting for this one -- end every
+// communicator so that their streams come back (with an error), and make the next RCCL build start from new ones
+// (the handles stay in m->comm until the build's threads have joined: a shard that has not reached its group yet finds
+// comm_dead set and posts nothing; debwt_multi_build drops the handles afterwards)
+void abort_comms(debwt_multi *m) {
+    {
+        std::lock_guard<std::mutex> lk(m->rv.m);
+        if (m->comm_dead) return;
+        m->comm_dead = true;
+    }
+    for (ncclComm_t cm : m->comm) if (cm) (void)m->rccl.CommAbort(cm);
+}
+
 void shard_thread(debwt_multi *m, int r) {
     const int G = m->G;
     debwt_ctx *c = m->ctx[r];
     Rendezvous &rv = m->rv;
     (void)hipSetDevice(m->dev[r]);
-    int rc;
-#define STEP(call, what) do { rc = (call); if (rc) set_err(m, r, what); } while (0)
+    const bool over_rccl = m->exchange_backend == DEBWT_EXCHANGE_RCCL;
+    debwt_shard_report &rep = m->rep[r];
+    int rc = 0;
+#define STEP(id, call, what) do { StepTimer t_(m, r, id); rc = (call); if (rc) set_err(m, r, what); } while (0)
+    // the barrier between two stages; in serial mode the shards then take turns again.  (The time a shard spends here is
+    // its wait for the slowest shard: reported, since it is what imbalance costs.)
+    auto barrier = [&](int rc_) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool ok = rv.sync(rc_);
+        if (ok) rv.enter(r);
+        if (!rv.serial) rep.ms[S_WAITING] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return ok;
+    };
+    // An RCCL exchange is a collective: either every shard posts its sends and receives or none may -- a shard that
+    // skipped its group after a local error (out of memory, a failed step) would leave the others waiting in theirs for
+    // ever.  So over RCCL the shards agree on rc before every exchange; peer copies need no such gate (a pull that is
+    // skipped is missed by nobody).  On an error INSIDE the group all communicators are ended (abort_comms).
+#define EXCHANGE(id, xid, dst, esz, ptr_of, off_of, cnt_of) do { \
+        if (over_rccl && !barrier(rc)) return; \
+        if (!rc) { \
+            StepTimer t_(m, r, id); \
+            uint64_t in_ = 0, out_ = 0; \
+            for (int s_ = 0; s_ < G; s_++) if (s_ != r) { in_ += (cnt_of)(s_, r); out_ += (cnt_of)(r, s_); } \
+            rep.bytes_in[xid] += in_ * (esz); rep.bytes_out[xid] += out_ * (esz); \
+            if (xchg(m, r, dst, esz, ptr_of, off_of, cnt_of) < 0) { rc = DEBWT_EDEVICE; if (over_rccl) abort_comms(m); } \
+        } \
+    } while (0)
+
+    rv.enter(r);
     // 1. census of the slices -> splitters over the shards (instance counts balanced on the summed census, the
     //    reference's segCount idea, src/mySort.c:104-110), key ranges inside every shard
-    STEP(debwt_shard_begin(c, r, G), "shard_begin");
-    if (!rc) STEP(debwt_shard_histogram(c, m->hist[r].data()), "shard_histogram");
-    if (!rv.sync(rc)) return;
+    rc = debwt_shard_begin(c, r, G);
+    if (rc) set_err(m, r, "shard_begin");
+    if (!rc) STEP(S_HIST, debwt_shard_histogram(c, m->hist[r].data()), "shard_histogram");
+    if (!barrier(rc)) return;
     std::vector<uint64_t> total(BINS, 0), cum(BINS + 1, 0);
     for (int s = 0; s < G; s++) for (int b = 0; b < BINS; b++) total[b] += m->hist[s][b];
     for (int b = 0; b < BINS; b++) cum[b + 1] = cum[b] + total[b];
@@ -198,26 +304,29 @@ void shard_thread(debwt_multi *m, int r) {
         uint32_t b = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
         bins[s] = std::min<uint32_t>(std::max(b, bins[s - 1]), BINS);
     }
+    rep.bin_lo = bins[r]; rep.bin_hi = bins[r + 1];
+    rep.keys = cum[bins[r + 1]] - cum[bins[r]];
     uint32_t nr = 0;
     const uint64_t held = m->xa[r].cap + m->xb[r].cap + m->facts[r].cap + m->allfacts[r].cap + m->sp[r].cap + m->allsp[r].cap +
                           m->part[r].cap + (r == 0 ? m->parts.cap + m->out.cap : 0);
     const int keys = m->key_mode >= 0 ? m->key_mode : debwt_shard_key_mode(m->n, G, 0.0, nullptr, nullptr);
     const bool exchange = keys == DEBWT_KEYS_EXCHANGE;
-    STEP(debwt_shard_plan(c, total.data(), bins[r], bins[r + 1], cum[bins[r]], exchange ? 1 : 2, held, &nr), "shard_plan");
+    STEP(S_PLAN, debwt_shard_plan(c, total.data(), bins[r], bins[r + 1], cum[bins[r]], exchange ? 1 : 2, held, &nr), "shard_plan");
     std::vector<uint64_t> mk(MAXR, 0);
     m->cuts[r].assign(MAXR + 1, 0);
-    if (!rc) STEP(debwt_shard_ranges(c, m->cuts[r].data(), mk.data(), MAXR), "shard_ranges");
+    if (!rc) { rc = debwt_shard_ranges(c, m->cuts[r].data(), mk.data(), MAXR); if (rc) set_err(m, r, "shard_ranges"); }
     m->cuts[r].resize(rc ? 1 : nr + 1);
-    if (!rv.sync(rc)) return;
+    rep.key_ranges = rc ? 0 : nr;
+    if (!barrier(rc)) return;
     size_t rounds = 0;
     for (int s = 0; s < G; s++) rounds = std::max(rounds, m->cuts[s].size() - 1);
     if (r == 0) { m->st.rounds = (uint32_t)rounds; m->st.key_mode = (uint32_t)keys; m->st.exchange_backend = (uint32_t)m->exchange_backend; }
 
     // 2. the keys of the shard's ranges: read from the shard's own copy of the text (key rescan) ...
-    if (!exchange) STEP(debwt_kmer_sort_rle(c), "kmer_sort_rle");
+    if (!exchange) STEP(S_RESCAN, debwt_kmer_sort_rle(c), "kmer_sort_rle");
     // ... or the k-mer bucket exchange, one round per key range
-    if (exchange) STEP(debwt_shard_sort_begin(c), "shard_sort_begin");
-    if (!rv.sync(rc)) return;
+    if (exchange) { rc = debwt_shard_sort_begin(c); if (rc) set_err(m, r, "shard_sort_begin"); }
+    if (!barrier(rc)) return;
     for (size_t t = 0; exchange && t < rounds; t++) {
         std::vector<uint8_t> tab(BINS, 0xFF);
         for (int s = 0; s < G; s++)
@@ -226,26 +335,28 @@ void shard_thread(debwt_multi *m, int r) {
         uint64_t ns = 0;
         for (int b = 0; b < BINS; b++) if (tab[b] != 0xFF) ns += m->hist[r][b];
         rc = m->xa[r].ensure((ns + 64) * 8) ? 0 : DEBWT_ENOMEM;
-        if (!rc) STEP(debwt_shard_partition_keys(c, tab.data(), (uint64_t *)m->xa[r].p, m->xa[r].cap / 8, m->offs[r].data()),
+        if (!rc) STEP(S_PARTITION, debwt_shard_partition_keys(c, tab.data(), (uint64_t *)m->xa[r].p, m->xa[r].cap / 8, m->offs[r].data()),
                       "shard_partition_keys");
-        if (!rv.sync(rc)) return;
+        if (!barrier(rc)) return;
         uint64_t nrecv = 0;
         for (int s = 0; s < G; s++) nrecv += m->offs[s][r + 1] - m->offs[s][r];
         rc = m->xb[r].ensure((nrecv + 64) * 8) ? 0 : DEBWT_ENOMEM;
-        if (!rc && xchg(m, r, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s, int d) { return m->offs[s][d]; },
-                            [&](int s, int d) { return m->offs[s][d + 1] - m->offs[s][d]; }) < 0) rc = DEBWT_EDEVICE;
+        EXCHANGE(S_XKEYS, X_KEYS, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s, int d) { return m->offs[s][d]; },
+                 [&](int s, int d) { return m->offs[s][d + 1] - m->offs[s][d]; });
         if (r == 0) { uint64_t moved = 0; for (int s = 1; s < G; s++) moved += m->offs[s][1] - m->offs[s][0]; m->st.key_bytes_in += moved * 8; }
-        if (!rv.sync(rc)) return;                                   // every pull is done: the send buffers are free again
-        if (t + 1 < m->cuts[r].size()) STEP(debwt_shard_sort_range(c, (uint32_t)t, (uint64_t *)m->xb[r].p, nrecv), "shard_sort_range");
-        if (!rv.sync(rc)) return;
+        if (!barrier(rc)) return;                                   // every pull is done: the send buffers are free again
+        if (t + 1 < m->cuts[r].size())
+            STEP(S_SORT_RANGE, debwt_shard_sort_range(c, (uint32_t)t, (uint64_t *)m->xb[r].p, nrecv), "shard_sort_range");
+        if (!barrier(rc)) return;
     }
-    if (exchange) STEP(debwt_shard_sort_end(c), "shard_sort_end");
+    if (exchange) STEP(S_SORT_END, debwt_shard_sort_end(c), "shard_sort_end");
 
     // 3. local classification totals, red table from everybody's facts
-    if (!rc) STEP(debwt_shard_classify_local(c, &m->nfacts[r], &m->nblocks[r], &m->brows[r]), "shard_classify_local");
+    if (!rc) STEP(S_CLASSIFY_LOCAL, debwt_shard_classify_local(c, &m->nfacts[r], &m->nblocks[r], &m->brows[r]), "shard_classify_local");
     if (!rc) rc = m->facts[r].ensure((m->nfacts[r] + 1) * 8) ? 0 : DEBWT_ENOMEM;
-    if (!rc) STEP(debwt_shard_facts_export(c, (uint64_t *)m->facts[r].p, m->facts[r].cap / 8), "shard_facts_export");
-    if (!rv.sync(rc)) return;
+    if (!rc) STEP(S_FACTS_EXPORT, debwt_shard_facts_export(c, (uint64_t *)m->facts[r].p, m->facts[r].cap / 8), "shard_facts_export");
+    rep.blocks = m->nblocks[r]; rep.blue_rows = m->brows[r];
+    if (!barrier(rc)) return;
     uint64_t allf = 0, qbase = 0, btotal = 0;
     std::vector<uint32_t> first_block(G + 1, 0);
     for (int s = 0; s < G; s++) {
@@ -254,62 +365,62 @@ void shard_thread(debwt_multi *m, int r) {
         first_block[s + 1] = first_block[s] + (uint32_t)m->nblocks[s];
     }
     rc = m->allfacts[r].ensure((allf + 1) * 8) ? 0 : DEBWT_ENOMEM;
-    if (!rc && xchg(m, r, m->allfacts[r].p, 8, [&](int s) { return m->facts[s].p; }, [&](int, int) { return (uint64_t)0; },
-                        [&](int s, int) { return m->nfacts[s]; }) < 0) rc = DEBWT_EDEVICE;
-    if (!rc) STEP(debwt_shard_classify_global(c, (const uint64_t *)m->allfacts[r].p, allf, qbase, btotal), "shard_classify_global");
+    EXCHANGE(S_XFACTS, X_FACTS, m->allfacts[r].p, 8, [&](int s) { return m->facts[s].p; }, [&](int, int) { return (uint64_t)0; },
+             [&](int s, int) { return m->nfacts[s]; });
+    if (!rc) STEP(S_CLASSIFY_GLOBAL, debwt_shard_classify_global(c, (const uint64_t *)m->allfacts[r].p, allf, qbase, btotal), "shard_classify_global");
 
     // 4. SP code of the slices, symbols gathered everywhere
     uint64_t bloc = 0;
-    if (!rc) STEP(debwt_shard_sp_flags(c, &m->slen[r], &bloc), "shard_sp_flags");
-    if (!rv.sync(rc)) return;
+    if (!rc) STEP(S_SP_FLAGS, debwt_shard_sp_flags(c, &m->slen[r], &bloc), "shard_sp_flags");
+    if (!barrier(rc)) return;
     uint64_t sp_off = 0, sp_total = 0;
     for (int s = 0; s < G; s++) { if (s < r) sp_off += m->slen[s]; sp_total += m->slen[s]; }
     rc = m->sp[r].ensure(m->slen[r] + 64) ? 0 : DEBWT_ENOMEM;
-    if (!rc) STEP(debwt_shard_sp_emit(c, sp_off, (uint8_t *)m->sp[r].p, m->sp[r].cap), "shard_sp_emit");
-    if (!rv.sync(rc)) return;
+    if (!rc) STEP(S_SP_EMIT, debwt_shard_sp_emit(c, sp_off, (uint8_t *)m->sp[r].p, m->sp[r].cap), "shard_sp_emit");
+    if (!barrier(rc)) return;
     rc = m->allsp[r].ensure(sp_total + 64) ? 0 : DEBWT_ENOMEM;
-    if (!rc && xchg(m, r, m->allsp[r].p, 1, [&](int s) { return m->sp[s].p; }, [&](int, int) { return (uint64_t)0; },
-                        [&](int s, int) { return m->slen[s]; }) < 0) rc = DEBWT_EDEVICE;
-    if (!rc) STEP(debwt_shard_sp_import(c, (const uint8_t *)m->allsp[r].p, sp_total), "shard_sp_import");
+    EXCHANGE(S_XSP, X_SP, m->allsp[r].p, 1, [&](int s) { return m->sp[s].p; }, [&](int, int) { return (uint64_t)0; },
+             [&](int s, int) { return m->slen[s]; });
+    if (!rc) STEP(S_SP_IMPORT, debwt_shard_sp_import(c, (const uint8_t *)m->allsp[r].p, sp_total), "shard_sp_import");
 
     // 5. blue entries of the slice -> the owners of their blocks
     if (!rc) rc = m->xa[r].ensure((bloc + 64) * 8) ? 0 : DEBWT_ENOMEM;
-    if (!rc) STEP(debwt_shard_blue_route(c, first_block.data(), (uint64_t *)m->xa[r].p, m->xa[r].cap / 8, m->boffs[r].data()),
+    if (!rc) STEP(S_BLUE_ROUTE, debwt_shard_blue_route(c, first_block.data(), (uint64_t *)m->xa[r].p, m->xa[r].cap / 8, m->boffs[r].data()),
                   "shard_blue_route");
-    if (!rv.sync(rc)) return;
+    if (!barrier(rc)) return;
     uint64_t brecv = 0;
     for (int s = 0; s < G; s++) brecv += m->boffs[s][r + 1] - m->boffs[s][r];
     rc = m->xb[r].ensure((brecv + 64) * 8) ? 0 : DEBWT_ENOMEM;
-    if (!rc && xchg(m, r, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s, int d) { return m->boffs[s][d]; },
-                        [&](int s, int d) { return m->boffs[s][d + 1] - m->boffs[s][d]; }) < 0) rc = DEBWT_EDEVICE;
+    EXCHANGE(S_XBLUE, X_BLUE, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s, int d) { return m->boffs[s][d]; },
+             [&](int s, int d) { return m->boffs[s][d + 1] - m->boffs[s][d]; });
     if (r == 0) { uint64_t moved = 0; for (int s = 1; s < G; s++) moved += m->boffs[s][1] - m->boffs[s][0]; m->st.blue_bytes_in = moved * 8; }
-    if (!rv.sync(rc)) return;
-    STEP(debwt_shard_blue_place(c, (uint64_t *)m->xb[r].p, brecv), "shard_blue_place");
+    if (!barrier(rc)) return;
+    STEP(S_BLUE_PLACE, debwt_shard_blue_place(c, (uint64_t *)m->xb[r].p, brecv), "shard_blue_place");
 
     // 6. owned blocks and rows
-    if (!rc) STEP(debwt_blue_sort(c), "blue_sort");
-    if (!rc) STEP(debwt_bwt_assemble(c), "bwt_assemble");
-    if (!rc) STEP(debwt_shard_info(c, &m->rowbase[r], &m->rows[r], &m->nhash[r]), "shard_info");
-    if (!rv.sync(rc)) return;
+    if (!rc) STEP(S_BLUE_SORT, debwt_blue_sort(c), "blue_sort");
+    if (!rc) STEP(S_ASSEMBLE, debwt_bwt_assemble(c), "bwt_assemble");
+    if (!rc) { rc = debwt_shard_info(c, &m->rowbase[r], &m->rows[r], &m->nhash[r]); if (rc) set_err(m, r, "shard_info"); }
+    rep.rows = m->rows[r];
+    if (!barrier(rc)) return;
 
     // 7. final concat on the first GPU: the packed row ranges are pulled there and shift-merged by row offset
     uint64_t maxw = 0;
     for (int s = 0; s < G; s++) maxw = std::max<uint64_t>(maxw, (m->rows[s] + 31) / 32 + 1);
     rc = m->part[r].ensure(maxw * 8) ? 0 : DEBWT_ENOMEM;
-    if (!rc) STEP(debwt_shard_export(c, (uint64_t *)m->part[r].p, maxw), "shard_export");
+    if (!rc) STEP(S_EXPORT, debwt_shard_export(c, (uint64_t *)m->part[r].p, maxw), "shard_export");
     m->hrows[r].assign(std::max<uint64_t>(m->nhash[r], 1), 0);
-    if (!rc) STEP(debwt_shard_fetch(c, nullptr, m->hrows[r].data(), &m->drow[r]), "shard_fetch");
+    if (!rc) { rc = debwt_shard_fetch(c, nullptr, m->hrows[r].data(), &m->drow[r]); if (rc) set_err(m, r, "shard_fetch"); }
     m->hrows[r].resize(m->nhash[r]);
-    if (!rv.sync(rc)) return;
+    if (!barrier(rc)) return;
     if (r == 0) rc = (m->parts.ensure(maxw * G * 8) && m->out.ensure(((m->n + 31) / 32 + 1) * 8)) ? 0 : DEBWT_ENOMEM;
-    if (m->exchange_backend == DEBWT_EXCHANGE_RCCL && !rv.sync(rc)) return;      // (a gather: everybody sends, the first GPU receives)
-    if (!rc && (r == 0 || m->exchange_backend == DEBWT_EXCHANGE_RCCL) &&
-        xchg(m, r, r == 0 ? m->parts.p : nullptr, 8, [&](int s) { return m->part[s].p; }, [&](int, int) { return (uint64_t)0; },
-                 [&](int, int d) { return d == 0 ? maxw : (uint64_t)0; }) < 0) rc = DEBWT_EDEVICE;
+    if (r == 0 || over_rccl)                                       // (a gather: everybody sends, the first GPU receives)
+        EXCHANGE(S_XROWS, X_ROWS, r == 0 ? m->parts.p : nullptr, 8, [&](int s) { return m->part[s].p; }, [&](int, int) { return (uint64_t)0; },
+                 [&](int, int d) { return d == 0 ? maxw : (uint64_t)0; });
     if (r == 0) {
         std::vector<uint64_t> poff(G), pbase(G), prows(G);
         for (int s = 0; s < G; s++) { poff[s] = maxw * s; pbase[s] = m->rowbase[s]; prows[s] = m->rows[s]; }
-        if (!rc) STEP(debwt_concat_rows(c, (const uint64_t *)m->parts.p, (uint32_t)G, poff.data(), pbase.data(), prows.data(), m->n,
+        if (!rc) STEP(S_CONCAT, debwt_concat_rows(c, (const uint64_t *)m->parts.p, (uint32_t)G, poff.data(), pbase.data(), prows.data(), m->n,
                                         (uint64_t *)m->out.p), "concat_rows");
         m->hash_rows.clear();
         m->dollar_row = ~0ull;
@@ -326,6 +437,7 @@ void shard_thread(debwt_multi *m, int r) {
     }
     (void)rv.sync(rc);
 #undef STEP
+#undef EXCHANGE
 }
 
 }  // namespace
@@ -343,6 +455,7 @@ extern "C" int debwt_multi_create(const debwt_config *cfg, const int *devices, i
     m->cuts.assign(ngpus, {});
     for (auto *v : {&m->nfacts, &m->nblocks, &m->brows, &m->slen, &m->rowbase, &m->rows, &m->nhash, &m->drow}) v->assign(ngpus, 0);
     m->hrows.assign(ngpus, {});
+    m->rep.assign(ngpus, debwt_shard_report{});
     m->rv.n = ngpus;
     int rc = DEBWT_OK;
     for (int r = 0; r < ngpus && !rc; r++) {
@@ -379,7 +492,7 @@ extern "C" void debwt_multi_destroy(debwt_multi *m) {
         if (m->ctx[r]) debwt_destroy(m->ctx[r]);
     }
     m->parts.release(); m->out.release();
-    for (ncclComm_t cm : m->comm) if (cm) (void)m->rccl.CommDestroy(cm);
+    if (!m->comm_dead) for (ncclComm_t cm : m->comm) if (cm && m->rccl.ready) (void)m->rccl.CommDestroy(cm);
     if (m->own.words) debwt_free_packed(&m->own);
     delete m;
 }
@@ -436,8 +549,13 @@ extern "C" int debwt_multi_set_exchange(debwt_multi *m, int backend) {
 extern "C" int debwt_multi_build(debwt_multi *m) {
     if (!m || !m->n) return DEBWT_ESTATE;
     m->err.clear(); m->built = false;
-    m->rv.failed = 0; m->rv.waiting = 0;
+    if (m->rv.serial && m->exchange_backend == DEBWT_EXCHANGE_RCCL) {
+        m->err = "serial mode takes the shards one at a time: an RCCL exchange needs all of them at once (use peer copies)";
+        return DEBWT_EINVAL;
+    }
+    m->rv.failed = 0; m->rv.waiting = 0; m->rv.turn = 0;
     m->st = debwt_multi_stats{};
+    m->rep.assign(m->G, debwt_shard_report{});
     m->st.ngpus = (uint32_t)m->G;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
@@ -445,6 +563,10 @@ extern "C" int debwt_multi_build(debwt_multi *m) {
     shard_thread(m, 0);
     for (auto &t : th) t.join();
     m->st.ms_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (m->comm_dead) {                                           // aborted communicators are gone: the next RCCL build asks again
+        m->comm.clear(); m->comm_dead = false;
+        m->exchange_backend = DEBWT_EXCHANGE_PEER_COPY;
+    }
     if (m->rv.failed) return m->rv.failed;
     m->built = true;
     return DEBWT_OK;
@@ -467,6 +589,20 @@ extern "C" int debwt_multi_get_stats(const debwt_multi *m, debwt_multi_stats *ou
     if (shard0) return debwt_get_stats(m->ctx[0], shard0);
     return DEBWT_OK;
 }
+
+extern "C" int debwt_multi_set_serial(debwt_multi *m, int serial) {
+    if (!m) return DEBWT_EINVAL;
+    m->rv.serial = serial != 0;
+    return DEBWT_OK;
+}
+
+extern "C" int debwt_multi_get_shard_report(const debwt_multi *m, int shard, debwt_shard_report *out) {
+    if (!m || !out || shard < 0 || shard >= m->G) return DEBWT_EINVAL;
+    *out = m->rep[shard];
+    return DEBWT_OK;
+}
+
+extern "C" const char *debwt_multi_step_name(int step) { return step >= 0 && step < DEBWT_MULTI_STEPS ? STEP_NAMES[step] : ""; }
 
 extern "C" int debwt_multi_verify(debwt_multi *m, debwt_verify_report *rep) {
     // inverse BWT of the concatenated result on the first GPU (it holds the text like every GPU)

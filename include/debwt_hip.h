@@ -118,11 +118,12 @@ int debwt_load_fasta_opts(debwt_ctx *ctx, const char *path, int threads, unsigne
  * seconds the driver takes to hand out a few hundred GB (it clears what another process released) pass behind the
  * ingest instead of inside the first build.  branching: expected fraction of positions that are branching nodes, sizes the
  * data-dependent buffers (<= 0: 0.12); everything grows later if the text needs more.  Optional: without it the same
- * buffers are allocated by debwt_load_text and the stages.  Not re-entrant with other calls on the context.
+ * buffers are allocated by debwt_load_text and the stages.  Not re-entrant with other calls on the context; DEBWT_ESTATE
+ * on a context that already holds a text (its buffers would be re-allocated under it).
  * DEBWT_RESERVE_ONE_SHOT: the context will build once.  When the first buffers arrive at the driver's clearing rate (the
  * memory was another process's a moment ago) the text is cut into more, smaller key ranges than a context that is reused
- * would take -- less workspace to wait for, a few more passes over the text (the choice stays with the context like a
- * debwt_set_range_cap). */
+ * would take -- less workspace to wait for, a few more passes over the text.  That choice STAYS with the context for every
+ * later build, exactly like a debwt_set_range_cap (which also undoes it). */
 #define DEBWT_RESERVE_ONE_SHOT 1u
 int debwt_reserve(debwt_ctx *ctx, uint64_t n, uint64_t nrec, double branching, unsigned flags);
 
@@ -304,6 +305,25 @@ int debwt_multi_set_exchange(debwt_multi *m, int backend);
 int debwt_multi_build(debwt_multi *m);
 int debwt_multi_fetch_bwt(debwt_multi *m, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar_row);
 int debwt_multi_get_stats(const debwt_multi *m, debwt_multi_stats *out, debwt_stats *shard0);
+/* What one shard of the last debwt_multi_build did, step by step -- the evidence for load balance over the shards (the
+ * reference balances its per-thread segments by instance counts, src/mySort.c:104-110; whether that balances the later
+ * stages too is a measurement).  ms[i]: wall milliseconds of step i (debwt_multi_step_name(i): the debwt_shard_* calls of
+ * the sequence above, the exchanges, and "waiting" = time at the barriers between the stages, i.e. what the slowest
+ * shard costs this one); bytes_in / bytes_out: what the shard received from / sent to OTHER shards in each exchange
+ * (0 keys, 1 facts, 2 SP symbols, 3 blue entries, 4 final rows).
+ * debwt_multi_set_serial(m, 1): the shards of a build take turns between the barriers, one on its GPU at a time, device
+ * drained around every step -- the steps' times are then each shard's own even when several shards share one GPU (the
+ * way N = 2, 4, 8 are measured on a one-GPU box; peer-copy exchanges only).  The result of the build is the same. */
+#define DEBWT_MULTI_STEPS 24
+typedef struct {
+    float ms[DEBWT_MULTI_STEPS];
+    uint64_t bytes_in[5], bytes_out[5];
+    uint64_t keys, key_ranges, blocks, blue_rows, rows;   /* node instances, key ranges, multi-in blocks, their rows, BWT rows */
+    uint32_t bin_lo, bin_hi;                              /* the shard's 12-bit prefix bins [bin_lo, bin_hi) */
+} debwt_shard_report;
+int debwt_multi_set_serial(debwt_multi *m, int serial);
+int debwt_multi_get_shard_report(const debwt_multi *m, int shard, debwt_shard_report *out);
+const char *debwt_multi_step_name(int step);
 
 /* ---- intermediates, for stage-by-stage parity ---------------------------------- */
 typedef enum {

@@ -18,7 +18,10 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """Plain `pytest tests/` on a box without a GPU skips the GPU tests instead of failing them."""
+    """Harness tests (subprocess runs of bench.py) are collected after every parity test, whatever the file order: under
+    `pytest -x` a flake there must not hide a comparison with the oracle.  Plain `pytest tests/` on a box without a GPU
+    skips the GPU tests instead of failing them."""
+    items.sort(key=lambda it: 1 if "bench_harness" in it.nodeid else 0)       # stable: everything else keeps its order
     try:
         import torch
         have_gpu = torch.cuda.is_available()

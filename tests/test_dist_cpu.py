@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 import textwrap
+import time
 
 from conftest import ROOT
 
@@ -164,3 +165,64 @@ def test_bench_starts_its_own_ranks_when_run_directly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-check"],
                        env=env2, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "one process per GPU" in r.stderr
+
+
+def _probe(extra, env_extra=None, timeout=300):
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-probe"] + extra,
+                          env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_extras_are_child_launches_that_cannot_own_the_exit_code():
+    """The N > 1 extras of bench.py (the other key path, the C host) are fresh child launches after the measurement's ranks
+    have exited (--launch-probe: rendezvous only).  Recorded when they come back; text in the line and exit code 0 when they
+    fail or are not back in time; `--host=both` (one argument) is taken like `--host both` and does not recurse."""
+    r = _probe(["--host=both"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["ranks_joined"] == 2 and set(j["key_modes_ms"]) >= {"exchange", "rescan"} and j["host_c"]["host"] == "c", j
+    assert r.stderr.count("rank 1 joined") == 2          # the measurement's launch and the other key path's, nothing nested
+
+    r = _probe([], env_extra={"DEBWT_BENCH_FAIL_EXTRA": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert "exit code" in j["key_modes_ms"]["exchange"] and "exit code" in j["host_c"]["error"], j
+    assert "injected failure" in r.stderr
+
+    t0 = time.perf_counter()
+    r = _probe(["--extras-timeout", "2"], env_extra={"DEBWT_BENCH_EXTRA_SLEEP": "60"})
+    assert r.returncode == 0 and time.perf_counter() - t0 < 50, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert "not back within" in j["key_modes_ms"]["exchange"] and "not back within" in j["host_c"]["error"], j
+
+    # started by a launcher (WORLD_SIZE set): no extras at all; --host python / --no-other-mode: none either
+    r = _probe(["--host", "python", "--no-other-mode"])
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert r.returncode == 0 and "key_modes_ms" not in j and "host_c" not in j, j
+
+
+def test_bench_asked_to_leave_during_the_extras_prints_the_measured_line_first():
+    """SIGTERM while an extra is running: the held line goes to stdout, the extra's processes are ended, exit code = the
+    measurement's."""
+    import signal
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DEBWT_BENCH_EXTRA_SLEEP"] = "120"
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-probe"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    err = []
+    for ln in p.stderr:                                   # wait for the measurement to be over and the extras to start
+        err.append(ln)
+        if "held back for the extras" in ln:
+            break
+    time.sleep(3.0)
+    p.send_signal(signal.SIGTERM)
+    out, _ = p.communicate(timeout=120)
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, out, "".join(err)[-1500:])
+    j = json.loads(lines[0])
+    assert j["ranks_joined"] == 2 and "key_modes_ms" not in j

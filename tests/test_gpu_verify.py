@@ -227,97 +227,3 @@ def test_million_reads_property(api):
     rep = d.verify_device()
     assert rep["inverse_bwt_ok"], rep
     d.close()
-
-
-def _run_bench_direct(extra, timeout=900, env_extra=None):
-    """`python bench.py --gpus N ...` exactly as the driver types it for N = 1: no launcher in front."""
-    import json
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(env_extra or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True,
-                       text=True, timeout=timeout)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
-
-
-def test_bench_two_ranks_started_by_bench_itself_gloo():
-    """bench.py --gpus 2 run DIRECTLY starts its two ranks as child processes (they share this box's one GPU, so the
-    collectives go over gloo), builds ONE chr1-sized collection as two k-mer-prefix shards and prints one line whose
-    result passed the census and the device inverse BWT."""
-    j = _run_bench_direct(["--gpus", "2", "--backend", "gloo", "--workload", "chr1_250M", "--steps", "1", "--warmup", "1",
-                           "--no-cpu-baseline"])
-    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "strong" and j["value"] > 0
-    assert j["check"]["census_equals_text"] and j["check"]["inverse_bwt_ok"], j["check"]
-    assert "chr1_250M" in j["config"]["workload"] and j["config"]["bases_per_gpu"] * 2 <= j["config"]["bases"]
-    # the link probe ran and both key paths were timed (--mode auto times the one the cost model did not choose as well)
-    assert j["link_probe"]["content_ok"] and set(j["key_modes_ms"]) >= {"exchange", "rescan"}, (j["link_probe"], j["key_modes_ms"])
-    assert all(isinstance(j["key_modes_ms"][m], float) for m in ("exchange", "rescan")), j["key_modes_ms"]
-
-
-def test_bench_c_host_two_shards_on_one_gpu():
-    """bench.py --gpus 2 --host c: ONE process, debwt_multi_build over two shards (both on this box's GPU with --backend
-    gloo), the line says which host and which exchange its number belongs to; and the default N > 1 run (python ranks first,
-    then the C host as a child process) carries the C host's line under `host_c`."""
-    j = _run_bench_direct(["--gpus", "2", "--backend", "gloo", "--host", "c", "--workload", "chr1_250M", "--steps", "2", "--warmup", "1",
-                           "--no-cpu-baseline"])
-    assert j["host"] == "c" and j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0
-    assert j["check"]["inverse_bwt_ok"] and j["check"]["census_equals_text"], j["check"]
-    assert "peer copies" in j["exchange"]["backend"] and j["exchange"]["keys"] in ("exchange", "rescan")
-    j = _run_bench_direct(["--gpus", "2", "--backend", "gloo", "--workload", "ecoli_4.6M", "--steps", "1", "--warmup", "1",
-                           "--no-cpu-baseline", "--no-other-mode"])
-    assert j["n_gpus"] == 2 and j["check"]["inverse_bwt_ok"] and "python" in j["host"]
-    hc = j["host_c"]
-    assert hc.get("host") == "c" and hc["value"] > 0 and hc["check"]["inverse_bwt_ok"], hc
-
-
-def test_bench_extra_key_mode_cannot_cost_the_result():
-    """The second key path of --mode auto is extra information: when it does not come back in time (here: a watchdog of
-    a millisecond) every rank leaves with exit code 0 and rank 0 has printed the finished line first."""
-    j = _run_bench_direct(["--gpus", "2", "--backend", "gloo", "--workload", "ecoli_4.6M", "--steps", "1", "--warmup", "1",
-                           "--no-cpu-baseline", "--other-mode-timeout", "0.001"])
-    assert j["n_gpus"] == 2 and j["value"] > 0 and j["check"]["inverse_bwt_ok"], j
-    dropped = [v for v in j["key_modes_ms"].values() if isinstance(v, str) and v.startswith("dropped")]
-    assert len(dropped) == 1, j["key_modes_ms"]
-
-
-@pytest.mark.parametrize("failing_rank", [0, 1])
-def test_bench_extra_key_mode_failure_is_an_error_not_a_timeout(failing_rank):
-    """A rank whose extra build RAISES ends the run with a non-zero exit code -- after rank 0 has printed the finished line
-    with the exception text (rank 0's own failure) or the watchdog's words (another rank's) -- so that a broken key path
-    cannot pass for a slow one."""
-    import json
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env["DEBWT_BENCH_FAIL_OTHER_MODE"] = str(failing_rank)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload",
-                        "ecoli_4.6M", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--other-mode-timeout", "20"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0, r.stdout[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    j = json.loads(lines[0])
-    assert j["value"] > 0 and j["check"]["inverse_bwt_ok"]
-    dropped = [v for v in j["key_modes_ms"].values() if isinstance(v, str) and v.startswith("dropped")]
-    assert len(dropped) == 1 and ("failed" in dropped[0]) == (failing_rank == 0), j["key_modes_ms"]
-    assert "injected failure" in r.stderr
-
-
-def test_bench_two_ranks_started_by_bench_itself_rccl():
-    """The same over RCCL when the box has two GPUs (the driver's 8-GPU node; skipped on a one-GPU box)."""
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("one GPU on this box: two RCCL ranks need two devices")
-    for mode in ("exchange", "rescan"):
-        j = _run_bench_direct(["--gpus", "2", "--workload", "chr1_250M", "--steps", "1", "--warmup", "1",
-                               "--no-cpu-baseline", "--mode", mode], env_extra={"DEBWT_BIG_MESSAGE_PROBE": "1"})
-        assert j["n_gpus"] == 2 and j["check"]["census_equals_text"] and j["check"]["inverse_bwt_ok"], j
-        assert j["link_probe"]["content_ok"] and j["link_probe"]["gbytes_per_s_per_peer"] > 0, j["link_probe"]
