@@ -1347,7 +1347,7 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
     // its block gets a PIVOT round next (LsBlock::pivot, stage_kernels.h), which measures how far every row follows one
     // row of the block and so halves what is left of a periodic stretch -- 805 rounds became ~40 on
     // scripts/gpu_lowcomplexity.py.  The bitonic network with its symbol-by-symbol comparator is only the last resort.
-    constexpr u64 LS_BATCH_ROWS = 1ull << 28;
+    constexpr u64 LS_BATCH_ROWS = 1ull << 29;
     struct Work { u64 b0, j0; u32 m, depth, pivot; };
     std::vector<Work> work, next;
     u32 maxm = 0;
@@ -1364,45 +1364,57 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
     std::vector<LsOver> over;
     std::vector<LsBlock> desc;
     u32 round = 0;
+    static const u32 bin_rows = getenv("DEBWT_LS_BIN_ROWS") ? (u32)atoi(getenv("DEBWT_LS_BIN_ROWS")) : LS_BIN_ROWS;
+    static const u32 oversample = getenv("DEBWT_LS_OVERSAMPLE") ? (u32)atoi(getenv("DEBWT_LS_OVERSAMPLE")) : LS_OVERSAMPLE;
+    const bool trace = getenv("DEBWT_TRACE_LARGE") != nullptr;
     while (!work.empty()) {
         next.clear();
+        u64 tr_rows = 0, tr_tie_n = 0, tr_tie_rows = 0, tr_piv = 0, tr_net = 0;
+        for (const Work &wk : work) { tr_rows += wk.m; tr_piv += wk.pivot; }
         for (size_t w0 = 0; w0 < work.size();) {
             desc.clear();
-            u64 rows = 0, wgs = 0;
+            u64 rows = 0, wgs = 0, slots = 0;
+            bool small_ns = false, big_ns = false, small_nb = false, big_nb = false;
             size_t w1 = w0;
             for (; w1 < work.size() && (desc.empty() || rows + work[w1].m <= LS_BATCH_ROWS) && wgs < 0x7FFF0000ull; w1++) {
                 const Work &wk = work[w1];
                 u32 nb = 8;
-                while (nb < LS_MAXBINS && (u64)nb * LS_BIN_ROWS < wk.m) nb <<= 1;
-                u32 ns = std::min<u32>(LS_SAMPLES, std::max<u32>(64u, nb * LS_OVERSAMPLE));
-                desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs, wk.depth, wk.pivot});
+                while (nb < LS_MAXBINS && (u64)nb * bin_rows < wk.m) nb <<= 1;
+                u32 ns = 64;
+                while (ns < LS_SAMPLES && ns < nb * oversample) ns <<= 1;        // a power of two (bitonic sort), a multiple of nb
+                desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs, (u32)slots, wk.depth, wk.pivot});
                 rows += (wk.m + 1u) & ~1u;
-                wgs += (wk.m + 255u) / 256u;
+                wgs += (wk.m + LS_WG_ROWS - 1u) / LS_WG_ROWS;
+                slots += nb;
+                (ns <= 256u ? small_ns : big_ns) = true;
+                (nb <= 64u ? small_nb : big_nb) = true;
             }
             const size_t nblk = desc.size();
             const size_t over_cap = (size_t)(rows / LS_QUEUE_CAP) + 2;
-            // scratch: w, x, en (u64 per row), bin (u32 per row); per block: splitters, range words, result, descriptor;
-            // the batch's oversize ranges
-            const size_t per_blk = LS_MAXBINS * 16 + LS_MAXR * 12 + 4 + sizeof(LsBlock);
-            ENSURE(c, c->ls_buf, rows * 28 + nblk * per_blk + over_cap * sizeof(LsOver) + 512);
+            // scratch: en (u64 per row), bin (u32 per row); per splitter slot: two splitter words, three words for each of
+            // its two ranges; per block: result, descriptor; per workgroup: its block; the batch's oversize ranges
+            ENSURE(c, c->ls_buf, rows * 12 + slots * 40 + nblk * (8 + sizeof(LsBlock)) + wgs * 4 + over_cap * sizeof(LsOver) + 512);
             u64 *p64 = c->ls_buf.as<u64>();
             LargeSplit ls{};
             ls.nblk = (u32)nblk;
-            ls.w = p64; ls.x = p64 + rows; ls.en = p64 + 2 * rows;
-            ls.spl_w = p64 + 3 * rows; ls.spl_x = ls.spl_w + nblk * LS_MAXBINS;
-            LsBlock *dblk = reinterpret_cast<LsBlock *>(ls.spl_x + nblk * LS_MAXBINS);
+            ls.en = p64;
+            ls.spl_w = p64 + rows; ls.spl_x = ls.spl_w + slots;
+            LsBlock *dblk = reinterpret_cast<LsBlock *>(ls.spl_x + slots);
             ls.blk = dblk;
             ls.over = reinterpret_cast<LsOver *>(dblk + nblk);
             ls.bin = reinterpret_cast<u32 *>(ls.over + over_cap);
-            ls.cnt = ls.bin + rows; ls.start = ls.cnt + nblk * LS_MAXR; ls.cur = ls.start + nblk * LS_MAXR;
-            ls.res = ls.cur + nblk * LS_MAXR;
-            ls.nover = ls.res + nblk;
+            ls.cnt = ls.bin + rows; ls.start = ls.cnt + 2 * slots; ls.cur = ls.start + 2 * slots;
+            ls.wgblk = ls.cur + 2 * slots;
+            ls.piv = ls.wgblk + wgs;
+            ls.res = ls.piv + nblk;
+            ls.nover = ls.res + nblk;                               // (read back together with res)
             HIPCHK(c, hipMemcpyAsync(dblk, desc.data(), nblk * sizeof(LsBlock), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemsetAsync(ls.nover, 0, 4, c->stream));
-            k_ls_windows<<<(u32)wgs, 256, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
-            k_ls_splitters<<<(u32)nblk, 1024, 0, c->stream>>>(ls);
-            k_ls_bin<<<(u32)wgs, 256, 0, c->stream>>>(ls);
-            k_ls_plan<<<(u32)nblk, LS_MAXBINS, 0, c->stream>>>(ls, sub);
+            if (small_ns) k_ls_splitters<256, 256><<<(u32)nblk, 256, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
+            if (big_ns) k_ls_splitters<LS_SAMPLES, 1024><<<(u32)nblk, 1024, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
+            k_ls_bin<<<(u32)wgs, 256, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
+            if (small_nb) k_ls_plan<64><<<(u32)nblk, 64, 0, c->stream>>>(ls, sub);
+            if (big_nb) k_ls_plan<LS_MAXBINS><<<(u32)nblk, LS_MAXBINS, 0, c->stream>>>(ls, sub);
             k_ls_scatter<<<(u32)wgs, 256, 0, c->stream>>>(c->blue.as<u64>(), ls);
             res.resize(nblk + 1);
             HIPCHK(c, hipMemcpyAsync(res.data(), ls.res, (nblk + 1) * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1415,6 +1427,7 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
                 if (res[i]) { const Work &wk = work[w0 + i]; if ((rc = bitonic_large(c, wk.b0, wk.m, wk.j0))) return rc; }
             for (const LsOver &o : over) {
                 const Work &wk = work[w0 + o.blk];
+                if (o.ties) { tr_tie_n++; tr_tie_rows += o.cnt; }
                 // a range of ties shares o.adv more pairs of windows (1 after a window round); one that is most of
                 // its block is a stretch that keeps tying: pivot round next.  After a pivot round a range of ties is
                 // smaller than its block (the pivot row itself is not in it), so the rounds end.
@@ -1423,16 +1436,18 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
                 const u32 pivot = (o.ties && (u64)o.cnt * 4 > wk.m && (!wk.pivot || o.adv >= 1) && !(c->cfg.reserved & 8192)) ? 1u : 0u;
                 if (o.ties && (o.adv || wk.pivot) && deeper < c->S + 2 * SP_WIN && o.cnt < wk.m + (wk.pivot ? 0u : 1u))
                     next.push_back(Work{wk.b0 + o.st, wk.j0 + o.st, o.cnt, wk.depth + o.adv, pivot});
-                else if (!o.ties && o.cnt < wk.m) next.push_back(Work{wk.b0 + o.st, wk.j0 + o.st, o.cnt, wk.depth, wk.pivot});
-                else if ((rc = bitonic_large(c, wk.b0 + o.st, o.cnt, wk.j0 + o.st))) return rc;
+                else if (!o.ties && o.cnt < wk.m) next.push_back(Work{wk.b0 + o.st, wk.j0 + o.st, o.cnt, wk.depth + o.adv, wk.pivot});
+                else { tr_net++; if ((rc = bitonic_large(c, wk.b0 + o.st, o.cnt, wk.j0 + o.st))) return rc; }
             }
             w0 = w1;
         }
-        if (getenv("DEBWT_TRACE_LARGE")) {
+        if (trace) {
             u32 dmax = 0; u64 rows = 0;
             for (const Work &wk : next) { dmax = std::max(dmax, wk.depth); rows += wk.m; }
-            fprintf(stderr, "large blocks: round %u of %zu blocks -> %zu ranges to split again (%llu rows, deepest %u)\n",
-                    round, work.size(), next.size(), (unsigned long long)rows, dmax);
+            fprintf(stderr, "large blocks: round %u of %zu blocks (%llu rows, %llu pivot rounds) -> %zu ranges to split again (%llu rows, deepest %u; "
+                            "ranges of ties: %llu with %llu rows; to the network: %llu)\n",
+                    round, work.size(), (unsigned long long)tr_rows, (unsigned long long)tr_piv, next.size(), (unsigned long long)rows, dmax,
+                    (unsigned long long)tr_tie_n, (unsigned long long)tr_tie_rows, (unsigned long long)tr_net);
         }
         work.swap(next);
         round++;

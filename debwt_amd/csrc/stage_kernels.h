@@ -1567,9 +1567,11 @@ static_assert(LS_QUEUE_CAP <= BLUE_WAVE_CAP, "the queue is drained by the kernel
 #endif
 #define LS_MAXBINS 1024                // splitters + 1
 #define LS_MAXR (2 * LS_MAXBINS)       // ranges: below splitter 0, equal to it, between 0 and 1, equal to 1, ...
-struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0, depth, pivot; };  // row0: first scratch row; wg0: first 256-row
-                                                                        // workgroup; depth: window pairs already equal;
-                                                                        // pivot: 1 = keys of a pivot round (k_ls_windows)
+#define LS_WG_ROWS 1024u               // rows of ONE block a workgroup of the row kernels takes (four per thread)
+struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0, t0, depth, pivot; };  // row0: first scratch row; wg0: first workgroup of
+                                                                        // LS_WG_ROWS rows; t0: first splitter slot (ranges
+                                                                        // from 2 t0); depth: window pairs already equal;
+                                                                        // pivot: 1 = keys of a pivot round (ls_row_key)
 struct LsOver { u32 blk, st, cnt, ties, adv; };                         // a range above BLUE_LDS_CAP rows: block of the
                                                                         // batch, first row, rows, 1 = rows tie with a
                                                                         // splitter, window pairs they are known to share
@@ -1586,30 +1588,24 @@ __device__ __forceinline__ u32 ls_pivot_adv(u64 key) {
 }
 struct LargeSplit {
     const LsBlock *blk; u32 nblk;
-    u64 *w, *x, *en;                  // per row: first two windows, entry (copy)
+    u32 *wgblk;                       // per workgroup of the row kernels: its block (written by k_ls_splitters)
+    u64 *en;                          // per row: entry (copy)
     u32 *bin;                         // per row: its range
-    u64 *spl_w, *spl_x;               // per block: LS_MAXBINS splitters
-    u32 *cnt, *start, *cur;           // per block: LS_MAXR ranges
+    u64 *spl_w, *spl_x;               // per block: nb splitter slots from t0
+    u32 *cnt, *start, *cur;           // per block: 2 nb ranges from 2 t0
     u32 *res;                         // per block: 1 = sub-block table full (nothing queued, nothing moved)
-    LsOver *over; u32 *nover;         // oversize ranges of the batch (at most rows / BLUE_LDS_CAP of them), their number
+    u32 *piv;                         // per block of a pivot round: its pivot row (chosen by k_ls_splitters)
+    LsOver *over; u32 *nover;         // oversize ranges of the batch (at most rows / LS_QUEUE_CAP of them), their number
 };
-__device__ __forceinline__ u32 ls_block_of(const LargeSplit &ls, u32 wg) {
-    u32 lo = 0, hi = ls.nblk;                                // last block whose first workgroup is <= wg
-    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (ls.blk[mid].wg0 <= wg) lo = mid; else hi = mid; }
-    return lo;
-}
-__global__ __launch_bounds__(256) void k_ls_windows(const u64 *__restrict__ blue, const u64 *__restrict__ spn, u64 S, LargeSplit ls) {
-    const u32 bi = ls_block_of(ls, blockIdx.x);
-    const LsBlock B = ls.blk[bi];
-    const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
-    if (i >= B.m) return;
-    const u64 e = blue[B.b0 + i];
+// The key a round sorts row `i` of block B by: its next pair of SP windows (window round), or how far it follows the
+// block's pivot row `piv` (pivot round; second word 0).  e = the row's blue entry.
+__device__ __forceinline__ void ls_row_key(const u64 *__restrict__ blue, const u64 *__restrict__ spn, u64 S, const LsBlock &B, u32 piv, u32 i,
+                                           u64 e, u64 *kw, u64 *kx) {
     const u64 pos = (e >> 4) + (u64)B.depth * (2 * SP_WIN);
-    ls.en[B.row0 + i] = e;
     if (B.pivot) {
-        const u64 ppos = (blue[B.b0 + (B.m >> 1)] >> 4) + (u64)B.depth * (2 * SP_WIN);
+        const u64 ppos = (blue[B.b0 + piv] >> 4) + (u64)B.depth * (2 * SP_WIN);
         u64 key = LS_TCAP;                                   // equal to the pivot for as long as we look
-        for (u32 t = 0; t < LS_TCAP && i != (B.m >> 1); t++) {
+        for (u32 t = 0; t < LS_TCAP && i != piv; t++) {
             const u64 a = pos + (u64)t * (2 * SP_WIN), b = ppos + (u64)t * (2 * SP_WIN);
             const bool la = a < S, lb = b < S;
             if (!la && !lb) break;                           // both behind the end: zeros from here on
@@ -1620,27 +1616,73 @@ __global__ __launch_bounds__(256) void k_ls_windows(const u64 *__restrict__ blue
                 break;
             }
         }
-        ls.w[B.row0 + i] = key;
-        ls.x[B.row0 + i] = 0ull;
+        *kw = key; *kx = 0ull;
         return;
     }
     const bool live = pos < S;
-    ls.w[B.row0 + i] = live ? sp_window(spn, pos) : 0ull;
-    ls.x[B.row0 + i] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
+    *kw = live ? sp_window(spn, pos) : 0ull;
+    *kx = live ? sp_window(spn, pos + SP_WIN) : 0ull;
 }
-__global__ __launch_bounds__(1024) void k_ls_splitters(LargeSplit ls) {
-    __shared__ u64 sw[LS_SAMPLES], sx[LS_SAMPLES];
+// One workgroup per block: the keys of `ns` evenly spaced rows are fetched and sorted, nb - 1 of them become the block's
+// splitters; the block's range counters are cleared and its workgroups of the row kernels are given its index.  NS:
+// the sample capacity of the instance (LDS); a block whose samples belong to the other instance is skipped -- most large
+// blocks are a few thousand rows with 64 samples, and 64 KB of LDS per workgroup for those leaves two workgroups per CU.
+template <u32 NS, u32 T>
+__global__ __launch_bounds__(T) void k_ls_splitters(const u64 *__restrict__ blue, const u64 *__restrict__ spn, u64 S, LargeSplit ls) {
+    __shared__ u64 sw[NS], sx[NS];
+    __shared__ u32 s_cand, s_tmax, s_cnt, s_next;
     const LsBlock B = ls.blk[blockIdx.x];
     const u32 tid = threadIdx.x, ns = B.ns;
-    for (u32 i = tid; i < ns; i += 1024) {
-        const u64 r = B.row0 + ((u64)i * B.m) / ns;
-        sw[i] = ls.w[r]; sx[i] = ls.x[r];
+    if ((NS < LS_SAMPLES) != (ns <= 256u)) return;
+    u32 piv = B.m >> 1;
+    if (B.pivot) {
+        // The pivot of a pivot round: a row that follows the block's periodic stretch for LONG.  The rows that outlast the
+        // pivot all leave with the pivot's own t, in one range that needs another round; the rows the pivot outlasts leave
+        // with their own t and are done -- so a pivot at the median run length halves the stretch per round (the middle
+        // row: 4-5 rounds for the ~7,700 rows of an average tie range of distribution R at 30 Gbp), one near the maximum
+        // finishes it in a round or two.  64 evenly spaced rows are measured against the candidate; when two or more of them share
+        // the largest t they (in all likelihood) outlast it and the first of them becomes the candidate -- each step halves
+        // the rows that still outlast; three steps leave an eighth (every step walks the stretch once more: more steps cost a
+        // 7 Mbp collection of nothing but runs and tandem repeats more than they save it).  Any row is a valid pivot: this only picks.
+        if (tid == 0) s_cand = piv;
+        __syncthreads();
+        for (int it = 0; it < 3; it++) {
+            if (tid == 0) { s_tmax = 0; s_cnt = 0; s_next = ~0u; }
+            __syncthreads();
+            const u32 cand = s_cand;
+            u32 r = 0, t = 0;
+            bool mine = false;
+            if (tid < 64u) {
+                r = (u32)(((u64)tid * B.m) >> 6);
+                if (r != cand) {
+                    u64 kw, kx;
+                    ls_row_key(blue, spn, S, B, cand, r, blue[B.b0 + r], &kw, &kx);
+                    t = ls_pivot_adv(kw);
+                    mine = true;
+                    atomicMax(&s_tmax, t);
+                }
+            }
+            __syncthreads();
+            if (mine && t == s_tmax) { atomicAdd(&s_cnt, 1u); atomicMin(&s_next, r); }
+            __syncthreads();
+            if (s_cnt < 2u) break;                           // (uniform: read behind a barrier, reset behind the next)
+            if (tid == 0) s_cand = s_next;
+            __syncthreads();
+        }
+        piv = s_cand;
+        if (tid == 0) ls.piv[blockIdx.x] = piv;
     }
-    for (u32 i = tid; i < LS_MAXR; i += 1024) { ls.cnt[blockIdx.x * LS_MAXR + i] = 0; ls.cur[blockIdx.x * LS_MAXR + i] = 0; }
+    for (u32 i = tid; i < ns; i += T) {
+        const u32 r = (u32)(((u64)i * B.m) / ns);
+        ls_row_key(blue, spn, S, B, piv, r, blue[B.b0 + r], &sw[i], &sx[i]);
+    }
+    for (u32 i = tid; i < 2 * B.nb; i += T) { ls.cnt[2 * (size_t)B.t0 + i] = 0; ls.cur[2 * (size_t)B.t0 + i] = 0; }
+    const u32 nwg = (B.m + LS_WG_ROWS - 1) / LS_WG_ROWS;
+    for (u32 i = tid; i < nwg; i += T) ls.wgblk[B.wg0 + i] = blockIdx.x;
     __syncthreads();
     for (u32 kk = 2; kk <= ns; kk <<= 1)
         for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
-            for (u32 t = tid; t < ns / 2; t += 1024) {
+            for (u32 t = tid; t < ns / 2; t += T) {
                 const u32 i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), l = i | jj;
                 const u64 wi = sw[i], wl = sw[l], xi = sx[i], xl = sx[l];
                 const bool l_less = wl != wi ? wl < wi : xl < xi;
@@ -1650,53 +1692,75 @@ __global__ __launch_bounds__(1024) void k_ls_splitters(LargeSplit ls) {
             __syncthreads();
         }
     // splitter b = sorted sample (b + 1) * ns / nb - 1, b < nb - 1
-    for (u32 b = tid; b + 1 < B.nb; b += 1024) {
+    for (u32 b = tid; b + 1 < B.nb; b += T) {
         const u32 i = (b + 1) * (ns / B.nb) - 1;
-        ls.spl_w[blockIdx.x * LS_MAXBINS + b] = sw[i]; ls.spl_x[blockIdx.x * LS_MAXBINS + b] = sx[i];
+        ls.spl_w[(size_t)B.t0 + b] = sw[i]; ls.spl_x[(size_t)B.t0 + b] = sx[i];
     }
 }
-// A workgroup takes 256 consecutive rows of one block.  The rows' ranges are counted in LDS first and the global range
-// counters receive one atomic per range and workgroup (issued by different threads, not one after the other): rows of a
-// low-complexity block crowd into a handful of ranges, and one device-scope atomic per row serialises on them.
-__global__ __launch_bounds__(256) void k_ls_bin(LargeSplit ls) {
+// A workgroup takes LS_WG_ROWS consecutive rows of one block, four per thread: their keys are fetched (the gathers of a
+// thread's four rows are in flight together), every row finds its range by bisection over the block's splitters, staged in
+// LDS -- below a splitter, or equal to it: the rows that tie with a splitter form a range of their own.  The rows' ranges
+// are counted in LDS first and the global range counters receive one atomic per range and workgroup (issued by different
+// threads, not one after the other): rows of a low-complexity block crowd into a handful of ranges, and one device-scope
+// atomic per row serialises on them.  (Round 5: this kernel was two -- windows to HBM, then the bisection over splitters
+// in global memory by workgroups of 256 rows that found their block by a binary search over the batch's blocks: 17 + ~8
+// dependent loads in front of every 256 rows' work, 233 ms per 30 Gbp build of distribution R.)
+__global__ __launch_bounds__(256) void k_ls_bin(const u64 *__restrict__ blue, const u64 *__restrict__ spn, u64 S, LargeSplit ls) {
+    __shared__ u64 spw[LS_MAXBINS], spx[LS_MAXBINS];
     __shared__ u32 h[LS_MAXR];
-    const u32 bi = ls_block_of(ls, blockIdx.x);
+    const u32 bi = ls.wgblk[blockIdx.x];
     const LsBlock B = ls.blk[bi];
-    const u32 nr = 2 * B.nb;
-    for (u32 r = threadIdx.x; r < nr; r += 256) h[r] = 0;
+    const u32 nr = 2 * B.nb, tid = threadIdx.x;
+    for (u32 r = tid; r < nr; r += 256) h[r] = 0;
+    for (u32 b = tid; b + 1 < B.nb; b += 256) { spw[b] = ls.spl_w[(size_t)B.t0 + b]; spx[b] = ls.spl_x[(size_t)B.t0 + b]; }
+    const u32 i0 = (blockIdx.x - B.wg0) * LS_WG_ROWS + tid;
+    const u32 piv = B.pivot ? ls.piv[bi] : 0u;
+    u64 e[4], w[4], x[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[j] = i0 + j * 256u < B.m ? blue[B.b0 + i0 + j * 256u] : 0ull;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        w[j] = x[j] = 0ull;
+        if (i0 + j * 256u < B.m) ls_row_key(blue, spn, S, B, piv, i0 + j * 256u, e[j], &w[j], &x[j]);
+    }
     __syncthreads();
-    const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
-    if (i < B.m) {
-        const u64 w = ls.w[B.row0 + i], x = ls.x[B.row0 + i];
-        const u64 *spw = ls.spl_w + (size_t)bi * LS_MAXBINS, *spx = ls.spl_x + (size_t)bi * LS_MAXBINS;
-        u32 lo = 0, hi = B.nb - 1;                           // number of splitters below the row's windows
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const u32 i = i0 + j * 256u;
+        if (i >= B.m) continue;
+        u32 lo = 0, hi = B.nb - 1;                           // number of splitters below the row's key
         while (lo < hi) {
             const u32 mid = (lo + hi) >> 1;
             const u64 sw = spw[mid], sx = spx[mid];
-            if (sw != w ? sw < w : sx < x) lo = mid + 1; else hi = mid;
+            if (sw != w[j] ? sw < w[j] : sx < x[j]) lo = mid + 1; else hi = mid;
         }
-        const bool tie = lo + 1 < B.nb && spw[lo] == w && spx[lo] == x;
+        const bool tie = lo + 1 < B.nb && spw[lo] == w[j] && spx[lo] == x[j];
         const u32 r = 2 * lo + (tie ? 1u : 0u);
         ls.bin[B.row0 + i] = r;
+        ls.en[B.row0 + i] = e[j];
         atomicAdd(&h[r], 1u);
     }
     __syncthreads();
-    for (u32 r = threadIdx.x; r < nr; r += 256)
-        if (h[r]) atomicAdd(&ls.cnt[(size_t)bi * LS_MAXR + r], h[r]);
+    for (u32 r = tid; r < nr; r += 256)
+        if (h[r]) atomicAdd(&ls.cnt[2 * (size_t)B.t0 + r], h[r]);
 }
-// one workgroup per block: range starts; ranges of <= BLUE_LDS_CAP rows become sub-blocks, larger ones are reported
-__global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub sub) {
-    __shared__ u32 part[LS_MAXBINS];
+// one workgroup per block: range starts; ranges of <= LS_QUEUE_CAP rows become sub-blocks, larger ones are reported.  NB:
+// the splitter capacity of the instance (threads; two ranges per thread); blocks of the other instance are skipped.
+template <u32 NB>
+__global__ __launch_bounds__(NB) void k_ls_plan(LargeSplit ls, BlueSub sub) {
+    __shared__ u32 part[NB];
     __shared__ u32 nsub, base, full;
     const LsBlock B = ls.blk[blockIdx.x];
+    if ((NB < LS_MAXBINS) != (B.nb <= 64u)) return;
     const u32 tid = threadIdx.x;
     const u32 nr = 2 * B.nb;
+    const size_t r0 = 2 * (size_t)B.t0;
     u32 c[2];
-    for (int h = 0; h < 2; h++) c[h] = 2 * tid + h < nr ? ls.cnt[blockIdx.x * LS_MAXR + 2 * tid + h] : 0u;
+    for (int h = 0; h < 2; h++) c[h] = 2 * tid + h < nr ? ls.cnt[r0 + 2 * tid + h] : 0u;
     part[tid] = c[0] + c[1];
     if (tid == 0) { nsub = 0; full = 0; }
     __syncthreads();
-    for (u32 d = 1; d < LS_MAXBINS; d <<= 1) {
+    for (u32 d = 1; d < NB; d <<= 1) {
         const u32 v = tid >= d ? part[tid - d] : 0u;
         __syncthreads();
         part[tid] += v;
@@ -1706,7 +1770,7 @@ __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub s
     st[0] = part[tid] - c[0] - c[1]; st[1] = st[0] + c[0];
     u32 my[2] = {0, 0};
     for (int h = 0; h < 2; h++) {
-        if (2 * tid + h < nr) ls.start[blockIdx.x * LS_MAXR + 2 * tid + h] = st[h];
+        if (2 * tid + h < nr) ls.start[r0 + 2 * tid + h] = st[h];
         if (c[h] >= 1 && c[h] <= LS_QUEUE_CAP) my[h] = atomicAdd(&nsub, 1u);
     }
     __syncthreads();
@@ -1719,36 +1783,58 @@ __global__ __launch_bounds__(LS_MAXBINS) void k_ls_plan(LargeSplit ls, BlueSub s
     // pairs of windows the rows of the tie range (h = 1) share beyond B.depth: those of a pivot round the pairs their
     // key counts, those of a window round the pair just compared (the host checks that a deeper pair exists; a
     // sub-block starts conservatively at B.depth there, as before)
-    const u32 adv_tie = B.pivot ? (tid + 1 < B.nb ? ls_pivot_adv(ls.spl_w[(size_t)blockIdx.x * LS_MAXBINS + tid]) : 0u) : 1u;
+    const u32 adv_tie = B.pivot ? (tid + 1 < B.nb ? ls_pivot_adv(ls.spl_w[(size_t)B.t0 + tid]) : 0u) : 1u;
+    // ... and the rows of a range BETWEEN two splitters of a pivot round (h = 0): keys k with lower < k < upper.  Below the
+    // pivot (upper <= TCAP) k is the row's t, so every row follows the pivot -- and hence every other row of the range --
+    // for more than `lower` pairs; above it (lower >= TCAP) k = 2 TCAP - t, so for more than 2 TCAP - upper.  Without this
+    // the rows of a homopolymer block that left the pivot after 90..100 pairs were queued at the block's depth and the
+    // LDS kernels walked those 90 pairs again, a round per pair.
+    u32 adv_btw = 0;
+    if (B.pivot) {
+        const bool has_lo = tid >= 1, has_up = tid + 1 < B.nb;
+        const u64 lower = has_lo ? ls.spl_w[(size_t)B.t0 + tid - 1] : 0ull, upper = has_up ? ls.spl_w[(size_t)B.t0 + tid] : 0ull;
+        if (has_up && upper <= LS_TCAP) adv_btw = has_lo ? (u32)lower + 1u : 0u;
+        else if (has_lo && lower >= LS_TCAP) adv_btw = has_up ? (u32)(2 * LS_TCAP - upper) + 1u : 0u;
+    }
     for (int h = 0; h < 2; h++) {
+        const u32 adv = B.pivot ? (h ? adv_tie : adv_btw) : 0u;
         if (c[h] >= 1 && c[h] <= LS_QUEUE_CAP && !full) {
             const u32 e = base + my[h];
             sub.start[e] = B.b0 + st[h]; sub.freq[e] = c[h]; sub.j0[e] = B.j0 + st[h];
-            sub.depth[e] = B.depth + (h && B.pivot ? adv_tie : 0u);
+            sub.depth[e] = B.depth + adv;
         }
         if (c[h] > LS_QUEUE_CAP && !full)                                    // h = 1: a range of ties
-            ls.over[atomicAdd(ls.nover, 1u)] = LsOver{blockIdx.x, st[h], c[h], (u32)h, h ? adv_tie : 0u};
+            ls.over[atomicAdd(ls.nover, 1u)] = LsOver{blockIdx.x, st[h], c[h], (u32)h, h ? adv_tie : adv_btw};
     }
 }
 __global__ __launch_bounds__(256) void k_ls_scatter(u64 *__restrict__ blue, LargeSplit ls) {
     __shared__ u32 h[LS_MAXR];                               // rows of the workgroup per range, then their first slot
-    const u32 bi = ls_block_of(ls, blockIdx.x);
+    const u32 bi = ls.wgblk[blockIdx.x];
     const LsBlock B = ls.blk[bi];
     if (ls.res[bi]) return;                                  // nothing was queued: the rows stay for the network
-    const u32 nr = 2 * B.nb;
-    for (u32 r = threadIdx.x; r < nr; r += 256) h[r] = 0;
+    const u32 nr = 2 * B.nb, tid = threadIdx.x;
+    const size_t r0 = 2 * (size_t)B.t0;
+    for (u32 r = tid; r < nr; r += 256) h[r] = 0;
     __syncthreads();
-    const u32 i = (blockIdx.x - B.wg0) * 256u + threadIdx.x;
-    const bool valid = i < B.m;
-    const u32 b = valid ? ls.bin[B.row0 + i] : 0u;
-    const u32 mine = valid ? atomicAdd(&h[b], 1u) : 0u;      // rank among the workgroup's rows of the range
-    __syncthreads();
-    for (u32 r = threadIdx.x; r < nr; r += 256) {
-        const u32 c = h[r];
-        if (c) h[r] = ls.start[bi * LS_MAXR + r] + atomicAdd(&ls.cur[(size_t)bi * LS_MAXR + r], c);
+    const u32 i0 = (blockIdx.x - B.wg0) * LS_WG_ROWS + tid;
+    u32 b[4], mine[4];
+    u64 e[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool valid = i0 + j * 256u < B.m;
+        b[j] = valid ? ls.bin[B.row0 + i0 + j * 256u] : 0u;
+        e[j] = valid ? ls.en[B.row0 + i0 + j * 256u] : 0ull;
+        mine[j] = valid ? atomicAdd(&h[b[j]], 1u) : 0u;      // rank among the workgroup's rows of the range
     }
     __syncthreads();
-    if (valid) blue[B.b0 + h[b] + mine] = ls.en[B.row0 + i];
+    for (u32 r = tid; r < nr; r += 256) {
+        const u32 c = h[r];
+        if (c) h[r] = ls.start[r0 + r] + atomicAdd(&ls.cur[r0 + r], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (i0 + j * 256u < B.m) blue[B.b0 + h[b[j]] + mine[j]] = e[j];
 }
 
 // descriptors of the large blocks (context-wide block ids in large_q) in one gather
