@@ -110,6 +110,16 @@ class Synth:
 
     @classmethod
     def named(cls, name, seed=None, threads=None):
+        if name not in WORKLOADS:
+            # pan<G>x<L>[M|G] / real<G>x<L>[M|G]: G genomes of L bases in 24 records each, distribution P or R at the
+            # densities of the named 3 Gbp workloads (an Alu-like copy per 3,000 bases, 3 % low-complexity tracts)
+            import re
+            mt = re.fullmatch(r"(pan|real)(\d+)x(\d+(?:\.\d+)?)([MG])", name)
+            if not mt:
+                raise KeyError(f"unknown workload {name!r}")
+            gl = int(float(mt.group(3)) * (1_000_000 if mt.group(4) == "M" else 1_000_000_000))
+            extra = {"lowcx_fraction": 0.03, "alu_copies": gl // 3000} if mt.group(1) == "real" else {}
+            WORKLOADS[name] = (gl, int(mt.group(2)), 24, extra)
         gl, g, c, extra = WORKLOADS[name]
         kw = dict(extra)
         if seed is not None:

@@ -68,18 +68,24 @@ def main():
     for N in [int(x) for x in args.shards.split(",")]:
         for mode in args.modes.split(","):
             m = api.MultiDeBWT([0] * N, k=args.k, tune=args.tune)
-            m.set_serial(True)
-            m.set_key_mode(mode)
-            if args.range_cap:
-                for r in range(N):
-                    rc = m._L.debwt_set_range_cap(m._shard_ctx(r), args.range_cap)
-                    assert rc == 0
-            m.load_packed(text.a, n, sep)
-            m.build()
-            m.build()
-            ok = m.verify_device()["ok"]
-            reps = [m.shard_report(r) for r in range(N)]
-            ms, _ = m.stats()
+            try:
+                m.set_serial(True)
+                m.set_key_mode(mode)
+                if args.range_cap:
+                    for r in range(N):
+                        rc = m._L.debwt_set_range_cap(m._shard_ctx(r), args.range_cap)
+                        assert rc == 0
+                m.load_packed(text.a, n, sep)
+                m.build()
+                m.build()
+                ok = m.verify_device()["ok"]
+                reps = [m.shard_report(r) for r in range(N)]
+                ms, _ = m.stats()
+            except api.DebwtError as e:
+                print(f"\n## N = {N}, keys: {mode}: {e} -- the {N} shards of this collection do not fit next to each other in ONE GPU's HBM "
+                      f"(on a node every shard has a GPU of its own)")
+                m.close()
+                continue
             m.close()
             if jf:
                 jf.write(json.dumps({"workload": args.workload, "n": n, "N": N, "mode": mode, "inverse_bwt_ok": bool(ok), "shards": reps}) + "\n")
