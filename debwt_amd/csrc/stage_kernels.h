@@ -671,6 +671,10 @@ struct SpBlockIds {
 #ifndef SP_FLAGS_WAVES
 #define SP_FLAGS_WAVES 4
 #endif
+#ifndef SP_PROBE_BATCH
+#define SP_PROBE_BATCH 2               // home slots of the node table requested per lane before the first is used (measured at 30 Gbp,
+                                       // SP stage: 1 -> 424.4 ms, 2 -> 405.0, 4 -> 412.9, 8 -> 410.8; profiles/r05_experiments.txt)
+#endif
 template <int MZ>
 __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_FLAGS_WAVES))) void k_sp_flags(const u64 *__restrict__ text, const u64 *__restrict__ sepbits,
                                                            u64 n, int K, const HSlot *__restrict__ htab, int hbits,
@@ -783,6 +787,52 @@ __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_
             }
         }
     }
+#if SP_PROBE_BATCH > 1
+    // The candidates' home slots are requested SP_PROBE_BATCH at a time before the first answer is looked at: a lane that
+    // walks its ~7 candidates one round trip after the other keeps one line in flight, and with four waves per SIMD the
+    // chip then holds 2.6e5 requests -- what the memory system needs to deliver its 51 G random lines per second
+    // (scripts/micro/random_lines.hip) only if no lane ever computes or idles behind a longer lane of its wave.
+    while (cand) {
+        u32 tt[SP_PROBE_BATCH], hh[SP_PROBE_BATCH];
+        u64 nd[SP_PROBE_BATCH];
+        ulonglong2 v[SP_PROBE_BATCH];
+        bool have[SP_PROBE_BATCH];
+#pragma unroll
+        for (int b = 0; b < SP_PROBE_BATCH; b++) {
+            have[b] = cand != 0u;
+            const u32 t = have[b] ? (u32)__ffs(cand) - 1u : 0u;
+            cand &= cand - 1u;                                  // 0 stays 0
+            tt[b] = t;
+            nd[b] = (t ? ((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) : w0) >> (64 - 2 * K);
+            hh[b] = red_hash(nd[b], hbits);
+        }
+#pragma unroll
+        for (int b = 0; b < SP_PROBE_BATCH; b++) {
+            v[b] = make_ulonglong2(0ull, 0ull);
+            if (have[b]) v[b] = *reinterpret_cast<const ulonglong2 *>(&htab[hh[b]]);
+        }
+#pragma unroll
+        for (int b = 0; b < SP_PROBE_BATCH; b++) {
+            if (!have[b] || v[b].x == 0ull) continue;           // no candidate / empty home slot: not a red node
+            u32 fl, q = 0;
+            if ((v[b].x >> 2) == nd[b]) { fl = (u32)(v[b].x & 3ull); q = (u32)(v[b].y >> 32); }
+            else {                                              // the home slot holds another node: on along the line
+                const u32 mask = (1u << hbits) - 1u;
+                u32 h = (hh[b] + 1u) & mask;
+                fl = 0;
+                for (;;) {
+                    const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(&htab[h]);
+                    if (x.x == 0ull) break;
+                    if ((x.x >> 2) == nd[b]) { fl = (u32)(x.x & 3ull); q = (u32)(x.y >> 32); break; }
+                    h = (h + 1u) & mask;
+                }
+            }
+            mo |= (fl & 1u) << tt[b];
+            mi |= ((fl >> 1) & 1u) << tt[b];
+            if (ids.list && (fl & 2u)) lq[threadIdx.x * 32 + tt[b]] = q;
+        }
+    }
+#else
     while (cand) {
         u32 t = (u32)__ffs(cand) - 1u;
         cand &= cand - 1u;
@@ -793,6 +843,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_
         mi |= ((fl >> 1) & 1u) << t;
         if (ids.list && (fl & 2u)) lq[threadIdx.x * 32 + t] = q;
     }
+#endif
     // special module: multi-out iff listed in specialBranch (src/generateSP.c:612-624).  Collections of many records --
     // a third of all positions of a read set are special, and millions of them branches -- carry the list as a bitmap over
     // the text positions (one word beside the text word instead of a binary search per special position)

@@ -153,8 +153,8 @@ def measure_link(device, mib_per_peer=1024, reps=2):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     best = float(t.item())
     per_peer = per * 8 / best / 1e9                                   # one direction, one peer pair
-    res = {"all_to_all_mib_per_peer": mib_per_peer, "seconds": round(best, 4), "gbytes_per_s_per_peer": round(per_peer, 2),
-           "gbytes_per_s_out_of_one_gpu": round(per_peer * (world - 1), 2), "content_ok": bool(ok),
+    res = {"all_to_all_mib_per_peer": mib_per_peer, "seconds": round(best, 4), "gbytes_per_s_per_peer": round(per_peer, 4),
+           "gbytes_per_s_out_of_one_gpu": round(per_peer * (world - 1), 4), "content_ok": bool(ok),
            "calls_of_at_most_bytes": P2P_MAX}
     # one message of 1.25 GiB per peer in ONE call (the exchanges never do this: they stay below P2P_MAX).  Opt-in
     # (DEBWT_BIG_MESSAGE_PROBE=1): a library that mishandles such a message must not be able to take a bench run down

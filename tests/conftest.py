@@ -67,3 +67,25 @@ def oracle():
     from oracle import oracle as O
     O.lib()
     return O
+
+
+def outside_domain_cases():
+    """Inputs the reference does not handle (it crashes or mis-orders on them; 'the build must not imitate the
+    failures'): a base missing from the whole collection, records of one symbol, short exact duplicates, so few branching
+    positions that the SP code is shorter than one 32-symbol word."""
+    rng = np.random.default_rng(4242)
+    ac = lambda m: rng.integers(0, 2, size=m).astype(np.uint8)                       # noqa: E731 -- only A and C
+    cases = {
+        "only_A_and_C": [ac(400), ac(333), ac(90)],
+        "only_G_and_T": [ac(257) + 2, ac(64) + 2],
+        "one_symbol_per_record": [np.full(40, 0, np.uint8), np.full(77, 3, np.uint8), np.full(33, 1, np.uint8), np.full(120, 0, np.uint8)],
+        "homopolymer_only_one_record": [np.full(500, 2, np.uint8)],
+        "three_identical_40_base_records": [rng.integers(0, 4, size=40).astype(np.uint8)] * 3,
+        "identical_records_of_34_bases_and_a_prefix_of_them": (lambda r: [r, r.copy(), r.copy(), np.concatenate([r, r[:7]])])(
+            rng.integers(0, 4, size=34).astype(np.uint8)),
+        "sp_code_shorter_than_32_symbols": [rng.integers(0, 4, size=60).astype(np.uint8)],   # a unique text: no branching node at all
+        "two_records_one_branch": (lambda r: [r, np.concatenate([r[:50], (r[50:51] + 1) % 4, rng.integers(0, 4, size=40).astype(np.uint8)])])(
+            rng.integers(0, 4, size=100).astype(np.uint8)),
+        "tandem_repeat_of_two_symbols": [np.tile(np.array([0, 3], np.uint8), 150), np.tile(np.array([0, 3], np.uint8), 40)],
+    }
+    return cases

@@ -6,7 +6,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import golden_id, golden_manifest, golden_outputs, golden_records
+from conftest import outside_domain_cases, golden_id, golden_manifest, golden_outputs, golden_records
 
 pytestmark = pytest.mark.gpu
 MANIFEST = golden_manifest()
@@ -973,3 +973,34 @@ def test_randomised_parity_sweep(api, oracle):
             w, h, dr = d.fetch()
             assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od, (c, kind, k, tune, cap, rep)
         d.close()
+
+
+@pytest.mark.parametrize("name", sorted(outside_domain_cases()))
+def test_inputs_outside_the_reference_domain_equal_the_definition(api, oracle, name, monkeypatch):
+    """outside the reference's valid domain (a base that never occurs, homopolymer-only records, short
+    exact duplicates, an SP code below 32 symbols) the reference itself crashes or mis-orders, so there is nothing of it
+    to be bit-exact with; the contract there is the BWT of r0#r1#...$ under A<C<G<T<#<$ BY DEFINITION (naive suffix sort,
+    orc_naive_bwt).  k = 12 and 32, one key range and ranges of 4096 instances, host and device special-region module."""
+    recs = outside_domain_cases()[name]
+    sym = oracle.sym_from_codes(recs)
+    want = oracle.naive_bwt(sym)
+    n = len(sym)
+    for k in (12, 32):
+        for cap in (0, 4096):
+            for device_special in (False, True):
+                if device_special:
+                    monkeypatch.setenv("DEBWT_SPECIAL_DEVICE_MIN", "0")
+                else:
+                    monkeypatch.delenv("DEBWT_SPECIAL_DEVICE_MIN", raising=False)
+                d = api.DeBWT(k=k)
+                if cap:
+                    d.set_range_cap(cap)
+                d.load_records(recs)
+                d.build()
+                w, h, dr = d.fetch()
+                st = d.stats()
+                d.close()
+                assert (st["special_path"] == 2) == device_special, (name, k, cap, st["special_path"])
+                got = oracle.unpack_bwt(w, n, h, dr)
+                assert np.array_equal(got, want), (name, k, cap, device_special)
+                assert len(h) == len(recs) - 1 and (len(h) < 2 or bool((np.diff(h.astype(np.int64)) > 0).all()))

@@ -5,7 +5,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import golden_id, golden_manifest, golden_outputs, golden_records
+from conftest import golden_id, golden_manifest, golden_outputs, golden_records, outside_domain_cases
 
 MANIFEST = golden_manifest()
 
@@ -160,3 +160,16 @@ def test_pack_text_layout(oracle):
     for j in range(n + 32):
         c = int(w[j >> 5] >> np.uint64(2 * (31 - (j & 31)))) & 3
         assert c == (int(sym[j]) if j < n and sym[j] < 4 else 3)
+
+
+@pytest.mark.parametrize("name", sorted(outside_domain_cases()))
+def test_oracle_equals_the_definition_outside_the_reference_domain(oracle, name):
+    """inputs the reference crashes or mis-orders on (a base that never occurs, homopolymer-only records, short
+    exact duplicates, an SP code below 32 symbols): the oracle -- the checker of the GPU path on exactly these inputs,
+    tests/test_gpu_parity.py -- gives the BWT by definition there, for k = 12, 20 and 32."""
+    recs = outside_domain_cases()[name]
+    sym = oracle.sym_from_codes(recs)
+    want = oracle.naive_bwt(sym)
+    for k in (12, 20, 32):
+        w, h, d, _ = oracle.build_bwt(sym, k)
+        assert np.array_equal(oracle.unpack_bwt(w, len(sym), h, d), want), (name, k)

@@ -83,11 +83,13 @@ WORKER = textwrap.dedent("""
 @pytest.mark.parametrize("mode", ["scan", "exchange", "rescan", "auto"])
 @pytest.mark.parametrize("world,case,k,cap", [(2, "pan", 32, 0), (3, "pan", 20, 0), (2, "many", 32, 0), (4, "chrom", 32, 0),
                                               (2, "pan", 32, 100_000), (3, "chrom", 24, 150_000), (4, "many", 32, 8192),
-                                              (3, "reads", 32, 0), (2, "reads", 20, 50_000)])
+                                              (3, "reads", 32, 0), (2, "reads", 20, 50_000),
+                                              (5, "chrom", 32, 0)])          # the most ranks the GPU box lets share its card
+                                                                             # (6 processes incl. this one); 8: CPU, test_dist_cpu.py
 def test_sharded_build_equals_oracle(tmp_path, oracle, world, case, k, mode, cap):
     from debwt_amd import synth
-    if case == "reads" and mode in ("scan", "auto"):
-        pytest.skip("the many-record collection runs in the two key modes only (suite time)")
+    if (case == "reads" or world == 5) and mode in ("scan", "auto"):
+        pytest.skip("the many-record collection and the 5-rank case run in the two key modes only (suite time)")
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / "res.npz")
