@@ -8,6 +8,7 @@
 // Layout, alphabet and checks are the reference's: A0 C1 G2 T3 either case (src/main.c:18-23), 'T' at every
 // separator and 32 'T' behind the end (src/collect#$.c:78-90), every record longer than 32 bases (:41-45).
 #include "fasta_host.h"
+#include "gz_parallel.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -488,12 +489,19 @@ int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, s
     if (pread(fd, magic, 2, 0) != 2) { close(fd); return fail(err, errlen, "unreadable input"); }
     int rc;
     if (magic[0] == 0x1f && magic[1] == 0x8b) {
-        {   // block gzip first: its members inflate in parallel
+        {   // block gzip first: its members inflate in parallel; then a one-member stream in pieces (gz_parallel.cpp)
             void *zm = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (zm != MAP_FAILED) {
                 char *buf = nullptr;
                 size_t len = 0;
-                const int br = inflate_bgzf((const unsigned char *)zm, (size_t)st.st_size, threads, &buf, &len);
+                int br = inflate_bgzf((const unsigned char *)zm, (size_t)st.st_size, threads, &buf, &len);
+                if (br == 1 && !getenv("DEBWT_GZ_SERIAL")) {
+                    br = inflate_gzip_parallel((const unsigned char *)zm, (size_t)st.st_size, threads, &buf, &len) == 0 ? 0 : 1;
+                    if (br == 1 && getenv("DEBWT_GZ_REQUIRE_PARALLEL")) {            // tests: no silent serial fall-back
+                        munmap(zm, (size_t)st.st_size); close(fd);
+                        return fail(err, errlen, "the parallel gzip path declined the file");
+                    }
+                }
                 munmap(zm, (size_t)st.st_size);
                 if (br < 0) { close(fd); return fail(err, errlen, "gzip stream is damaged"); }
                 if (br == 0) {
@@ -507,7 +515,7 @@ int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, s
                 }
             }
         }
-        // a plain gzip stream (one member): inflate is serial; the parse behind it is not
+        // what is left (several plain members, not text, tiny, one thread): serial inflate; the parse behind it is not
         close(fd);
         gzFile f = gzopen(path, "rb");
         if (!f) return fail(err, errlen, "can not open ref file");
@@ -526,6 +534,11 @@ int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, s
             if (r < 0) { free(buf); gzclose(f); return fail(err, errlen, "gzip stream is damaged"); }
             if (r == 0) break;
             len += (size_t)r;
+        }
+        {   // a stream that ends before its end (gzread hands out what it has and says so only here)
+            int zerr = Z_OK;
+            (void)gzerror(f, &zerr);
+            if (zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR) { free(buf); gzclose(f); return fail(err, errlen, "gzip stream is cut short or damaged"); }
         }
         gzclose(f);
         out->seconds_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

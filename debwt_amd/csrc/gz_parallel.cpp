@@ -1,0 +1,485 @@
+// gz_parallel.cpp -- a ONE-MEMBER gzip file inflated by all host threads (the reference reads gzip through
+// zlib's gzread on one thread, src/collect#$.c:26,34-37 / src/kseq.h).
+//
+// A deflate stream cannot be entered in the middle for two reasons: block boundaries are not marked (they fall on any
+// bit), and a block may copy from the 32 KB of output before it.  Both are dealt with the way pugz / rapidgzip do:
+//   1. the compressed bytes are cut into chunks; for every chunk but the first a block start is FOUND by trial: at each
+//      bit offset a block header is parsed (stored: LEN / NLEN complement; dynamic: the code-length codes must describe
+//      complete, not over-subscribed Huffman codes with an end-of-block symbol) and the block plus the header of the one
+//      behind it decoded with the demand that every literal is text -- FASTA and FASTQ are;
+//   2. a chunk is decoded from its block start with an UNKNOWN window: a small decoder of our own (RFC 1951, canonical
+//      codes decoded the counting way) writes 16-bit symbols, where a copy that reaches into the unknown window leaves a
+//      marker (which window byte) instead of a byte.  DNA text compresses by its Huffman codes, not by long copies, so
+//      after a few blocks the last 32 KB of output hold no marker: from the next block boundary on zlib's own inflate
+//      continues (raw deflate, that 32 KB as dictionary, inflatePrime for the bits before the first whole byte -- the
+//      random-access recipe of zlib's examples/zran.c) up to the bit where the next chunk starts, which must be one of
+//      the block boundaries it stops at (Z_BLOCK);
+//   3. the chunks' marker prefixes are resolved in order with the 32 KB before them (a few hundred KB per chunk), the
+//      pieces are copied into one buffer by all threads, and the CRC32 and length of the whole (crc32_combine of the
+//      chunks') must equal the gzip trailer.
+// Anything that does not fit -- several members, no text, a block start that cannot be found, a chunk that does not end
+// where the next begins, a CRC that differs -- makes the function return 1 and the caller inflates serially with gzread,
+// as before.  Nothing here is trusted without the trailer check.
+#include "gz_parallel.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+typedef uint16_t sym_t;                       // < 256: a byte; >= MARK: byte (value - MARK) of the 32 KB before the chunk
+constexpr sym_t MARK = 0x8000;
+constexpr size_t WIN = 32768;
+
+struct Bits {                                 // LSB-first bit reader over the whole file; pos = absolute bit offset.  The
+    const unsigned char *z; size_t nbits, pos; // deflate data is followed by the 8-byte gzip trailer, so the 8-byte loads
+    bool over = false;                         // below never leave the file
+    inline uint64_t peek() const {            // at least 56 bits from pos on
+        uint64_t v;
+        memcpy(&v, z + (pos >> 3), 8);
+        return v >> (pos & 7);
+    }
+    inline unsigned get(int n) {              // n <= 16
+        if (pos + (size_t)n > nbits) { over = true; return 0; }
+        const unsigned v = (unsigned)(peek() & ((1u << n) - 1u));
+        pos += (size_t)n;
+        return v;
+    }
+};
+
+constexpr int FB = 10;                        // codes of up to FB bits are decoded by one table look-up
+struct Huff {
+    uint16_t count[16]; uint16_t symbol[288];
+    uint16_t fast[1 << FB];                   // by the next FB input bits: symbol | length << 9; 0: a longer code (bit by bit)
+    bool has_fast = false;
+};
+
+// canonical code from lengths; returns 0 complete, > 0 incomplete (bits left over), < 0 over-subscribed
+int build(Huff &h, const uint8_t *len, int n, bool fast = false) {
+    memset(h.count, 0, sizeof h.count);
+    h.has_fast = false;
+    for (int i = 0; i < n; i++) h.count[len[i]]++;
+    if (h.count[0] == n) return 0;            // no codes (complete in the sense that nothing can be decoded)
+    int left = 1;
+    for (int l = 1; l <= 15; l++) { left <<= 1; left -= h.count[l]; if (left < 0) return left; }
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int l = 1; l < 15; l++) offs[l + 1] = offs[l] + h.count[l];
+    for (int i = 0; i < n; i++) if (len[i]) h.symbol[offs[len[i]]++] = (uint16_t)i;
+    if (fast) {
+        memset(h.fast, 0, sizeof h.fast);
+        unsigned next[16], code = 0;
+        for (int l = 1; l <= 15; l++) { code = (code + h.count[l - 1] * (l > 1 ? 1u : 0u)) << 1; next[l] = code; }
+        for (int i = 0; i < n; i++) {
+            const int l = len[i];
+            if (!l || l > FB) { if (l) next[l]++; continue; }
+            unsigned c = next[l]++, r = 0;
+            for (int k = 0; k < l; k++) r |= ((c >> k) & 1u) << (l - 1 - k);     // codes are sent most significant bit first
+            for (unsigned e = r; e < (1u << FB); e += 1u << l) h.fast[e] = (uint16_t)(i | (l << 9));
+        }
+        h.has_fast = true;
+    }
+    return left;
+}
+inline int decode(Bits &b, const Huff &h) {   // -1: not a code / out of input
+    if (h.has_fast) {
+        const unsigned e = h.fast[b.peek() & ((1u << FB) - 1u)];
+        if (e) {
+            b.pos += e >> 9;
+            if (b.pos > b.nbits) { b.over = true; return -1; }
+            return (int)(e & 511u);
+        }
+    }
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= 15; l++) {
+        code |= (int)b.get(1);
+        if (b.over) return -1;
+        const int c = h.count[l];
+        if (code - c < first) return h.symbol[index + (code - first)];
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+
+const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
+                            8193, 12289, 16385, 24577};
+const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+inline bool is_text(unsigned c) { return c == '\n' || c == '\r' || c == '\t' || (c >= 32 && c < 127); }
+
+struct Fixed {
+    Huff lit, dist;
+    Fixed() {
+        uint8_t l[288];
+        for (int i = 0; i < 144; i++) l[i] = 8;
+        for (int i = 144; i < 256; i++) l[i] = 9;
+        for (int i = 256; i < 280; i++) l[i] = 7;
+        for (int i = 280; i < 288; i++) l[i] = 8;
+        build(lit, l, 288, true);
+        for (int i = 0; i < 30; i++) l[i] = 5;
+        build(dist, l, 30, true);
+    }
+};
+const Fixed FIXED;
+
+// One deflate block from b.pos on, appended to `out` as 16-bit symbols (copies that reach before out[0] leave markers).
+// strict: literals must be text (the block-start search).  Returns 0 ok (b.pos behind the block, *last = BFINAL), -1 not
+// a valid block / out of input, -2 out of memory.  max_out bounds the growth of `out` (search: a wrong start must not
+// decode for ever).
+int block(Bits &b, std::vector<sym_t> &out, bool strict, int *last, size_t max_out) {
+    *last = (int)b.get(1);
+    const unsigned type = b.get(2);
+    if (b.over || type == 3) return -1;
+    if (type == 0) {
+        b.pos = (b.pos + 7) & ~(size_t)7;
+        const unsigned len = b.get(16), nlen = b.get(16);
+        if (b.over || (len ^ nlen) != 0xFFFFu) return -1;
+        if (b.pos + 8 * (size_t)len > b.nbits) return -1;
+        if (out.size() + len > max_out) return -1;
+        const unsigned char *p = b.z + (b.pos >> 3);
+        for (unsigned i = 0; i < len; i++) {
+            if (strict && !is_text(p[i])) return -1;
+            out.push_back(p[i]);
+        }
+        b.pos += 8 * (size_t)len;
+        return 0;
+    }
+    Huff lit, dist;
+    const Huff *L = &FIXED.lit, *D = &FIXED.dist;
+    if (type == 2) {
+        const int nlen = (int)b.get(5) + 257, ndist = (int)b.get(5) + 1, ncode = (int)b.get(4) + 4;
+        if (b.over || nlen > 286 || ndist > 30) return -1;
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        uint8_t lengths[320];
+        memset(lengths, 0, sizeof lengths);
+        for (int i = 0; i < ncode; i++) lengths[order[i]] = (uint8_t)b.get(3);
+        if (b.over) return -1;
+        Huff cl;
+        if (build(cl, lengths, 19) != 0) return -1;          // the code-length code must be complete
+        uint8_t ll[320];
+        int idx = 0;
+        while (idx < nlen + ndist) {
+            const int s = decode(b, cl);
+            if (s < 0) return -1;
+            if (s < 16) ll[idx++] = (uint8_t)s;
+            else {
+                int prev = 0, rep;
+                if (s == 16) { if (idx == 0) return -1; prev = ll[idx - 1]; rep = 3 + (int)b.get(2); }
+                else if (s == 17) rep = 3 + (int)b.get(3);
+                else rep = 11 + (int)b.get(7);
+                if (b.over || idx + rep > nlen + ndist) return -1;
+                while (rep--) ll[idx++] = (uint8_t)prev;
+            }
+        }
+        if (ll[256] == 0) return -1;                          // no end-of-block code
+        int e = build(lit, ll, nlen, true);
+        if (e < 0 || (e > 0 && nlen - lit.count[0] != 1)) return -1;   // incomplete only for a single code
+        e = build(dist, ll + nlen, ndist, true);
+        if (e < 0 || (e > 0 && ndist - dist.count[0] != 1)) return -1;
+        L = &lit; D = &dist;
+    }
+    size_t n = out.size();
+    if (out.capacity() < n + 65536 + 258) out.reserve(n + n / 2 + ((size_t)1 << 20));
+    out.resize(out.capacity());                               // written through a pointer; cut back to n on every way out
+    sym_t *v = out.data();
+    size_t cap = out.size();
+    int rc = -1;
+    for (;;) {
+        if (n + 258 > cap) {
+            if (n + 258 > max_out) break;
+            out.resize(n); out.reserve(n + n / 2 + ((size_t)1 << 20)); out.resize(out.capacity());
+            v = out.data(); cap = out.size();
+        }
+        const int s = decode(b, *L);
+        if (s < 0) break;
+        if (s < 256) {
+            if (strict && !is_text((unsigned)s)) break;
+            v[n++] = (sym_t)s;
+        } else if (s == 256) {
+            rc = n <= max_out ? 0 : -1;
+            break;
+        } else {
+            if (s > 285) break;
+            const unsigned len = LBASE[s - 257] + b.get(LEXT[s - 257]);
+            const int ds = decode(b, *D);
+            if (ds < 0 || ds > 29) break;
+            const unsigned d = DBASE[ds] + b.get(DEXT[ds]);
+            if (b.over) break;
+            if (n >= d) {
+                const sym_t *src = v + n - d;
+                for (unsigned i = 0; i < len; i++) v[n + i] = src[i];
+            } else {
+                for (unsigned i = 0; i < len; i++) {
+                    const long long src = (long long)(n + i) - (long long)d;
+                    v[n + i] = src >= 0 ? v[(size_t)src] : (sym_t)(MARK + (sym_t)((long long)WIN + src));
+                }
+            }
+            n += len;
+        }
+    }
+    out.resize(n);
+    return rc;
+}
+
+// first bit offset >= from (< to) at which a non-final DYNAMIC block starts that decodes as text (at least 1024 symbols)
+// and is followed by a block that decodes as text too -- or nbits (none).  Only dynamic blocks are taken for a start: their
+// header is its own proof (the code-length code and both codes it describes must be complete), while any bit string is
+// a valid run of fixed-code symbols and a stored block proves itself with 16 bits; gzip writes dynamic blocks for text of
+// any size worth cutting into pieces.
+size_t find_block(const unsigned char *z, size_t nbits, size_t from, size_t to) {
+    std::vector<sym_t> tmp, t2;
+    for (size_t p = from; p < to; p++) {
+        const unsigned hdr = (z[p >> 3] >> (p & 7)) | ((p >> 3) + 1 < (nbits + 7) >> 3 ? (unsigned)z[(p >> 3) + 1] << (8 - (p & 7)) : 0u);
+        if ((hdr & 7u) != 4u) continue;                       // BFINAL = 0, BTYPE = 2 (bits LSB first: 0, then 0 1)
+        Bits b{z, nbits, p};
+        tmp.clear();
+        int last = 0;
+        if (block(b, tmp, true, &last, (size_t)1 << 22) != 0 || last || tmp.size() < 1024) continue;
+        Bits c = b;
+        t2.clear();
+        int last2 = 0;
+        if (block(c, t2, true, &last2, (size_t)1 << 22) != 0) continue;
+        return p;
+    }
+    return nbits;
+}
+
+struct Piece {
+    size_t start_bit = 0, end_bit = 0;       // decoded from / up to (the next piece's start_bit, or the end of the final block)
+    std::vector<sym_t> head;                  // symbols decoded with the unknown window (may hold markers)
+    char *body = nullptr; size_t body_len = 0, body_cap = 0;   // what zlib decoded behind them (final bytes)
+    std::vector<char> head_bytes;             // head, resolved
+    bool final_block = false;
+    int status = 0;                           // 0 ok, 1 does not fit (serial fallback), -1 damaged / out of memory
+};
+
+bool grow(Piece &p, size_t need) {
+    if (p.body_len + need <= p.body_cap) return true;
+    size_t cap = p.body_cap ? p.body_cap : ((size_t)8 << 20);
+    while (cap < p.body_len + need) cap *= 2;
+    char *nb = (char *)realloc(p.body, cap);
+    if (!nb) return false;
+    p.body = nb; p.body_cap = cap;
+    return true;
+}
+
+// zlib continues at a block boundary `bit` with the 32 KB `dict` before it, until it reaches `stop_bit` (a boundary) or
+// the end of the final block
+void zlib_part(const unsigned char *z, size_t zlen, size_t bit, size_t stop_bit, const unsigned char *dict, size_t dictlen, Piece &p) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { p.status = -1; return; }
+    if (dictlen && inflateSetDictionary(&zs, dict, (uInt)dictlen) != Z_OK) { inflateEnd(&zs); p.status = 1; return; }
+    size_t byte = bit >> 3;
+    if (bit & 7) {
+        if (inflatePrime(&zs, 8 - (int)(bit & 7), z[byte] >> (bit & 7)) != Z_OK) { inflateEnd(&zs); p.status = 1; return; }
+        byte++;
+    }
+    size_t in_done = byte;                                    // bytes of z handed to zlib and consumed
+    for (;;) {
+        if (!grow(p, (size_t)1 << 20)) { p.status = -1; break; }
+        const size_t chunk_in = zlen - in_done < ((size_t)1 << 30) ? zlen - in_done : ((size_t)1 << 30);
+        zs.next_in = const_cast<Bytef *>(z + in_done); zs.avail_in = (uInt)chunk_in;
+        const size_t room = p.body_cap - p.body_len < ((size_t)1 << 30) ? p.body_cap - p.body_len : ((size_t)1 << 30);
+        zs.next_out = (Bytef *)p.body + p.body_len; zs.avail_out = (uInt)room;
+        const int r = inflate(&zs, Z_BLOCK);
+        in_done += chunk_in - zs.avail_in;
+        p.body_len += room - zs.avail_out;
+        if (r == Z_STREAM_END) { p.final_block = true; p.end_bit = 8 * in_done - (size_t)(zs.data_type & 63); break; }
+        if (r != Z_OK && r != Z_BUF_ERROR) { p.status = 1; break; }       // not deflate from here: the start was wrong
+        if (zs.data_type & 128) {                             // at a block boundary
+            const size_t here = 8 * in_done - (size_t)(zs.data_type & 63);
+            if (here == stop_bit) { p.end_bit = here; break; }
+            if (here > stop_bit) { p.status = 1; break; }     // the next piece does not start on a boundary of this one
+        }
+        if (r == Z_BUF_ERROR && zs.avail_in == 0 && in_done >= zlen) { p.status = 1; break; }   // input ends inside a block
+    }
+    inflateEnd(&zs);
+}
+
+void decode_piece(const unsigned char *z, size_t zlen, size_t stop_bit, bool first, Piece &p) {
+    const size_t nbits = 8 * zlen;
+    if (first) { zlib_part(z, zlen, p.start_bit, stop_bit, nullptr, 0, p); return; }
+    Bits b{z, nbits, p.start_bit};
+    size_t clean = 0;                                         // symbols at the end of head that hold no marker
+    for (;;) {
+        if (b.pos == stop_bit) { p.end_bit = b.pos; return; }
+        if (b.pos > stop_bit) { p.status = 1; return; }
+        if (clean >= WIN) break;                              // a known window: zlib from here
+        const size_t before = p.head.size();
+        int last = 0;
+        // (a text whose copies keep reaching back -- tandem repeats -- never sheds its markers: beyond 2^26 symbols of head
+        // the file is left to the serial path rather than decoded at this decoder's pace)
+        const int r = block(b, p.head, false, &last, (size_t)1 << 26);
+        if (r != 0) { p.status = 1; return; }
+        (void)before;
+        clean = 0;                                            // marker-free symbols at the end, as far as it matters
+        for (size_t i = p.head.size(); i > 0 && clean < WIN && p.head[i - 1] < MARK; i--) clean++;
+        if (last) { p.final_block = true; p.end_bit = b.pos; return; }
+    }
+    unsigned char dict[WIN];
+    for (size_t i = 0; i < WIN; i++) dict[i] = (unsigned char)p.head[p.head.size() - WIN + i];
+    zlib_part(z, zlen, b.pos, stop_bit, dict, WIN, p);
+}
+
+}  // namespace
+
+#define GZ_TRACE(...) do { if (trace) fprintf(stderr, "gz_parallel: " __VA_ARGS__); } while (0)
+
+int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char **out_buf, size_t *out_len) {
+    const bool trace = getenv("DEBWT_TRACE_GZ") != nullptr;
+    if (threads < 2 || zlen < 18 + ((size_t)1 << 16)) return 1;
+    // the member header (RFC 1952)
+    if (z[0] != 0x1f || z[1] != 0x8b || z[2] != 8 || (z[3] & 0xE0)) return 1;
+    const unsigned flg = z[3];
+    size_t q = 10;
+    if (flg & 4) { if (q + 2 > zlen) return 1; q += 2 + (z[q] | ((size_t)z[q + 1] << 8)); }
+    if (flg & 8) { while (q < zlen && z[q]) q++; q++; }
+    if (flg & 16) { while (q < zlen && z[q]) q++; q++; }
+    if (flg & 2) q += 2;
+    if (q + 8 >= zlen) return 1;
+    const size_t nbits = 8 * (zlen - 8);                      // the trailer is not deflate data
+    // pieces: the compressed bytes cut evenly (DEBWT_GZ_PIECE_BYTES for tests), at least 1 MB each, two per thread (every piece
+    // but the first pays for a head of 0.5 - 3 MB at our own decoder's pace, whatever its size)
+    size_t piece_bytes = (zlen / ((size_t)threads * 2)) + 1;
+    if (piece_bytes < ((size_t)1 << 20)) piece_bytes = (size_t)1 << 20;
+    if (const char *e = getenv("DEBWT_GZ_PIECE_BYTES")) { const long long v = atoll(e); if (v >= 4096) piece_bytes = (size_t)v; }
+    const size_t npieces_max = (zlen - q + piece_bytes - 1) / piece_bytes;
+    if (npieces_max < 2) return 1;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    // 1. block starts, in parallel
+    std::vector<size_t> start(npieces_max, nbits);
+    start[0] = 8 * q;
+    {
+        std::atomic<size_t> next{1};
+        auto work = [&] {
+            for (size_t i; (i = next.fetch_add(1)) < npieces_max;) {
+                const size_t from = 8 * (q + i * piece_bytes), to = std::min(nbits, 8 * (q + (i + 1) * piece_bytes));
+                start[i] = from < nbits ? find_block(z, nbits, from, to) : nbits;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; t++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    std::vector<Piece> pc;
+    for (size_t i = 0; i < npieces_max; i++)
+        if (start[i] < nbits) { pc.emplace_back(); pc.back().start_bit = start[i]; }    // (a piece without a start joins the one before)
+    GZ_TRACE("%zu bytes, pieces of %zu bytes: %zu of %zu block starts found after %.3f s\n", zlen, piece_bytes, pc.size(), npieces_max, since());
+    if (pc.size() < 2) return 1;
+    // 2. the pieces, in parallel
+    {
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t i; (i = next.fetch_add(1)) < pc.size();)
+                decode_piece(z, zlen - 8, i + 1 < pc.size() ? pc[i + 1].start_bit : ~(size_t)0, i == 0, pc[i]);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; t++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    GZ_TRACE("pieces decoded after %.3f s\n", since());
+    auto cleanup = [&] { for (Piece &p : pc) free(p.body); };
+    int st = 0;
+    for (size_t i = 0; i < pc.size(); i++) {
+        const Piece &p = pc[i];
+        GZ_TRACE("piece %zu: bits %zu..%zu, head %zu symbols, body %zu bytes, final %d, status %d\n", i, p.start_bit, p.end_bit, p.head.size(),
+                 p.body_len, (int)p.final_block, p.status);
+        if (p.status) { st = p.status; break; }
+        const bool lastp = i + 1 == pc.size();
+        if (p.final_block != lastp) { st = 1; break; }        // the final block in the middle: more than one member, or a wrong start
+        if (!lastp && p.end_bit != pc[i + 1].start_bit) { st = 1; break; }
+    }
+    if (!st && ((pc.back().end_bit + 7) >> 3) != zlen - 8) { GZ_TRACE("bytes behind the final block\n"); st = 1; }   // another member
+    if (st) { cleanup(); return st; }
+    // 3. markers resolved piece by piece with the 32 KB before them; total length
+    std::vector<size_t> off(pc.size() + 1, 0);
+    for (size_t i = 0; i < pc.size(); i++) off[i + 1] = off[i] + pc[i].head.size() + pc[i].body_len;
+    const size_t total = off.back();
+    const size_t want_len = z[zlen - 4] | ((size_t)z[zlen - 3] << 8) | ((size_t)z[zlen - 2] << 16) | ((size_t)z[zlen - 1] << 24);
+    if ((total & 0xFFFFFFFFull) != want_len) { GZ_TRACE("length %zu differs from the trailer's %zu\n", total, want_len); cleanup(); return 1; }
+    char *buf = (char *)malloc(total + 1);
+    if (!buf) { cleanup(); return -1; }
+    // the window of every piece, in order: only the last WIN bytes of a piece are needed for the next one's
+    std::vector<std::vector<unsigned char>> window(pc.size() + 1);   // window[i]: the (up to) WIN bytes before piece i
+    auto resolve = [&](const std::vector<unsigned char> &win, sym_t s, unsigned char *byte) {
+        if (s < 256) { *byte = (unsigned char)s; return true; }
+        const size_t w = (size_t)(s - MARK);                  // byte w of the window of WIN bytes that ends where the piece starts
+        if (w + win.size() < WIN) return false;               // reaches before the start of the data
+        *byte = win[w - (WIN - win.size())];
+        return true;
+    };
+    for (size_t i = 0; i < pc.size() && !st; i++) {
+        const Piece &p = pc[i];
+        const size_t hl = p.head.size(), bl = p.body_len;
+        std::vector<unsigned char> &nw = window[i + 1];
+        if (bl >= WIN) nw.assign((unsigned char *)p.body + bl - WIN, (unsigned char *)p.body + bl);
+        else {
+            const size_t from_head = std::min(hl, WIN - bl), from_win = std::min(window[i].size(), WIN - bl - from_head);
+            nw.insert(nw.end(), window[i].end() - (long)from_win, window[i].end());
+            for (size_t j = hl - from_head; j < hl; j++) {
+                unsigned char c;
+                if (!resolve(window[i], p.head[j], &c)) { st = 1; break; }
+                nw.push_back(c);
+            }
+            nw.insert(nw.end(), (unsigned char *)p.body, (unsigned char *)p.body + bl);
+        }
+    }
+    if (st) { free(buf); cleanup(); return st; }
+    GZ_TRACE("windows known after %.3f s\n", since());
+    // heads resolved, bodies into place and the CRC of every piece, in parallel
+    std::vector<uLong> crc(pc.size(), 0);
+    std::atomic<int> bad{0};
+    {
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t i; (i = next.fetch_add(1)) < pc.size();) {
+                Piece &p = pc[i];
+                unsigned char *dst = (unsigned char *)buf + off[i];
+                const std::vector<unsigned char> &win = window[i];
+                const size_t wbase = WIN - win.size();
+                for (size_t j = 0, hl = p.head.size(); j < hl; j++) {
+                    const sym_t s = p.head[j];
+                    if (s < 256) dst[j] = (unsigned char)s;
+                    else if ((size_t)(s - MARK) >= wbase) dst[j] = win[(size_t)(s - MARK) - wbase];
+                    else { bad = 1; break; }
+                }
+                std::vector<sym_t>().swap(p.head);
+                if (p.body_len) memcpy(dst + (off[i + 1] - off[i] - p.body_len), p.body, p.body_len);
+                free(p.body); p.body = nullptr;
+                uLong c = crc32(0L, Z_NULL, 0);
+                for (size_t a = 0, n = off[i + 1] - off[i]; a < n;) {
+                    const size_t m = std::min<size_t>(n - a, (size_t)1 << 30);
+                    c = crc32(c, dst + a, (uInt)m);
+                    a += m;
+                }
+                crc[i] = c;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; t++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    if (bad) { free(buf); cleanup(); return 1; }
+    GZ_TRACE("resolved, copied and summed after %.3f s\n", since());
+    uLong all = crc32(0L, Z_NULL, 0);
+    for (size_t i = 0; i < pc.size(); i++) all = crc32_combine(all, crc[i], (z_off_t)(off[i + 1] - off[i]));
+    const uLong want_crc = z[zlen - 8] | ((uLong)z[zlen - 7] << 8) | ((uLong)z[zlen - 6] << 16) | ((uLong)z[zlen - 5] << 24);
+    if (all != want_crc) { GZ_TRACE("CRC differs from the trailer's\n"); free(buf); return 1; }             // (the serial path will say whether the file is damaged)
+    *out_buf = buf; *out_len = total;
+    return 0;
+}

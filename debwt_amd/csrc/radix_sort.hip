@@ -534,6 +534,9 @@ __device__ __forceinline__ void rs_flush_body(ScShared &sh, const RsDigit &dg, u
         else if (js >= lo) out[(u32)b[r] + (u32)js] = k[r];
     }
 }
+#ifndef SPARSE_DOUBLE_TEST
+#define SPARSE_DOUBLE_TEST 0
+#endif
 #ifndef RS_WAVES_EU
 #define RS_WAVES_EU 4                  // 128 VGPRs: two 512-thread workgroups per CU, as the LDS footprint allows
 #endif
@@ -659,6 +662,20 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
                 const bool in = AUX ? ((stab[pre >> 5] >> (pre & 31u)) & 1u) != 0u : (pre - lo12) < span12;
                 m |= (in ? 1u : 0u) << t;
             }
+#if SPARSE_DOUBLE_TEST
+            {   // DIAGNOSTIC (same result): the prefix tests once more on an opaque copy of the words -- what they cost
+                u64 c0 = w0, c1 = w1;
+                asm volatile("" : "+v"(c0), "+v"(c1));
+                u32 m2 = 0;
+#pragma unroll
+                for (u32 t = 0; t < 32; t++) {
+                    const u32 pre = t <= 26 ? (u32)(c0 >> (52 - 2 * t)) & 0xFFFu
+                                            : (u32)(((c0 << (2 * t)) | (c1 >> (64 - 2 * t))) >> 52);
+                    m2 |= ((pre - lo12) < span12 ? 1u : 0u) << t;
+                }
+                m &= m2;
+            }
+#endif
             if (sb) {                                          // a separator within 64 positions: rare, tested apart
 #pragma unroll
                 for (u32 t = 0; t < 32; t++)

@@ -89,6 +89,53 @@ int main() {
         remove(path);
         CHECK(pack_fasta_file("/nonexistent/x.fa", 2, &p, err, sizeof err) != 0);
     }
+    {   // a one-member gzip file in pieces (gz_parallel.cpp): block starts found by trial, marker heads, zlib hand-over,
+        // windows, CRC -- compression levels 1 (markers never clear), 6 and 9, pieces of 16 KB and 64 KB; then damaged and cut short
+        std::string big;
+        {
+            std::vector<std::string> rr;
+            for (int r = 0; r < 6; r++) { std::string q(300000 + rnd() % 200000, 'A'); for (auto &c : q) c = acgt[rnd() & 3]; rr.push_back(q); }
+            big = fasta_of(rr, 80, false, false);
+        }
+        PackedText want{};
+        CHECK(pack_fasta_buffer(big.data(), big.size(), 2, &want, err, sizeof err) == 0);
+        const char *path = "/tmp/debwt_sanitize_one_member.fa.gz";
+        setenv("DEBWT_GZ_REQUIRE_PARALLEL", "1", 1);
+        for (int level : {1, 6, 9})
+            for (const char *piece : {"16384", "65536"}) {
+                char mode[8];
+                snprintf(mode, sizeof mode, "wb%d", level);
+                gzFile g = gzopen(path, mode);
+                CHECK(g && gzwrite(g, big.data(), (unsigned)big.size()) == (int)big.size());
+                gzclose(g);
+                setenv("DEBWT_GZ_PIECE_BYTES", piece, 1);
+                for (int threads : {2, 8}) {
+                    PackedText p{};
+                    CHECK(pack_fasta_file(path, threads, &p, err, sizeof err) == 0);
+                    CHECK(p.n == want.n && p.nrec == want.nrec && !memcmp(p.words, want.words, want.nwords * 8));
+                    free_packed_text(&p);
+                }
+            }
+        unsetenv("DEBWT_GZ_REQUIRE_PARALLEL");
+        {   // one byte flipped in the middle, and the last 20 KB missing: errors, whichever path notices
+            FILE *f = fopen(path, "rb");
+            std::string z;
+            char tmp[65536];
+            size_t got;
+            while ((got = fread(tmp, 1, sizeof tmp, f)) > 0) z.append(tmp, got);
+            fclose(f);
+            std::string bad = z;
+            bad[bad.size() / 2] ^= 0x5A;
+            f = fopen(path, "wb"); fwrite(bad.data(), 1, bad.size(), f); fclose(f);
+            PackedText p{};
+            CHECK(pack_fasta_file(path, 4, &p, err, sizeof err) != 0);
+            f = fopen(path, "wb"); fwrite(z.data(), 1, z.size() - 20000, f); fclose(f);
+            CHECK(pack_fasta_file(path, 4, &p, err, sizeof err) != 0);
+        }
+        unsetenv("DEBWT_GZ_PIECE_BYTES");
+        free_packed_text(&want);
+        remove(path);
+    }
     {   // block gzip (BGZF: members with the 'BC' subfield, inflated in parallel), whole and with a damaged member
         std::string fa = fasta_of(recs, 70, false, false);
         const char *path = "/tmp/debwt_sanitize_bgzf.fa.gz";

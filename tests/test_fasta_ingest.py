@@ -311,3 +311,91 @@ def test_pack_fastq_with_ambiguity_letters(tmp_path):
     a = api.pack_fasta(p, 1, iupac_seed=5)
     b = api.pack_fasta(p, 8, iupac_seed=5)
     assert a[1] == b[1] and np.array_equal(a[0], b[0])
+
+
+def _gz_members(parts, level=6):
+    """Plain gzip members (no BGZF subfield), concatenated."""
+    return b"".join(gzip.compress(p, compresslevel=level, mtime=0) for p in parts)
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+@pytest.mark.parametrize("piece", [65536, 300000])
+def test_pack_one_member_gzip_in_parallel(tmp_path, monkeypatch, level, piece):
+    """A one-member gzip file (how genome FASTA is distributed) is inflated by all ingest threads: the compressed bytes are
+    cut into pieces, a deflate block start is found in every piece by trial, pieces are decoded with an unknown 32 KB window
+    (markers) until zlib can take over, markers are resolved in order, CRC32 and length are checked against the trailer
+    (gz_parallel.cpp).  DEBWT_GZ_REQUIRE_PARALLEL: no silent fall-back to the serial path.  Same packed text as from the plain
+    file, for compression levels 1 (markers never clear: our decoder alone), 6 and 9 and for pieces of 64 KB and 300 KB (the
+    default, two pieces per thread and at least 1 MB each: test_pack_one_member_gzip_default_pieces)."""
+    rng = np.random.default_rng(21 + level)
+    recs = [rng.integers(0, 4, size=int(rng.integers(200_000, 1_500_000))).astype(np.uint8) for _ in range(5)]
+    plain = str(tmp_path / "g.fa")
+    _write(plain, recs, width=80)
+    data = open(plain, "rb").read()
+    p = str(tmp_path / "g.fa.gz")
+    open(p, "wb").write(gzip.compress(data, compresslevel=level, mtime=0))
+    monkeypatch.setenv("DEBWT_GZ_REQUIRE_PARALLEL", "1")
+    monkeypatch.setenv("DEBWT_GZ_PIECE_BYTES", str(piece))
+    for threads in (2, 8):
+        _check(p, recs, threads)
+
+
+def test_pack_one_member_gzip_default_pieces(tmp_path, monkeypatch):
+    """40 MB of FASTA in one gzip member with the default cut (two pieces per thread, at least 1 MB of compressed bytes each):
+    the same words as from the plain file."""
+    rng = np.random.default_rng(77)
+    codes = rng.integers(0, 4, size=40_000_000).astype(np.uint8)
+    lines = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].reshape(-1, 80)
+    data = b">one record\n" + np.concatenate([lines, np.full((lines.shape[0], 1), 10, np.uint8)], axis=1).tobytes()
+    plain, p = str(tmp_path / "d.fa"), str(tmp_path / "d.fa.gz")
+    open(plain, "wb").write(data)
+    open(p, "wb").write(gzip.compress(data, compresslevel=6, mtime=0))
+    w0, n0, sep0, _, _ = api.pack_fasta(plain, 8)
+    monkeypatch.setenv("DEBWT_GZ_REQUIRE_PARALLEL", "1")
+    for threads in (3, 8):
+        w, n, sep, _, _ = api.pack_fasta(p, threads)
+        assert n == n0 == 40_000_001 and np.array_equal(sep, sep0) and np.array_equal(w, w0)
+
+
+def test_pack_gzip_shapes_the_parallel_path_declines(tmp_path, monkeypatch):
+    """What the parallel path does not take is inflated serially as before, with the same result: several plain members
+    (the final block comes in the middle), stored blocks only (gzip -0: no dynamic block to start from), a file too small to
+    cut; a FASTQ .gz of one member IS taken; a stream damaged in the middle is an error, not a wrong text."""
+    rng = np.random.default_rng(31)
+    recs = [rng.integers(0, 4, size=int(rng.integers(100_000, 400_000))).astype(np.uint8) for _ in range(6)]
+    plain = str(tmp_path / "m.fa")
+    _write(plain, recs, width=61)
+    data = open(plain, "rb").read()
+    monkeypatch.setenv("DEBWT_GZ_PIECE_BYTES", "65536")
+    cut = data.index(b">", len(data) // 2)
+    shapes = {"two_members": _gz_members([data[:cut], data[cut:]]), "stored": gzip.compress(data, compresslevel=0, mtime=0),
+              "tiny": gzip.compress(data[:data.index(b"\n>", 1) + 1], mtime=0)}
+    for name, blob in shapes.items():
+        p = str(tmp_path / (name + ".fa.gz"))
+        open(p, "wb").write(blob)
+        monkeypatch.setenv("DEBWT_GZ_REQUIRE_PARALLEL", "1")
+        with pytest.raises(api.DebwtError, match="declined"):
+            api.pack_fasta(p, 4)
+        monkeypatch.delenv("DEBWT_GZ_REQUIRE_PARALLEL")
+        _check(p, recs if name != "tiny" else recs[:1], 4)
+    # FASTQ, one member
+    reads = [rng.integers(0, 4, size=150).astype(np.uint8) for _ in range(20000)]
+    fq = str(tmp_path / "r.fq")
+    _write_fastq(fq, reads)
+    fqz = str(tmp_path / "r.fq.gz")
+    open(fqz, "wb").write(gzip.compress(open(fq, "rb").read(), mtime=0))
+    monkeypatch.setenv("DEBWT_GZ_REQUIRE_PARALLEL", "1")
+    _check(fqz, reads, 8)
+    monkeypatch.delenv("DEBWT_GZ_REQUIRE_PARALLEL")
+    # damage in the middle of the one-member stream: declined by the parallel path (its pieces no longer meet, or the CRC
+    # differs), reported by the serial one
+    raw = bytearray(gzip.compress(data, mtime=0))
+    raw[len(raw) // 2] ^= 0x5A
+    bad = str(tmp_path / "bad.fa.gz")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(api.DebwtError):
+        api.pack_fasta(bad, 4)
+    # ... and cut short
+    open(bad, "wb").write(gzip.compress(data, mtime=0)[:-40000])
+    with pytest.raises(api.DebwtError):
+        api.pack_fasta(bad, 4)
