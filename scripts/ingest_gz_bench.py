@@ -20,10 +20,11 @@ with open(fa, "wb") as f:
         f.write(b"\n"); a += int(ln)
 data = open(fa, "rb").read()
 t0 = time.time()
-with open(f"{d}/x.plain.fa.gz", "wb") as f:
-    co = zlib.compressobj(1, zlib.DEFLATED, 31)
-    for o in range(0, len(data), 1 << 24): f.write(co.compress(data[o:o + (1 << 24)]))
-    f.write(co.flush())
+for level in (1, 6):                                   # one member each: gzip -1 and gzip's default, -6
+    with open(f"{d}/x.gzip{level}.fa.gz", "wb") as f:
+        co = zlib.compressobj(level, zlib.DEFLATED, 31)
+        for o in range(0, len(data), 1 << 24): f.write(co.compress(data[o:o + (1 << 24)]))
+        f.write(co.flush())
 t1 = time.time()
 with open(f"{d}/x.bgzf.fa.gz", "wb") as f:
     B = 65280
@@ -32,16 +33,20 @@ with open(f"{d}/x.bgzf.fa.gz", "wb") as f:
         co = zlib.compressobj(1, zlib.DEFLATED, -15); body = co.compress(chunk) + co.flush()
         f.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1))
         f.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
-print(f"{mbp} Mbp FASTA: {len(data) / 1e9:.2f} GB; gzip -1 written in {t1 - t0:.0f} s, BGZF in {time.time() - t1:.0f} s; {threads} host threads", flush=True)
+print(f"{mbp} Mbp FASTA: {len(data) / 1e9:.2f} GB; gzip -1 and -6 written in {t1 - t0:.0f} s, BGZF in {time.time() - t1:.0f} s; {threads} host threads", flush=True)
 ref = None
-for name in ("x.fa", "x.plain.fa.gz", "x.bgzf.fa.gz"):
+for name, env in (("x.fa", {}), ("x.gzip1.fa.gz", {"DEBWT_GZ_SERIAL": "1"}), ("x.gzip1.fa.gz", {}), ("x.gzip6.fa.gz", {"DEBWT_GZ_SERIAL": "1"}),
+                  ("x.gzip6.fa.gz", {}), ("x.bgzf.fa.gz", {})):
     best = None
+    os.environ.pop("DEBWT_GZ_SERIAL", None)
+    os.environ.update(env)
+    label = name + (" (serial: zlib's gzread, as in round 4)" if env else "")
     for _ in range(2):
         t0 = time.time(); w, n, sep, s_read, s_pack = api.pack_fasta(f"{d}/{name}", threads); dt = time.time() - t0
         best = min(best, (dt, s_read, s_pack)) if best else (dt, s_read, s_pack)
     if ref is None: ref = (w.copy(), n)
     same = n == ref[1] and np.array_equal(w, ref[0])
-    print(f"{name:16s} file {os.path.getsize(f'{d}/{name}') / 1e9:6.2f} GB: read/inflate {best[1]:6.2f} s + parse/pack {best[2]:5.2f} s = "
+    print(f"{label:56s} file {os.path.getsize(f'{d}/{name}') / 1e9:6.2f} GB: read/inflate {best[1]:6.2f} s + parse/pack {best[2]:5.2f} s = "
           f"{len(data) / 1e9 / (best[1] + best[2]):6.2f} GB/s of FASTA text ({mbp / 1e3 / (best[1] + best[2]):.2f} Gbp/s), same text: {same}", flush=True)
 for name in os.listdir(d): os.remove(f"{d}/{name}")
 os.rmdir(d)
