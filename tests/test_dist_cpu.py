@@ -135,7 +135,7 @@ def test_sharded_host_logic_over_gloo(tmp_path):
     script = tmp_path / "shard_worker.py"
     script.write_text(SHARD_WORKER)
     # (world 8 = the size the metric is quoted at: on the GPU box at most 6 processes may share the card, so the device-side
-    # test of the sharded build stops at 5 ranks, tests/test_sharded.py, and the C host covers 8 shards in one process)
+    # test of the sharded build stops at 4 ranks, tests/test_sharded.py, and the C host covers 8 shards in one process)
     for world, port, p2p_max in ((2, "29535", None), (3, "29536", "4096"), (8, "29537", "4096")):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         if p2p_max:

@@ -83,13 +83,14 @@ WORKER = textwrap.dedent("""
 @pytest.mark.parametrize("mode", ["scan", "exchange", "rescan", "auto"])
 @pytest.mark.parametrize("world,case,k,cap", [(2, "pan", 32, 0), (3, "pan", 20, 0), (2, "many", 32, 0), (4, "chrom", 32, 0),
                                               (2, "pan", 32, 100_000), (3, "chrom", 24, 150_000), (4, "many", 32, 8192),
-                                              (3, "reads", 32, 0), (2, "reads", 20, 50_000),
-                                              (5, "chrom", 32, 0)])          # the most ranks the GPU box lets share its card
-                                                                             # (6 processes incl. this one); 8: CPU, test_dist_cpu.py
+                                              (3, "reads", 32, 0), (2, "reads", 20, 50_000)])
+# (world <= 4: the GPU box allows 6 processes on its card at once, and the runner, the launcher's agent and the ranks all
+#  count -- five ranks were killed by its process guard.  World 8, the size the metric is quoted at: the host logic over gloo
+#  on CPU in tests/test_dist_cpu.py, and 8 shards in ONE process through debwt_multi_build in tests/test_gpu_verify.py)
 def test_sharded_build_equals_oracle(tmp_path, oracle, world, case, k, mode, cap):
     from debwt_amd import synth
-    if (case == "reads" or world == 5) and mode in ("scan", "auto"):
-        pytest.skip("the many-record collection and the 5-rank case run in the two key modes only (suite time)")
+    if case == "reads" and mode in ("scan", "auto"):
+        pytest.skip("the many-record collection runs in the two key modes only (suite time)")
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / "res.npz")
