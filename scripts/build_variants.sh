@@ -24,8 +24,9 @@ mkdir -p build/variants
   /opt/rocm/bin/hipcc $F -c multi_host.cpp -o multi_host.o &
   /opt/rocm/bin/hipcc $F -x c++ -c special_host.cpp -o special_host.o &
   /opt/rocm/bin/hipcc $F -x c++ -c fasta_host.cpp -o fasta_host.o &
+  /opt/rocm/bin/hipcc $F -x c++ -c gz_parallel.cpp -o gz_parallel.o &
   /opt/rocm/bin/hipcc $F -x c++ -c synth_host.cpp -o synth_host.o & wait )
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libdebwt_$name.so "$tmp"/radix_sort.o "$tmp"/debwt_hip.o \
-  "$tmp"/special_host.o "$tmp"/fasta_host.o "$tmp"/synth_host.o "$tmp"/multi_host.o -lz -lpthread
+  "$tmp"/special_host.o "$tmp"/fasta_host.o "$tmp"/gz_parallel.o "$tmp"/synth_host.o "$tmp"/multi_host.o -lz -lpthread
 rm -rf "$tmp"
 echo built build/variants/libdebwt_$name.so

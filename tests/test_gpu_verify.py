@@ -175,6 +175,44 @@ def test_multi_gpu_host_from_one_process(api, oracle, devices, case, k, cap, tun
     assert m.verify_device()["ok"] == 1
     m.close()
 
+@pytest.mark.parametrize("mode", ["rescan", "exchange"])
+def test_multi_gpu_host_serial_mode_reports_every_shard(api, oracle, mode):
+    """debwt_multi_set_serial: the shards of a build take turns between the barriers (how per-shard times are measured on a box
+    with one GPU) -- the same BWT as the oracle's and as the concurrent build; debwt_multi_get_shard_report: every shard's
+    keys / blocks / rows add up to the whole, its bins are contiguous, what the shards sent is what the shards received, and
+    every step it ran has a time."""
+    from debwt_amd import synth
+    recs = synth.pan_genome(300_000, 4, seed=9)
+    sym = oracle.sym_from_codes(recs)
+    ow, oh, od, ost = oracle.build_bwt(sym, 32)
+    m = api.MultiDeBWT([0, 0, 0, 0, 0], k=32)
+    m.load_records(recs)
+    m.set_key_mode(mode)
+    for serial in (True, False, True):
+        m.set_serial(serial)
+        m.build()
+        w, h, dr = m.fetch()
+        assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od, (mode, serial)
+    reps = [m.shard_report(r) for r in range(5)]
+    ms, _ = m.stats()
+    assert [r["bins"][0] for r in reps][0] == 0 and reps[-1]["bins"][1] == 4096
+    assert all(a["bins"][1] == b["bins"][0] for a, b in zip(reps, reps[1:]))
+    n_main = len(sym) - len(recs) * 31
+    assert sum(r["keys"] for r in reps) == n_main and sum(r["rows"] for r in reps) == len(sym)
+    assert sum(r["blocks"] for r in reps) == ost["blue_bound_num"] and sum(r["blue_rows"] for r in reps) == ost["blue_capacity"]
+    for x in ("keys", "facts", "sp", "blue"):
+        assert sum(r["bytes_in"][x] for r in reps) == sum(r["bytes_out"][x] for r in reps), x
+    assert (sum(r["bytes_in"]["keys"] for r in reps) > 0) == (mode == "exchange")
+    assert reps[0]["bytes_in"]["rows"] > 0 and all(r["bytes_in"]["rows"] == 0 for r in reps[1:])
+    must = {"shard_histogram", "shard_classify_local", "shard_sp_flags", "shard_sp_emit", "shard_blue_route", "shard_blue_place", "blue_sort",
+            "bwt_assemble", "shard_export"} | ({"kmer_sort_rle"} if mode == "rescan" else {"shard_partition_keys", "shard_sort_range"})
+    for r in reps:
+        assert must <= set(r["ms"]), (r["shard"], sorted(must - set(r["ms"])))
+        assert r["ctx"]["n"] == len(sym) and r["key_ranges"] >= 1
+    assert "concat_rows" in reps[0]["ms"] and "waiting" not in reps[0]["ms"]      # (serial: turns, not waits)
+    assert m.verify_device()["ok"] == 1
+    m.close()
+
 
 @pytest.mark.parametrize("ngpus", [1, 2])
 def test_multi_gpu_host_exchanges_over_rccl(api, oracle, ngpus):
