@@ -1363,6 +1363,7 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
     std::vector<u32> res;
     std::vector<LsOver> over;
     std::vector<LsBlock> desc;
+    std::vector<u32> bigidx;
     u32 round = 0;
     static const u32 bin_rows = getenv("DEBWT_LS_BIN_ROWS") ? (u32)atoi(getenv("DEBWT_LS_BIN_ROWS")) : LS_BIN_ROWS;
     static const u32 oversample = getenv("DEBWT_LS_OVERSAMPLE") ? (u32)atoi(getenv("DEBWT_LS_OVERSAMPLE")) : LS_OVERSAMPLE;
@@ -1372,8 +1373,9 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
         u64 tr_rows = 0, tr_tie_n = 0, tr_tie_rows = 0, tr_piv = 0, tr_net = 0;
         for (const Work &wk : work) { tr_rows += wk.m; tr_piv += wk.pivot; }
         for (size_t w0 = 0; w0 < work.size();) {
-            desc.clear();
+            desc.clear(); bigidx.clear();
             u64 rows = 0, wgs = 0, slots = 0;
+            u32 nbig = 0;                                          // blocks of more than 256 samples in the batch
             bool small_ns = false, big_ns = false, small_nb = false, big_nb = false;
             size_t w1 = w0;
             for (; w1 < work.size() && (desc.empty() || rows + work[w1].m <= LS_BATCH_ROWS) && wgs < 0x7FFF0000ull; w1++) {
@@ -1382,7 +1384,8 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
                 while (nb < LS_MAXBINS && (u64)nb * bin_rows < wk.m) nb <<= 1;
                 u32 ns = 64;
                 while (ns < LS_SAMPLES && ns < nb * oversample) ns <<= 1;        // a power of two (bitonic sort), a multiple of nb
-                desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs, (u32)slots, wk.depth, wk.pivot});
+                desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs, (u32)slots, wk.depth, wk.pivot, ns > 256u ? nbig : 0u});
+                if (ns > 256u) { bigidx.push_back((u32)(w1 - w0)); nbig++; }
                 rows += (wk.m + 1u) & ~1u;
                 wgs += (wk.m + LS_WG_ROWS - 1u) / LS_WG_ROWS;
                 slots += nb;
@@ -1393,25 +1396,34 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
             const size_t over_cap = (size_t)(rows / LS_QUEUE_CAP) + 2;
             // scratch: en (u64 per row), bin (u32 per row); per splitter slot: two splitter words, three words for each of
             // its two ranges; per block: result, descriptor; per workgroup: its block; the batch's oversize ranges
-            ENSURE(c, c->ls_buf, rows * 12 + slots * 40 + nblk * (8 + sizeof(LsBlock)) + wgs * 4 + over_cap * sizeof(LsOver) + 512);
+            ENSURE(c, c->ls_buf, rows * 12 + slots * 40 + (size_t)nbig * (LS_SAMPLES * 16 + 4) + nblk * (8 + sizeof(LsBlock)) + wgs * 4 +
+                                     over_cap * sizeof(LsOver) + 512);
             u64 *p64 = c->ls_buf.as<u64>();
             LargeSplit ls{};
             ls.nblk = (u32)nblk;
             ls.en = p64;
             ls.spl_w = p64 + rows; ls.spl_x = ls.spl_w + slots;
-            LsBlock *dblk = reinterpret_cast<LsBlock *>(ls.spl_x + slots);
+            ls.smp_w = ls.spl_x + slots; ls.smp_x = ls.smp_w + (size_t)nbig * LS_SAMPLES;
+            LsBlock *dblk = reinterpret_cast<LsBlock *>(ls.smp_x + (size_t)nbig * LS_SAMPLES);
             ls.blk = dblk;
             ls.over = reinterpret_cast<LsOver *>(dblk + nblk);
             ls.bin = reinterpret_cast<u32 *>(ls.over + over_cap);
             ls.cnt = ls.bin + rows; ls.start = ls.cnt + 2 * slots; ls.cur = ls.start + 2 * slots;
             ls.wgblk = ls.cur + 2 * slots;
             ls.piv = ls.wgblk + wgs;
-            ls.res = ls.piv + nblk;
+            u32 *d_big = ls.piv + nblk;
+            ls.bigidx = d_big;
+            ls.res = d_big + nbig;
             ls.nover = ls.res + nblk;                               // (read back together with res)
+            if (nbig) HIPCHK(c, hipMemcpyAsync(d_big, bigidx.data(), (size_t)nbig * 4, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(dblk, desc.data(), nblk * sizeof(LsBlock), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemsetAsync(ls.nover, 0, 4, c->stream));
             if (small_ns) k_ls_splitters<256, 256><<<(u32)nblk, 256, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
-            if (big_ns) k_ls_splitters<LS_SAMPLES, 1024><<<(u32)nblk, 1024, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
+            if (big_ns) {
+                k_ls_splitters<LS_SAMPLES, 64, 1><<<nbig, 64, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
+                k_ls_sample_keys<<<dim3(nbig, LS_SAMPLES / 256), 256, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
+                k_ls_splitters<LS_SAMPLES, 1024, 2><<<nbig, 1024, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
+            }
             k_ls_bin<<<(u32)wgs, 256, 0, c->stream>>>(c->blue.as<u64>(), c->spn.as<u64>(), c->S, ls);
             if (small_nb) k_ls_plan<64><<<(u32)nblk, 64, 0, c->stream>>>(ls, sub);
             if (big_nb) k_ls_plan<LS_MAXBINS><<<(u32)nblk, LS_MAXBINS, 0, c->stream>>>(ls, sub);

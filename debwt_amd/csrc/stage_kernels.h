@@ -1619,10 +1619,11 @@ static_assert(LS_QUEUE_CAP <= BLUE_WAVE_CAP, "the queue is drained by the kernel
 #define LS_MAXBINS 1024                // splitters + 1
 #define LS_MAXR (2 * LS_MAXBINS)       // ranges: below splitter 0, equal to it, between 0 and 1, equal to 1, ...
 #define LS_WG_ROWS 1024u               // rows of ONE block a workgroup of the row kernels takes (four per thread)
-struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0, t0, depth, pivot; };  // row0: first scratch row; wg0: first workgroup of
+struct LsBlock { u64 b0, j0, row0; u32 m, nb, ns, wg0, t0, depth, pivot, sidx; };  // row0: first scratch row; wg0: first workgroup of
                                                                         // LS_WG_ROWS rows; t0: first splitter slot (ranges
                                                                         // from 2 t0); depth: window pairs already equal;
-                                                                        // pivot: 1 = keys of a pivot round (ls_row_key)
+                                                                        // pivot: 1 = keys of a pivot round (ls_row_key);
+                                                                        // sidx: which of the batch's blocks of > 256 samples
 struct LsOver { u32 blk, st, cnt, ties, adv; };                         // a range above BLUE_LDS_CAP rows: block of the
                                                                         // batch, first row, rows, 1 = rows tie with a
                                                                         // splitter, window pairs they are known to share
@@ -1634,6 +1635,7 @@ struct LsOver { u32 blk, st, cnt, ties, adv; };                         // a ran
 // pivot's, not necessarily among them).  All rows of a run that outlast the pivot's leave with the pivot's own t in one
 // range: with the pivot in the middle of the block a round halves what is left of a periodic stretch.
 #define LS_TCAP 65536u
+#define LS_PICK_PAIRS 48u
 __device__ __forceinline__ u32 ls_pivot_adv(u64 key) {
     return key < LS_TCAP ? (u32)key : (key == LS_TCAP ? LS_TCAP : (u32)(2 * LS_TCAP - key));
 }
@@ -1646,17 +1648,19 @@ struct LargeSplit {
     u32 *cnt, *start, *cur;           // per block: 2 nb ranges from 2 t0
     u32 *res;                         // per block: 1 = sub-block table full (nothing queued, nothing moved)
     u32 *piv;                         // per block of a pivot round: its pivot row (chosen by k_ls_splitters)
+    u64 *smp_w, *smp_x;               // per block of > 256 samples (LsBlock::sidx): LS_SAMPLES sample keys (k_ls_sample_keys)
+    const u32 *bigidx;                // those blocks (sidx -> block of the batch)
     LsOver *over; u32 *nover;         // oversize ranges of the batch (at most rows / LS_QUEUE_CAP of them), their number
 };
 // The key a round sorts row `i` of block B by: its next pair of SP windows (window round), or how far it follows the
 // block's pivot row `piv` (pivot round; second word 0).  e = the row's blue entry.
 __device__ __forceinline__ void ls_row_key(const u64 *__restrict__ blue, const u64 *__restrict__ spn, u64 S, const LsBlock &B, u32 piv, u32 i,
-                                           u64 e, u64 *kw, u64 *kx) {
+                                           u64 e, u64 *kw, u64 *kx, u32 tcap = LS_TCAP) {
     const u64 pos = (e >> 4) + (u64)B.depth * (2 * SP_WIN);
     if (B.pivot) {
         const u64 ppos = (blue[B.b0 + piv] >> 4) + (u64)B.depth * (2 * SP_WIN);
         u64 key = LS_TCAP;                                   // equal to the pivot for as long as we look
-        for (u32 t = 0; t < LS_TCAP && i != piv; t++) {
+        for (u32 t = 0; t < tcap && i != piv; t++) {
             const u64 a = pos + (u64)t * (2 * SP_WIN), b = ppos + (u64)t * (2 * SP_WIN);
             const bool la = a < S, lb = b < S;
             if (!la && !lb) break;                           // both behind the end: zeros from here on
@@ -1678,15 +1682,20 @@ __device__ __forceinline__ void ls_row_key(const u64 *__restrict__ blue, const u
 // splitters; the block's range counters are cleared and its workgroups of the row kernels are given its index.  NS:
 // the sample capacity of the instance (LDS); a block whose samples belong to the other instance is skipped -- most large
 // blocks are a few thousand rows with 64 samples, and 64 KB of LDS per workgroup for those leaves two workgroups per CU.
-template <u32 NS, u32 T>
+// The instance for blocks of more than 256 samples runs in two launches with k_ls_sample_keys between them (PHASE 1: the
+// pivot, the counters, the workgroup table; PHASE 2: the sort of the sample keys that kernel fetched): one workgroup
+// walking 4096 samples of a block of 10^6 rows of one long run, four per thread one after the other, took milliseconds per
+// round while the rest of the chip idled.
+template <u32 NS, u32 T, int PHASE = 0>
 __global__ __launch_bounds__(T) void k_ls_splitters(const u64 *__restrict__ blue, const u64 *__restrict__ spn, u64 S, LargeSplit ls) {
-    __shared__ u64 sw[NS], sx[NS];
+    __shared__ u64 sw[PHASE == 1 ? 1 : NS], sx[PHASE == 1 ? 1 : NS];
     __shared__ u32 s_cand, s_tmax, s_cnt, s_next;
-    const LsBlock B = ls.blk[blockIdx.x];
+    const u32 bi = NS < LS_SAMPLES ? blockIdx.x : ls.bigidx[blockIdx.x];   // (the large instance runs over the list of its blocks)
+    const LsBlock B = ls.blk[bi];
     const u32 tid = threadIdx.x, ns = B.ns;
     if ((NS < LS_SAMPLES) != (ns <= 256u)) return;
     u32 piv = B.m >> 1;
-    if (B.pivot) {
+    if (B.pivot && PHASE != 2) {
         // The pivot of a pivot round: a row that follows the block's periodic stretch for LONG.  The rows that outlast the
         // pivot all leave with the pivot's own t, in one range that needs another round; the rows the pivot outlasts leave
         // with their own t and are done -- so a pivot at the median run length halves the stretch per round (the middle
@@ -1707,7 +1716,9 @@ __global__ __launch_bounds__(T) void k_ls_splitters(const u64 *__restrict__ blue
                 r = (u32)(((u64)tid * B.m) >> 6);
                 if (r != cand) {
                     u64 kw, kx;
-                    ls_row_key(blue, spn, S, B, cand, r, blue[B.b0 + r], &kw, &kx);
+                    // (the choice looks LS_PICK_PAIRS pairs far: a stretch of 30,000 equal symbols is 700 pairs, walked one
+                    // dependent gather after the other -- rows that follow the candidate that far count as outlasting it)
+                    ls_row_key(blue, spn, S, B, cand, r, blue[B.b0 + r], &kw, &kx, LS_PICK_PAIRS);
                     t = ls_pivot_adv(kw);
                     mine = true;
                     atomicMax(&s_tmax, t);
@@ -1721,15 +1732,22 @@ __global__ __launch_bounds__(T) void k_ls_splitters(const u64 *__restrict__ blue
             __syncthreads();
         }
         piv = s_cand;
-        if (tid == 0) ls.piv[blockIdx.x] = piv;
+        if (tid == 0) ls.piv[bi] = piv;
     }
-    for (u32 i = tid; i < ns; i += T) {
-        const u32 r = (u32)(((u64)i * B.m) / ns);
-        ls_row_key(blue, spn, S, B, piv, r, blue[B.b0 + r], &sw[i], &sx[i]);
+    if (PHASE != 2) {
+        for (u32 i = tid; i < 2 * B.nb; i += T) { ls.cnt[2 * (size_t)B.t0 + i] = 0; ls.cur[2 * (size_t)B.t0 + i] = 0; }
+        const u32 nwg = (B.m + LS_WG_ROWS - 1) / LS_WG_ROWS;
+        for (u32 i = tid; i < nwg; i += T) ls.wgblk[B.wg0 + i] = bi;
     }
-    for (u32 i = tid; i < 2 * B.nb; i += T) { ls.cnt[2 * (size_t)B.t0 + i] = 0; ls.cur[2 * (size_t)B.t0 + i] = 0; }
-    const u32 nwg = (B.m + LS_WG_ROWS - 1) / LS_WG_ROWS;
-    for (u32 i = tid; i < nwg; i += T) ls.wgblk[B.wg0 + i] = blockIdx.x;
+    if (PHASE == 1) return;
+    if (PHASE == 2) {
+        for (u32 i = tid; i < ns; i += T) { sw[i] = ls.smp_w[(size_t)B.sidx * LS_SAMPLES + i]; sx[i] = ls.smp_x[(size_t)B.sidx * LS_SAMPLES + i]; }
+    } else {
+        for (u32 i = tid; i < ns; i += T) {
+            const u32 r = (u32)(((u64)i * B.m) / ns);
+            ls_row_key(blue, spn, S, B, piv, r, blue[B.b0 + r], &sw[i], &sx[i]);
+        }
+    }
     __syncthreads();
     for (u32 kk = 2; kk <= ns; kk <<= 1)
         for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
@@ -1747,6 +1765,18 @@ __global__ __launch_bounds__(T) void k_ls_splitters(const u64 *__restrict__ blue
         const u32 i = (b + 1) * (ns / B.nb) - 1;
         ls.spl_w[(size_t)B.t0 + b] = sw[i]; ls.spl_x[(size_t)B.t0 + b] = sx[i];
     }
+}
+// the sample keys of the blocks of more than 256 samples: 256 samples of one block per workgroup (grid: such blocks x LS_SAMPLES / 256)
+__global__ __launch_bounds__(256) void k_ls_sample_keys(const u64 *__restrict__ blue, const u64 *__restrict__ spn, u64 S, LargeSplit ls) {
+    const u32 bi = ls.bigidx[blockIdx.x];
+    const LsBlock B = ls.blk[bi];
+    const u32 i = blockIdx.y * 256u + threadIdx.x;
+    if (i >= B.ns) return;
+    const u32 piv = B.pivot ? ls.piv[bi] : 0u;
+    const u32 r = (u32)(((u64)i * B.m) / B.ns);
+    u64 kw, kx;
+    ls_row_key(blue, spn, S, B, piv, r, blue[B.b0 + r], &kw, &kx);
+    ls.smp_w[(size_t)B.sidx * LS_SAMPLES + i] = kw; ls.smp_x[(size_t)B.sidx * LS_SAMPLES + i] = kx;
 }
 // A workgroup takes LS_WG_ROWS consecutive rows of one block, four per thread: their keys are fetched (the gathers of a
 // thread's four rows are in flight together), every row finds its range by bisection over the block's splitters, staged in
@@ -1769,10 +1799,43 @@ __global__ __launch_bounds__(256) void k_ls_bin(const u64 *__restrict__ blue, co
     u64 e[4], w[4], x[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) e[j] = i0 + j * 256u < B.m ? blue[B.b0 + i0 + j * 256u] : 0ull;
+    if (B.pivot) {
+        // the four rows of a thread follow the pivot in step: their gathers of a pair are in flight together and the pivot's
+        // windows are fetched once per pair (four walks one after the other made a block of 10^6 rows of one long run -- too
+        // few workgroups to fill the chip -- four times as slow as one row per thread had been)
+        const u64 ppos = (blue[B.b0 + piv] >> 4) + (u64)B.depth * (2 * SP_WIN);
+        u64 pos[4];
+        bool live[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        w[j] = x[j] = 0ull;
-        if (i0 + j * 256u < B.m) ls_row_key(blue, spn, S, B, piv, i0 + j * 256u, e[j], &w[j], &x[j]);
+        for (int j = 0; j < 4; j++) {
+            const u32 i = i0 + j * 256u;
+            pos[j] = (e[j] >> 4) + (u64)B.depth * (2 * SP_WIN);
+            live[j] = i < B.m && i != piv;
+            w[j] = LS_TCAP; x[j] = 0ull;                      // equal to the pivot for as long as we look
+        }
+        for (u32 t = 0; t < LS_TCAP && (live[0] || live[1] || live[2] || live[3]); t++) {
+            const u64 b = ppos + (u64)t * (2 * SP_WIN);
+            const bool lb = b < S;
+            const u64 bw = lb ? sp_window(spn, b) : 0ull, bx = lb ? sp_window(spn, b + SP_WIN) : 0ull;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!live[j]) continue;
+                const u64 a = pos[j] + (u64)t * (2 * SP_WIN);
+                const bool la = a < S;
+                if (!la && !lb) { live[j] = false; continue; }   // both behind the end: zeros from here on
+                const u64 aw = la ? sp_window(spn, a) : 0ull, ax = la ? sp_window(spn, a + SP_WIN) : 0ull;
+                if (aw != bw || ax != bx) {
+                    w[j] = (aw != bw ? aw < bw : ax < bx) ? (u64)t : (u64)(2 * LS_TCAP - t);
+                    live[j] = false;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            w[j] = x[j] = 0ull;
+            if (i0 + j * 256u < B.m) ls_row_key(blue, spn, S, B, piv, i0 + j * 256u, e[j], &w[j], &x[j]);
+        }
     }
     __syncthreads();
 #pragma unroll
