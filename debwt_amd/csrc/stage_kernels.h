@@ -671,6 +671,9 @@ struct SpBlockIds {
 #ifndef SP_FLAGS_WAVES
 #define SP_FLAGS_WAVES 4
 #endif
+#ifndef SP_EMIT_STAGE
+#define SP_EMIT_STAGE 1                // k_sp_emit: SP symbols of a tile through LDS and out as aligned words (0: a byte store per symbol)
+#endif
 #ifndef SP_PROBE_BATCH
 #define SP_PROBE_BATCH 2               // home slots of the node table requested per lane before the first is used (measured at 30 Gbp,
                                        // SP stage: 1 -> 424.4 ms, 2 -> 405.0, 4 -> 412.9, 8 -> 410.8; profiles/r05_experiments.txt)
@@ -906,6 +909,16 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
                                                           const u32 *__restrict__ off_mo,
                                                           const u32 *__restrict__ off_mi) {
     __shared__ u32 tmp[2 * DEBWT_WAVES];
+#if SP_EMIT_STAGE
+    // the SP symbols of a tile (at most 32 per lane) are gathered in LDS and leave as aligned 4-byte words: a lane's own
+    // ~3.4 symbols written byte by byte cost the pass a store instruction per symbol
+    __shared__ __attribute__((aligned(16))) u8 ssym[DEBWT_BLOCK * 32 + 16];
+    // ... and so do the routed blue entries and the block ids they are made of (a lane's ~3.4 entries lie ~27 bytes from its
+    // neighbour's: every store instruction of a wave touched ~14 lines): tiles of up to SP_EMIT_CAP multi-in positions
+    constexpr u32 SP_EMIT_CAP = 2048;
+    __shared__ u32 sq[SP_EMIT_CAP];
+    __shared__ u64 sr[SP_EMIT_CAP];
+#endif
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < ngroups ? beg + chunk : ngroups;
     u64 base_mo = (u64)off_mo[blockIdx.x] + a.sp_base;
@@ -920,11 +933,27 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
         u64 off = base_mo + ex[0];
         u32 omi = base_mi + ex[1];
         u32 all = mo | mi;
+#if SP_EMIT_STAGE
+        u32 ls_o = ex[0];
+#endif
         u64 w0 = 0, w1 = 0, wp = 0, sbp = 0;
         // block ids of the lane: its run starts at the wave's base + the lane's rank in the wave (the waves of this
         // tile are the waves of pass 1); read 4 ahead of their use
         const u32 *qrun = nullptr;
         u32 qn = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+#if SP_EMIT_STAGE
+        const bool staged = a.routed && tot[1] <= SP_EMIT_CAP;               // (uniform)
+        u32 lr_o = ex[1];
+        if (staged) {
+            // every wave brings its own run of block ids in, 64 at a time
+            const u32 wex0 = __shfl(ex[1], 0, 64), wcnt = __shfl(ex[1] + (u32)__popc(mi), 63, 64) - wex0;
+            if (wcnt) {
+                const u32 *run = a.ids.list + a.ids.wave_base[((tile + a.g0 + (threadIdx.x & ~63u)) - a.ids.g0) >> 6];
+                for (u32 j = threadIdx.x & 63u; j < wcnt; j += 64) sq[wex0 + j] = run[j];
+            }
+            __syncthreads();
+        } else
+#endif
         if (a.routed) {
             const u32 wex = ex[1] - __shfl(ex[1], 0, 64);
             if (mi) {
@@ -953,6 +982,12 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
                 if (i == 0) pred = 5;
                 else if ((sbp >> t) & 1ull) pred = 4;          // bit t of sbp = position i-1
                 else pred = t ? ((w0 >> (2 * (32 - t))) & 3ull) : (wp & 3ull);
+#if SP_EMIT_STAGE
+                if (staged) {
+                    sr[lr_o] = ((u64)sq[lr_o] << a.qshift) | (off << 3) | pred;
+                    lr_o++;
+                } else
+#endif
                 if (a.routed) {
                     a.routed[omi++] = ((u64)q0 << a.qshift) | (off << 3) | pred;
                     q0 = q1; q1 = q2; q2 = q3;
@@ -968,9 +1003,31 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_sp_emit(SpEmitArgs a, u64 ngrou
                 u8 sy;
                 if ((sbn >> b) & 1ull) sy = (j == a.n - 1) ? 5 : 4;
                 else sy = (u8)((b < 32 ? w0 >> (2 * (31 - b)) : w1 >> (2 * (63 - b))) & 3ull);
+#if SP_EMIT_STAGE
+                ssym[ls_o++] = sy; off++;
+#else
                 a.spsym[off++] = sy;
+#endif
             }
         }
+#if SP_EMIT_STAGE
+        __syncthreads();
+        {
+            const u32 ntot = tot[0];
+            const u32 head = (u32)((0ull - base_mo) & 3ull) < ntot ? (u32)((0ull - base_mo) & 3ull) : ntot;   // bytes before the first aligned word
+            if (threadIdx.x < head) a.spsym[base_mo + threadIdx.x] = ssym[threadIdx.x];
+            const u32 nw = (ntot - head) >> 2;
+            u32 *dw = reinterpret_cast<u32 *>(a.spsym + base_mo + head);
+            for (u32 j = threadIdx.x; j < nw; j += DEBWT_BLOCK) {
+                const u32 o = head + 4u * j;
+                dw[j] = (u32)ssym[o] | ((u32)ssym[o + 1] << 8) | ((u32)ssym[o + 2] << 16) | ((u32)ssym[o + 3] << 24);
+            }
+            const u32 done = head + 4u * nw;
+            if (threadIdx.x < ntot - done) a.spsym[base_mo + done + threadIdx.x] = ssym[done + threadIdx.x];
+            if (staged)
+                for (u32 j = threadIdx.x; j < tot[1]; j += DEBWT_BLOCK) a.routed[base_mi + j] = sr[j];
+        }
+#endif
         base_mo += tot[0]; base_mi += tot[1];
     }
 }
