@@ -1593,14 +1593,20 @@ extern "C" int debwt_blue_sort(debwt_ctx *c) {
 static u64 shard_rows(const debwt_ctx *c) { return c->Mctx + (c->s1 - c->s0); }
 
 // assembles the 8192-row blocks [b0, b1) of this shard's rows (all of them: b1 = ~0)
-static int run_assemble(debwt_ctx *c, u8 *rowsym, u64 b0 = 0, u64 b1 = ~0ull) {
+// The '#' rows: collections of up to 2^20 records have k_assemble append them to a list (c->hash_rows, counter in the
+// spare word 6 behind the '$' row) that assemble_finish sorts; collections of more records (read sets: n is small against
+// N there) mark them in hmask and find them by one counting pass over the mask words, as every collection did before.
+static bool hash_rows_by_list(const debwt_ctx *c) { return c->nrec <= (1ull << 20) && !(c->cfg.reserved & 2097152); }   // bit 21: masks (tests)
+static int run_assemble(debwt_ctx *c, u8 *rowsym, u64 b0 = 0, u64 b1 = ~0ull, bool collect = true) {
     const u64 rows = shard_rows(c);
     const u64 nb = (((rows + 31) >> 5) + DEBWT_BLOCK - 1) / DEBWT_BLOCK;
     b1 = std::min(b1, nb);
     if (b0 >= b1) return DEBWT_OK;
+    const bool list = collect && hash_rows_by_list(c);
     k_assemble<<<(u32)(b1 - b0), DEBWT_BLOCK, 0, c->stream>>>(
         c->mchar.as<u8>(), c->Mctx, c->sprow.as<u64>() + c->s0, c->spchr.as<u8>() + c->s0, c->s1 - c->s0, rows,
-        c->bwt.as<u64>(), c->hmask.as<u32>(), c->dollar.as<u64>(), rowsym, b0);
+        c->bwt.as<u64>(), c->hmask.as<u32>(), c->dollar.as<u64>(), rowsym, b0, list ? c->hash_rows.as<u64>() : nullptr,
+        reinterpret_cast<unsigned long long *>(c->dollar.as<u64>() + 6));
     return DEBWT_OK;
 }
 
@@ -1608,9 +1614,26 @@ static int run_assemble(debwt_ctx *c, u8 *rowsym, u64 b0 = 0, u64 b1 = ~0ull) {
 static int assemble_finish(debwt_ctx *c) {
     int rc;
     u64 nw = (shard_rows(c) + 31) >> 5;
-    HashRowsF fh{c->hmask.as<u32>(), c->hash_rows.as<u64>()};
-    if ((rc = cp_count(c, fh, nw, cp_area(c, 0), 9))) return rc;
-    if ((rc = cp_emit(c, fh, nw, cp_area(c, 0)))) return rc;
+    if (hash_rows_by_list(c)) {
+        u64 *h_cnt = reinterpret_cast<u64 *>(&c->h_scalars[40]);                   // (8-byte aligned pair of the pinned words)
+        HIPCHK(c, hipMemcpyAsync(h_cnt, c->dollar.as<u64>() + 6, 8, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = sync_check(c))) return rc;
+        const u64 cnt = *h_cnt;
+        if (cnt > c->nrec) { c->err = "more '#' rows than records"; return DEBWT_EINTERNAL; }
+        c->h_scalars[9] = (u32)cnt;
+        if (cnt > 1) {                                                              // ascending (src/insertCase3.c:86-97 walks the rows in order)
+            ENSURE(c, c->large_k0, cnt * 8 + 64);
+            ENSURE(c, c->rs_over, radix_over_bytes(cnt));
+            hipError_t e = hipSuccess;
+            u64 *r = radix_sort_bits(c->stream, c->hash_rows.as<u64>(), c->large_k0.as<u64>(), cnt, 0, bits_for(shard_rows(c)), radix_ws(c), &e);
+            if (e != hipSuccess) { c->err = std::string("'#' row sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
+            if (r != c->hash_rows.as<u64>()) HIPCHK(c, hipMemcpyAsync(c->hash_rows.p, r, cnt * 8, hipMemcpyDeviceToDevice, c->stream));
+        }
+    } else {
+        HashRowsF fh{c->hmask.as<u32>(), c->hash_rows.as<u64>()};
+        if ((rc = cp_count(c, fh, nw, cp_area(c, 0), 9))) return rc;
+        if ((rc = cp_emit(c, fh, nw, cp_area(c, 0)))) return rc;
+    }
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     if ((rc = sync_check(c))) return rc;
     c->n_hash_local = c->h_scalars[9];
@@ -1641,6 +1664,7 @@ extern "C" int debwt_bwt_assemble(debwt_ctx *c) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     HIPCHK(c, hipMemsetAsync(c->dollar.p, 0xFF, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dollar.as<u64>() + 6, 0, 8, c->stream));
     run_assemble(c, nullptr);
     return assemble_finish(c);
 }
@@ -1759,6 +1783,7 @@ extern "C" int debwt_build_to_host(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_r
     if (!c->ev_copy) HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     HIPCHK(c, hipMemsetAsync(c->dollar.p, 0xFF, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dollar.as<u64>() + 6, 0, 8, c->stream));
     c->st.blue_max_block = 0;
     BlueQueue bq{};
     if (c->Q && (rc = blue_queue(c, &bq))) return rc;
@@ -2325,7 +2350,7 @@ extern "C" int debwt_fetch_array(debwt_ctx *c, debwt_array which, void *dst, uin
         case DEBWT_ARR_ROW_SYMBOLS: {
             if (c->stage < ST_ASSEMBLED) return DEBWT_ESTATE;
             ENSURE(c, c->rowsym, c->n + 64);
-            run_assemble(c, c->rowsym.as<u8>());
+            run_assemble(c, c->rowsym.as<u8>(), 0, ~0ull, false);      // (symbols only: the '#' rows of the build stay as they are)
             int rc = sync_check(c);
             if (rc) return rc;
             src = c->rowsym.p; cnt = c->n; esz = 1; need = ST_ASSEMBLED;

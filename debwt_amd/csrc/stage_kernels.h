@@ -2081,7 +2081,10 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_assemble(const u8 *__restrict__
                                                            const u8 *__restrict__ spchr, u64 NS, u64 n,
                                                            u64 *__restrict__ bwt, u32 *__restrict__ hmask,
                                                            u64 *__restrict__ dollar_row, u8 *__restrict__ rowsym,
-                                                           u64 block0) {
+                                                           u64 block0, u64 *__restrict__ hlist,
+                                                           unsigned long long *__restrict__ hcount) {
+    // hlist: the rows that carry '#' are appended there (any order; the host sorts the nrec - 1 of them) and hmask is not
+    // written -- a collection of few records then needs no pass over n / 32 mask words to find them.  nullptr: hmask.
     // block0: first 8192-row block of this launch (a build that hands finished row ranges to the host as it goes
     // assembles them range by range)
     __shared__ u32 sm[ASM_ROWS / 4 + 12];
@@ -2125,7 +2128,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_assemble(const u8 *__restrict__
         }
         if (!(bad & 0xFCFCFCFCu)) {                                // no '#' / '$' among them
             bwt[w] = word;
-            hmask[w] = 0;
+            if (!hlist) hmask[w] = 0;
             return;
         }
     }
@@ -2142,7 +2145,11 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_assemble(const u8 *__restrict__
         word |= (u64)c << ((31 - t) << 1);
     }
     bwt[w] = word;
-    hmask[w] = hm;
+    if (!hlist) hmask[w] = hm;
+    else if (hm) {
+        unsigned long long o = atomicAdd(hcount, (unsigned long long)__popc(hm));
+        while (hm) { const u32 t = (u32)__ffs(hm) - 1u; hm &= hm - 1u; hlist[o++] = r0 + t; }
+    }
 }
 struct HashRowsF {
     const u32 *hmask; u64 *hash_rows;

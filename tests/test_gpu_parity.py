@@ -1004,3 +1004,27 @@ def test_inputs_outside_the_reference_domain_equal_the_definition(api, oracle, n
                 got = oracle.unpack_bwt(w, n, h, dr)
                 assert np.array_equal(got, want), (name, k, cap, device_special)
                 assert len(h) == len(recs) - 1 and (len(h) < 2 or bool((np.diff(h.astype(np.int64)) > 0).all()))
+
+
+@pytest.mark.parametrize("entry", [e for e in MANIFEST if e["k"] == 32 and (e["records"] >= 2000 or e["name"] in ("special_branches", "ecoli_4.6M"))][:4],
+                         ids=golden_id)
+def test_hash_rows_by_list_and_by_mask_are_the_reference_rows(api, entry):
+    """The '#' rows (OUT.#, src/insertCase3.c:86-97): collections of up to 2^20 records have the assembly kernel append them to
+    a list that is sorted afterwards, larger ones (and cfg.reserved bit 21) mark them in a mask per 32 rows and count -- the
+    same rows, the reference's, either way; single- and multi-range, streamed to the host or fetched."""
+    recs = golden_records(entry)
+    sha = entry["sha256"]
+    for tune in (0, 1 << 21):
+        for cap in (0, 4096):
+            d = api.DeBWT(k=32, tune=tune)
+            if cap:
+                d.set_range_cap(cap)
+            d.load_records(recs)
+            d.build()
+            words, hrows, drow = d.fetch()
+            assert _sha(hrows) == sha["hash"] and _sha(words) == sha["bwt"] and _sha(np.array([drow], dtype=np.uint64)) == sha["dollar"], (tune, cap)
+            n = sum(len(r) for r in recs) + len(recs)
+            w2 = np.zeros((n + 31) // 32, dtype=np.uint64); h2 = np.zeros(max(len(recs) - 1, 1), dtype=np.uint64); d2 = np.zeros(1, dtype=np.uint64)
+            d.build_into(w2, h2, d2)
+            assert _sha(h2[:len(recs) - 1]) == sha["hash"] and _sha(w2) == sha["bwt"], (tune, cap, "streamed")
+            d.close()
