@@ -754,6 +754,9 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
 #define RLW_CAP 1024                   // keys a single wave finishes (16 per lane, no barriers at all)
 #define RLW_H (RLW_CAP * 7 / 8)
 #define RLU_LONG 16u                   // unfit stretches of this many raster tiles or more: run-length encoded by several workgroups
+#ifndef RLU_LONG_NT
+#define RLU_LONG_NT 128                //   threads of a workgroup of the long-stretch launch
+#endif
 #define RLU_ROWS 64                    //   grid rows of that launch
 #ifndef RL_MAX_ROUNDS
 #define RL_MAX_ROUNDS 16               // merge-split rounds before a wave tile falls back to the full network
@@ -1566,13 +1569,14 @@ __global__ __launch_bounds__(256) void rs_tile_emit_kernel(const u64 *__restrict
 // list (rs_local_count), the workgroups of grid row y take the pieces y, y + gridDim.y, ... of a stretch (a repeat
 // family with 10^6 copies gives stretches of millions of keys that one workgroup used to walk alone).
 template <int EMIT, int LONG>
-__global__ __launch_bounds__(256) void rs_unfit_rle_kernel(const u64 *__restrict__ keys, u64 n,
+__global__ __launch_bounds__(LONG ? RLU_LONG_NT : 256) void rs_unfit_rle_kernel(const u64 *__restrict__ keys, u64 n,
                                                            const u64 *__restrict__ bnd, u32 nwtiles,
                                                            const u32 *__restrict__ unfit, const u32 *__restrict__ nunfit,
                                                            u32 *__restrict__ tcnt, const u32 *__restrict__ tex,
                                                            const u32 *__restrict__ boff, u64 *__restrict__ dk,
                                                            u32 *__restrict__ dstart, u8 *__restrict__ mchar, int staging_ok) {
-    constexpr u32 V = 8, STEP = 256 * V;
+    // (the pieces of the long stretches are 896 keys: workgroups of RLU_LONG_NT threads, so that twice as many of them are in flight)
+    constexpr u32 NT = LONG ? RLU_LONG_NT : 256, V = 8, STEP = NT * V;
     __shared__ u32 wsum[4];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const u32 nu = LONG ? nunfit[2] : nunfit[0];
@@ -1600,7 +1604,7 @@ __global__ __launch_bounds__(256) void rs_unfit_rle_kernel(const u64 *__restrict
                 if (!EMIT) { if (tid == 0) tcnt[t + k] = ps == s ? 1u : 0u; continue; }
                 if (tid == 0 && ps == s) { dk[run] = kfirst; dstart[run] = (u32)s; }
                 const u8 sy = (u8)(kfirst & 3);
-                for (u64 j = ps + tid; j < pe; j += 256) mchar[j] = sy;
+                for (u64 j = ps + tid; j < pe; j += NT) mchar[j] = sy;
                 continue;
             }
             for (u64 p = ps; p < pe; p += STEP) {
@@ -1630,7 +1634,7 @@ __global__ __launch_bounds__(256) void rs_unfit_rle_kernel(const u64 *__restrict
                 __syncthreads();
                 u32 before = incl - cnt, tot = 0;
 #pragma unroll
-                for (u32 x = 0; x < 4; x++) { const u32 v = wsum[x]; before += x < w ? v : 0u; tot += v; }
+                for (u32 x = 0; x < NT / 64; x++) { const u32 v = wsum[x]; before += x < w ? v : 0u; tot += v; }
                 if (EMIT && j0 < pe) {
                     u64 off = (u64)run + before;
 #pragma unroll
@@ -1899,7 +1903,7 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
         const u32 nb = (nwtiles + RLT_BLOCK - 1) / RLT_BLOCK;
         rs_unfit_rle_kernel<0, 0><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
                                                        rle_boff, sink->dk, sink->dstart, sink->mchar, staging_lost ? 0 : 1);
-                rs_unfit_rle_kernel<0, 1><<<dim3(64, RLU_ROWS), 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
+                rs_unfit_rle_kernel<0, 1><<<dim3(64, RLU_ROWS), RLU_LONG_NT, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
                                                        rle_boff, sink->dk, sink->dstart, sink->mchar, staging_lost ? 0 : 1);
         rs_tile_scan1_kernel<<<nb, 256, 0, stream>>>(rle_tcnt, nwtiles, rle_tex, rle_bsum);
         rs_tile_scan2_kernel<<<1, 1024, 0, stream>>>(rle_bsum, nb, rle_boff, rle_ctr + 1);
@@ -1907,7 +1911,7 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
                                                                    rle_tcnt, staging_lost ? nullptr : other);
         rs_unfit_rle_kernel<1, 0><<<ug, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
                                                        rle_boff, sink->dk, sink->dstart, sink->mchar, staging_lost ? 0 : 1);
-                rs_unfit_rle_kernel<1, 1><<<dim3(64, RLU_ROWS), 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
+                rs_unfit_rle_kernel<1, 1><<<dim3(64, RLU_ROWS), RLU_LONG_NT, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, rle_tcnt, rle_tex,
                                                        rle_boff, sink->dk, sink->dstart, sink->mchar, staging_lost ? 0 : 1);
         (void)hipMemcpyAsync(sink->h_total, rle_ctr + 1, sizeof(u32), hipMemcpyDeviceToHost, stream);
         if (sink->h_ctr) (void)hipMemcpyAsync(sink->h_ctr, rle_ctr, 4 * sizeof(u32), hipMemcpyDeviceToHost, stream);
