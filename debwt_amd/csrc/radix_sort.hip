@@ -1593,6 +1593,9 @@ __global__ __launch_bounds__(LONG ? RLU_LONG_NT : 256) void rs_unfit_rle_kernel(
         // (a stretch the classifying kernel counted has its whole count in the slot of its first tile: one piece)
         const u32 K = (K64 < 1 || (!LONG && (entry & RLU_COUNTED))) ? 1u : (u32)K64;
         if (!LONG && K >= RLU_LONG) continue;                                // the long list's
+        if (LONG && blockIdx.y >= K) continue;                               // no piece of this stretch for this grid row: on to the
+                                                                             // next before its keys are asked for (most stretches
+                                                                             // have fewer pieces than the grid has rows)
         const u64 kfirst = keys[s];
         const bool one_run = kfirst == keys[e - 1];                          // sorted: every key of the stretch is equal
         for (u32 k = LONG ? blockIdx.y : 0u; k < K; k += LONG ? gridDim.y : 1u) {
@@ -1637,13 +1640,19 @@ __global__ __launch_bounds__(LONG ? RLU_LONG_NT : 256) void rs_unfit_rle_kernel(
                 for (u32 x = 0; x < NT / 64; x++) { const u32 v = wsum[x]; before += x < w ? v : 0u; tot += v; }
                 if (EMIT && j0 < pe) {
                     u64 off = (u64)run + before;
+                    if (j0 + V <= pe && (reinterpret_cast<uintptr_t>(mchar + j0) & 7u) == 0) {   // the thread's eight row symbols as one word
+                        u64 sy = 0;
+#pragma unroll
+                        for (u32 q = 0; q < V; q++) sy |= (kk[1 + q] & 3ull) << (8 * q);
+                        *reinterpret_cast<u64 *>(mchar + j0) = sy;
+                    } else {
+#pragma unroll
+                        for (u32 q = 0; q < V; q++) if (j0 + q < pe) mchar[j0 + q] = (u8)(kk[1 + q] & 3);
+                    }
 #pragma unroll
                     for (u32 q = 0; q < V; q++) {
                         const u64 j = j0 + q;
-                        if (j < pe) {
-                            mchar[j] = (u8)(kk[1 + q] & 3);
-                            if ((heads >> q) & 1u) { dk[off] = kk[1 + q]; dstart[off] = (u32)j; off++; }
-                        }
+                        if (j < pe && ((heads >> q) & 1u)) { dk[off] = kk[1 + q]; dstart[off] = (u32)j; off++; }
                     }
                 }
                 run += tot;
