@@ -625,7 +625,7 @@ static int special_device_build(debwt_ctx *c, bool release_arena = true) {
     const size_t oX = take(NS * 8 + 64), oY = take(NS * 8 + 64);
     const size_t o_ord = take(N * 4), o_gid = take(N * 4), o_actA = take(N * 4), o_actB = take(N * 4), o_val = take(N * 8);
     const size_t o_recs = take(N * 4), o_vals = take(N * 8), o_gids = take(N * 4), o_ordv = take(N * 4);
-    const size_t o_head = take((N + 1) * 4), o_stay = take(N), o_rank = take(N * 4);
+    const size_t o_head = take((N + 1) * 4), o_stay = take(N), o_rank = take(N * 4), o_dep = take(N * 4), o_gmin = take(N * 4);
     const size_t o_grp = take(NS * 4), o_gflag = take(NS), o_headf = take(NS), o_spd = take(NS), o_item = take(NS * 16), o_bnd = take(64);
     ENSURE(c, c->sx, off);
     ENSURE(c, c->sppos, NS * 8 + 64);
@@ -637,7 +637,7 @@ static int special_device_build(debwt_ctx *c, bool release_arena = true) {
     u32 *ord = (u32 *)(base + o_ord), *gid = (u32 *)(base + o_gid), *act = (u32 *)(base + o_actA), *act2 = (u32 *)(base + o_actB);
     u64 *valbuf = (u64 *)(base + o_val), *val_s = (u64 *)(base + o_vals);
     u32 *rec_s = (u32 *)(base + o_recs), *gid_s = (u32 *)(base + o_gids), *ordv = (u32 *)(base + o_ordv);
-    u32 *headpos = (u32 *)(base + o_head), *rank = (u32 *)(base + o_rank);
+    u32 *headpos = (u32 *)(base + o_head), *rank = (u32 *)(base + o_rank), *dep = (u32 *)(base + o_dep), *gmin = (u32 *)(base + o_gmin);
     u8 *stay = base + o_stay;
     u32 *grp = (u32 *)(base + o_grp);
     u8 *gflag = base + o_gflag, *headf = base + o_headf, *spd = base + o_spd;
@@ -659,8 +659,10 @@ static int special_device_build(debwt_ctx *c, bool release_arena = true) {
     const u64 max_rounds = env_rounds ? strtoull(env_rounds, nullptr, 10) : 64ull;
     u64 na = N > 1 ? N : 0;
     bool one_group = true;
+    const bool host_ties = getenv("DEBWT_SPECIAL_HOST_TIES") != nullptr;     // tests, A/B: the long-tied groups by host comparison
+    bool jumping = false;
     for (u64 w = 0; na; w++) {
-        if (w >= max_rounds) {
+        if (w >= max_rounds && host_ties) {
             // records identical for max_rounds * 21 symbols and more: the few groups left are ordered on the host
             std::vector<u32> h_ord(N), h_gid(N), h_act(na);
             HIPCHK(c, hipMemcpyAsync(h_ord.data(), ord, N * 4, hipMemcpyDeviceToHost, c->stream));
@@ -672,8 +674,16 @@ static int special_device_build(debwt_ctx *c, bool release_arena = true) {
             if ((rc = sync_check(c))) return rc;
             break;
         }
+        if (w >= max_rounds) {
+            // ... on the device: jump rounds (special_kernels.h) -- every group's depth advances by the windows all its members
+            // share with its head, then the window round below tells at least one member apart
+            if (!jumping) { k_sx_depth_init<<<grid(na), 256, 0, c->stream>>>(act, na, (u32)w, dep); jumping = true; }
+            HIPCHK(c, hipMemsetAsync(gmin, 0xFF, N * 4, c->stream));
+            k_sx_lcp_min<<<grid(na * 64), 256, 0, c->stream>>>(T, ord, gid, act, na, dep, gmin);
+            k_sx_depth_add<<<grid(na), 256, 0, c->stream>>>(gid, act, na, gmin, dep, 0u);
+        }
         const int bA = bits_for(na - 1);
-        k_sx_round_keys<<<grid(na), 256, 0, c->stream>>>(T, ord, act, na, w, bA, valbuf, X);
+        k_sx_round_keys<<<grid(na), 256, 0, c->stream>>>(T, ord, act, na, w, bA, valbuf, X, jumping ? dep : nullptr);
         // three stable sorts, least significant field first: low 32 bits of the window, its high 31 bits, the tie group
         u64 *r = lsd(X, Y, na, bA, bA + 32);
         if (!r) return DEBWT_EDEVICE;
@@ -698,6 +708,7 @@ static int special_device_build(debwt_ctx *c, bool release_arena = true) {
         na = c->h_scalars[21];
         std::swap(act, act2);
         one_group = false;
+        if (jumping && na) k_sx_depth_add<<<grid(na), 256, 0, c->stream>>>(gid, act, na, nullptr, dep, 1u);   // the window just used
     }
     k_sx_rank_of<<<grid(N), 256, 0, c->stream>>>(ord, N, rank);
 

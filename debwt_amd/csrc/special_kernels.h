@@ -58,12 +58,14 @@ __global__ __launch_bounds__(256) void k_sx_init(u32 *__restrict__ ord, u32 *__r
     ord[j] = (u32)j; gid[j] = 0; act[j] = (u32)j;
 }
 
-// window of round w for the a-th active place; first sort key = low 32 bits of the window | a
+// window of round w for the a-th active place; first sort key = low 32 bits of the window | a.  dep != nullptr: the
+// window at the place's own depth (jump rounds, below) instead of the common w
 __global__ __launch_bounds__(256) void k_sx_round_keys(SxText T, const u32 *__restrict__ ord, const u32 *__restrict__ act, u64 na, u64 w,
-                                int bA, u64 *__restrict__ valbuf, u64 *__restrict__ keyA) {
+                                int bA, u64 *__restrict__ valbuf, u64 *__restrict__ keyA, const u32 *__restrict__ dep) {
     const u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= na) return;
     const u64 j = ord[act[a]];
+    if (dep) w = dep[act[a]];
     const u64 val = sx_window3(T.text, T.sepbits, T.n, T.rec_start(j) + 21ull * w);
     valbuf[a] = val;
     keyA[a] = ((val & 0xFFFFFFFFull) << bA) | a;
@@ -110,6 +112,46 @@ __global__ __launch_bounds__(256) void k_sx_apply(const u32 *__restrict__ rec_s,
     ord[p] = rec_s[f];
     gid[p] = act[h];
     stay[f] = sz > 1u;
+}
+// Jump rounds, for record starts that stay tied for long (duplicated contigs: thousands of symbols, a window round sheds
+// 21).  All places of a tie group share one depth (windows already known equal).  Every member walks on beside the
+// head of its group until a window differs; the fewest windows any member of the group shares with the head, all members
+// share with each other: the group's depth advances by that many at once, and the window round that follows tells at
+// least one member apart.  A group of g records is done in at most g - 1 such rounds, however long its records tie.
+__global__ __launch_bounds__(256) void k_sx_depth_init(const u32 *__restrict__ act, u64 na, u32 w, u32 *__restrict__ dep) {
+    const u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < na) dep[act[a]] = w;
+}
+// (one WAVE per active place: its lanes compare 64 consecutive windows at a time -- a duplicated contig of 80 kb is 3,800
+// windows, walked by one thread one dependent gather after the other it cost milliseconds per round)
+__global__ __launch_bounds__(256) void k_sx_lcp_min(SxText T, const u32 *__restrict__ ord, const u32 *__restrict__ gid, const u32 *__restrict__ act,
+                             u64 na, const u32 *__restrict__ dep, u32 *__restrict__ gmin) {
+    const u64 a = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u32 lane = threadIdx.x & 63u;
+    if (a >= na) return;
+    const u32 p = act[a], h = gid[p];                         // h: the place of the group's head
+    if (p == h) return;
+    const u64 pj = T.rec_start(ord[p]) + 21ull * dep[p], ph = T.rec_start(ord[h]) + 21ull * dep[p];
+    // (two different suffixes differ at the latest where the one nearer the end reaches '$': windows behind that are not
+    // read -- a lane whose window would start behind the text reports a difference)
+    for (u32 t0 = 0;; t0 += 64) {
+        const u64 qj = pj + 21ull * (t0 + lane), qh = ph + 21ull * (t0 + lane);
+        const bool diff = qj >= T.n || qh >= T.n ||
+                          sx_window3(T.text, T.sepbits, T.n, qj) != sx_window3(T.text, T.sepbits, T.n, qh);
+        const u64 m = __ballot(diff);
+        if (m) {
+            if (lane == 0) atomicMin(&gmin[h], t0 + (u32)__ffsll((long long)m) - 1u);
+            return;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_sx_depth_add(const u32 *__restrict__ gid, const u32 *__restrict__ act, u64 na,
+                               const u32 *__restrict__ gmin, u32 *__restrict__ dep, u32 plus) {
+    const u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= na) return;
+    const u32 p = act[a];
+    const u32 m = gmin ? gmin[gid[p]] : 0u;
+    dep[p] += (m == 0xFFFFFFFFu ? 0u : m) + plus;
 }
 struct SxStayF {
     const u8 *stay; const u32 *act; u32 *act_new;

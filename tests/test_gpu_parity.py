@@ -171,15 +171,19 @@ def test_hundred_thousand_records_equal_oracle(api, oracle):
 
 
 @pytest.mark.parametrize("case", ["adversarial", "reads", "contigs_dup", "reads_20000", "single_record"])
-@pytest.mark.parametrize("max_rounds", [None, 2])
+@pytest.mark.parametrize("max_rounds", [None, 2, 0, "2 on the host"])
 def test_special_region_tables_device_equals_host(api, case, max_rounds, monkeypatch):
     """the special-region tables (suffix order of the N*K special suffixes, their keys and BWT symbols, the
     special branches, head and tail nodes: src/collect#$.c:118-157,428-455,468-598) built by the device module against
-    the host module, element by element (debwt_special_compare); max_rounds = 2 sends every tie group of record starts
-    that is still tied after 42 symbols to the host comparison (the path of records identical for thousands of symbols)."""
+    the host module, element by element (debwt_special_compare); max_rounds = 2 (0) puts every tie group of record starts
+    that is still tied after 42 symbols (every group) through the JUMP rounds -- the path of records identical for thousands
+    of symbols: the group's depth advances by what all its members share with its head, then one window round -- and
+    "2 on the host" through the host comparison that did this job until round 5 (DEBWT_SPECIAL_HOST_TIES)."""
     from debwt_amd import synth
     if max_rounds is not None:
-        monkeypatch.setenv("DEBWT_SPECIAL_MAX_ROUNDS", str(max_rounds))
+        monkeypatch.setenv("DEBWT_SPECIAL_MAX_ROUNDS", str(max_rounds).split()[0])
+        if "host" in str(max_rounds):
+            monkeypatch.setenv("DEBWT_SPECIAL_HOST_TIES", "1")
     rng = np.random.default_rng(4242)
     if case == "adversarial":
         sets = [(_adversarial(rng), int(rng.choice([12, 16, 20, 27, 32]))) for _ in range(25)]
