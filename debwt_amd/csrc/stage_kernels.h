@@ -202,11 +202,34 @@ struct RleF {
 struct ClassifyCommon {
     const u64 *dk; const u32 *dstart; u64 D; u64 M;
     const u64 *head_keys; u64 nrec;
+    // 32-Kbit bitmap (LDS) of the hashed record-start keys, or nullptr: a quarter of all keys carry pred 3, the symbol that
+    // also stands before a record start, and every one of them asked the sorted list by bisection -- eight dependent
+    // loads at the 240 records of a genome collection; with the bitmap only a key whose bit is set (0.7 % there) does
+    const u32 *hbm = nullptr;
+    __device__ static u32 head_hash(u64 k) { return (u32)((k * 0x9E3779B97F4A7C15ull) >> 49); }
+    __device__ bool maybe_head(u64 k) const {                  // k = node << 2 | 3
+        if (!hbm) return true;
+        const u32 h = head_hash(k);
+        return (hbm[h >> 5] >> (h & 31u)) & 1u;
+    }
+    // fills the bitmap (1024 words of LDS; all threads of the workgroup; ends with a barrier); false: too many records
+    __device__ bool head_bitmap(u32 *bm) {
+        if (nrec > 8192) { __syncthreads(); return false; }
+        for (u32 i = threadIdx.x; i < 1024; i += blockDim.x) bm[i] = 0;
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < (u32)nrec; i += blockDim.x) {
+            const u32 h = head_hash(head_keys[i]);
+            atomicOr(&bm[h >> 5], 1u << (h & 31u));
+        }
+        __syncthreads();
+        hbm = bm;
+        return true;
+    }
     // does distinct key e have an instance that is a real edge?  (record-start instances carry the fake pred 3:
     // only a key that equals a record-start key needs its instance count)
     __device__ bool real_count(u64 e) const {
         u64 k = dk[e];
-        if ((k & 3) != 3) return true;
+        if ((k & 3) != 3 || !maybe_head(k)) return true;
         u64 lo = lower_bound_dev<u64>(head_keys, 0, nrec, k);
         if (lo >= nrec || head_keys[lo] != k) return true;
         u64 hi = upper_bound_dev<u64>(head_keys, lo, nrec, k);
@@ -215,6 +238,7 @@ struct ClassifyCommon {
     }
     __device__ bool is_head(u64 node) const {
         u64 k = (node << 2) | 3ull;
+        if (!maybe_head(k)) return false;
         u64 lo = lower_bound_dev<u64>(head_keys, 0, nrec, k);
         return lo < nrec && head_keys[lo] == k;
     }
@@ -271,27 +295,14 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_classify_flags(ClassifyFlagsF f
                                                                  u32 *__restrict__ wl_count) {
     __shared__ u32 red[2][DEBWT_WAVES];
     __shared__ u32 qn;
-    // A quarter of all keys carry pred 3, the symbol that also stands before a record start, and each of those asked the
-    // sorted list of record-start keys by bisection: eight dependent loads for the 240 records of a genome collection, in
-    // nearly every lane of every tile -- the sweep ran at 1.1 TB/s.  Collections of up to 8192 records hash their
-    // record-start keys into a 32-Kbit bitmap in LDS first; only a key whose bit is set (0.7 % at 240 records) is looked up.
-    __shared__ u32 hbm[1024];
-    const ClassifyCommon &c = f.c;
+    __shared__ u32 hbm[1024];                                  // record-start keys, hashed (ClassifyCommon::head_bitmap)
+    ClassifyCommon c = f.c;
     const u64 D = c.D;
     u64 beg = (u64)blockIdx.x * chunk;
     u64 end = beg + chunk < D ? beg + chunk : D;
     u32 la = 0, lb = 0;
-    const bool use_bm = c.nrec <= 8192;
     if (threadIdx.x == 0) qn = 0;
-    if (use_bm) {
-        for (u32 i = threadIdx.x; i < 1024; i += DEBWT_BLOCK) hbm[i] = 0;
-        __syncthreads();
-        for (u32 i = threadIdx.x; i < (u32)c.nrec; i += DEBWT_BLOCK) {
-            const u32 h = (u32)((c.head_keys[i] * 0x9E3779B97F4A7C15ull) >> 49);
-            atomicOr(&hbm[h >> 5], 1u << (h & 31u));
-        }
-    }
-    __syncthreads();
+    c.head_bitmap(hbm);
     wl += beg;
     for (u64 tile = beg; tile < end; tile += DEBWT_BLOCK * 4) {
         const u64 e0 = tile + (u64)threadIdx.x * 4;
@@ -318,12 +329,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_classify_flags(ClassifyFlagsF f
             const u64 key = k[1 + t], W = key >> 4;
             const bool alone = (e == 0 || (k[t] >> 4) != W) && (e + 1 >= D || (k[2 + t] >> 4) != W);
             if (alone) {
-                bool maybe = (key & 3) == 3;
-                if (maybe && use_bm) {
-                    const u32 h = (u32)((key * 0x9E3779B97F4A7C15ull) >> 49);      // head_keys hold node << 2 | 3 = this key
-                    maybe = (hbm[h >> 5] >> (h & 31u)) & 1u;
-                }
-                u32 mi = (maybe && c.is_head(key >> 2)) ? 1u : 0u;
+                u32 mi = ((key & 3) == 3 && c.is_head(key >> 2)) ? 1u : 0u;
                 word |= mi << (8 * t);
                 la += mi;
             } else {
@@ -437,14 +443,17 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_classify_groups(ClassifyFlagsF 
                                                                   u32 *__restrict__ counts_b, const u32 *__restrict__ wl,
                                                                   const u32 *__restrict__ wl_count) {
     __shared__ u32 red[2][DEBWT_WAVES];
+    __shared__ u32 hbm[1024];
     const u32 nq = wl_count[blockIdx.x];
     if (nq == 0) return;
+    ClassifyCommon c = f.c;
+    c.head_bitmap(hbm);                                        // (real_count and is_head ask the record-start keys: see there)
     wl += (u64)blockIdx.x * chunk;
     u32 la = 0, lb = 0;
     for (u32 i = threadIdx.x; i < nq; i += DEBWT_BLOCK) {
         const u64 e = wl[i];
-        const u32 mi = eval_multi_in(f.c, e, nullptr) ? 1u : 0u;
-        const u32 mo = eval_multi_out(f.c, f.K, e, nullptr);
+        const u32 mi = eval_multi_in(c, e, nullptr) ? 1u : 0u;
+        const u32 mo = eval_multi_out(c, f.K, e, nullptr);
         if (mi | mo) f.cf[e] = (u8)(mi | (mo << 1));
         la += mi; lb += mo;
     }
