@@ -36,6 +36,13 @@ __device__ __forceinline__ u32 rs_digit(const RsDigit &g, u64 k) {
     }
     if (g.mode == 1) return g.tab[(k >> g.tshift) & 4095u];   // masked: lanes without a key carry ~0
     u32 q = (u32)(k >> g.tshift), lo = 0, hi = g.nb;
+    if (hi <= 16u) {
+        // few owners (the key ranges of one GPU, the shards of one node): their bounds come by uniform loads and the owner is
+        // a count of compares -- a bisection asks memory three or four times per entry, each time with an address that
+        // depends on the answer before (and the digit of an entry is computed three times a pass: histogram, ranking, flush)
+        for (u32 i = 1; i < hi; i++) lo += g.bounds[i] <= q ? 1u : 0u;
+        return lo;
+    }
     while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (g.bounds[mid] <= q) lo = mid; else hi = mid; }
     return lo;
 }

@@ -373,6 +373,8 @@ struct FactEmitArgs {
     uint4 *work;              // one slot per fact, the item sits in the slot of its first fact, others stay 0
 };
 __global__ __launch_bounds__(DEBWT_BLOCK) void k_eval_facts(FactEmitArgs a, u64 nslots) {
+    __shared__ u32 hbm[1024];
+    a.c.head_bitmap(hbm);                                      // (every thread of the workgroup: barriers inside)
     u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots) return;
     uint4 it = a.work[s];
@@ -2110,11 +2112,12 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_assemble(const u8 *__restrict__
     // block0: first 8192-row block of this launch (a build that hands finished row ranges to the host as it goes
     // assembles them range by range)
     __shared__ u32 sm[ASM_ROWS / 4 + 12];
-    __shared__ u64 sblk;
+    __shared__ u64 sblk, send;
     const u64 blk = block0 + blockIdx.x;
     const u64 R0 = blk * ASM_ROWS;
     if (threadIdx.x == 0) sblk = lower_bound_dev<u64>(sprow, 0, NS, R0);       // special rows before the block
-    __syncthreads();
+    if (threadIdx.x == 64) send = lower_bound_dev<u64>(sprow, 0, NS, R0 + ASM_ROWS);   // ... and before the next: a word bisects between
+    __syncthreads();                                                           // the two (nearly always nothing lies there)
     const u64 jb = R0 - sblk, jal = jb & ~15ull;                                 // first instance of the block, 16-aligned
     // instances [jal, jal + ASM_ROWS + 16): mchar is padded by 64 bytes behind M
     for (u32 i = threadIdx.x; i < ASM_ROWS / 16 + 2; i += DEBWT_BLOCK) {
@@ -2128,7 +2131,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_assemble(const u8 *__restrict__
     u64 nw = (n + 31) >> 5;
     if (w >= nw) return;
     u64 r0 = w << 5;
-    u64 s = lower_bound_dev<u64>(sprow, sblk, NS, r0);            // special rows before r0
+    u64 s = lower_bound_dev<u64>(sprow, sblk, send, r0);          // special rows before r0
     u64 j = r0 - s;
     u64 next_special = s < NS ? sprow[s] : ~0ull;
     u32 lim = (n - r0) < 32 ? (u32)(n - r0) : 32u;
@@ -2193,7 +2196,10 @@ __global__ void k_concat_rows(const u64 *__restrict__ parts, const ConcatPart *_
     u64 R = w << 5;
     const u64 Rend = R + 32 < n ? R + 32 : n;
     u32 lo = 0, hi = nparts;                                  // last part that starts at or before row R
-    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (pp[mid].row_base <= R) lo = mid; else hi = mid; }
+    if (nparts <= 16u) {                                      // (the shards of one node: a count of compares on uniform loads)
+        for (u32 p = 1; p < nparts; p++) lo += pp[p].row_base <= R ? 1u : 0u;
+    } else
+        while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (pp[mid].row_base <= R) lo = mid; else hi = mid; }
     u64 word = 0;
     for (u32 p = lo; p < nparts && R < Rend; p++) {
         const ConcatPart P = pp[p];
