@@ -94,6 +94,7 @@ struct debwt_ctx {
     bool route_direct = false;  // SP pass 1 keeps the block ids of the multi-in positions (qlist: one run per wave, found
     u64 gq0 = 0;                //   through qwave, group gq0 first; qwave[0] is the bump counter), pass 2 writes routed entries
     bool exchange = false;      // sharded exchange mode: the keys of every range arrive by alltoallv in a caller buffer
+    bool whole_build = false;   // inside debwt_build / debwt_build_to_host: nothing between the stages can be fetched
     bool shard_planned = false; // `ranges` were cut by debwt_shard_plan from the global census
     u64 *sort_a = nullptr, *sort_b = nullptr;   // the two key buffers of the range being sorted
     u64 Dsum = 0;               // distinct keys over the ranges sorted so far
@@ -842,7 +843,10 @@ static int sort_range(debwt_ctx *c, size_t i, u64 *imported) {
     // the bucket finish of the sort counts the distinct keys of its tiles and the encoding follows tile by tile
     // (tune bit 8 = 256: separate count and emit passes over the sorted keys instead)
     RleSink sink{c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase, c->rs_rle.p, &c->h_scalars[0],
-                 &c->h_scalars[32], 0, (c->cfg.reserved & 131072) != 0, false};   // bit 17: no staging of distinct keys
+                 &c->h_scalars[32], 0, (c->cfg.reserved & 131072) != 0,           // bit 17: no staging of distinct keys
+                 // the sorted keys can be asked for (debwt_fetch_array) after the sort stage of a one-range build driven
+                 // stage by stage, and by nobody else: every other build keeps the encoding only (tune bit 23: keeps both -- A/B)
+                 (P > 1 || c->exchange || c->whole_build) && !(c->cfg.reserved & 8388608), false};
     if (imported && r.M < 2) c->sk = c->sort_a;
     else if ((rc = sort_keys(c, c->sort_a, c->sort_b, r.M, 2 * c->cfg.k, &c->sk, i == 0, imported ? nullptr : &ts, true,
                              (c->cfg.reserved & 256) ? nullptr : &sink))) return rc;
@@ -1758,11 +1762,19 @@ extern "C" int debwt_reserve(debwt_ctx *c, uint64_t n, uint64_t nrec, double bra
     return DEBWT_OK;
 }
 
+// (whole_build: the stages run back to back, no caller can ask for what lies between them)
+struct WholeBuild {
+    debwt_ctx *c;
+    explicit WholeBuild(debwt_ctx *c_) : c(c_) { c->whole_build = true; }
+    ~WholeBuild() { c->whole_build = false; }
+};
+
 extern "C" int debwt_build(debwt_ctx *c) {
     int rc;
     if (!c) return DEBWT_EINVAL;
     if (c->stage < ST_LOADED) return DEBWT_ESTATE;
     c->stage = ST_LOADED;
+    WholeBuild wb{c};
     if ((rc = debwt_kmer_sort_rle(c))) return rc;
     if ((rc = debwt_classify(c))) return rc;
     if ((rc = debwt_sp_generate(c))) return rc;
@@ -1781,6 +1793,7 @@ extern "C" int debwt_build_to_host(debwt_ctx *c, uint64_t *bwt, uint64_t *hash_r
     if (c->stage < ST_LOADED) return DEBWT_ESTATE;
     if (c->shard_world > 1) { c->err = "sharded context: use the debwt_shard_* calls"; return DEBWT_ESTATE; }
     c->stage = ST_LOADED;
+    WholeBuild wb{c};
     if ((rc = debwt_kmer_sort_rle(c))) return rc;
     if ((rc = debwt_classify(c))) return rc;
     if ((rc = debwt_sp_generate(c))) return rc;

@@ -92,6 +92,8 @@ struct RleSink {
                                        // left to the 4096-key network (valid once the stream drained)
     u32 n_over;                        // out: stretches above 4096 keys, finished by all-HBM passes
     bool no_staging;                   // in: tiles do not stage their distinct keys in the other key buffer (A/B, tests)
+    bool drop_sorted;                  // in: the caller reads the encoding only -- a tile that staged its distinct keys need not
+                                       // write its sorted keys back (the returned array is then sorted in the other tiles only)
     bool done;
 };
 size_t radix_rle_ws_bytes(u64 n);

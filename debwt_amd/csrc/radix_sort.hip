@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ ke
                                                             u8 *__restrict__ mark, u64 *__restrict__ bnd,
                                                             u32 *__restrict__ unfit, u32 *__restrict__ nunfit,
                                                             u32 *__restrict__ tcnt, u8 *__restrict__ mchar,
-                                                            u64 *__restrict__ stg) {
+                                                            u64 *__restrict__ stg, int drop_sorted) {
     constexpr int KPT = 16;
     constexpr u32 CAP = RLW_CAP;
     const u32 lane = threadIdx.x;
@@ -1210,7 +1210,11 @@ __global__ __launch_bounds__(64) void rs_local_count_kernel(u64 *__restrict__ ke
             for (int r = 0; r < KPT; r++) if (lane * KPT + r < cnt) dst[r] = (u8)(k[r] & 3ull);
         }
     }
-    for (u32 i = lane; i < cnt; i += 64) keys[s + i] = A[RL_PAD(i)];
+    // (drop_sorted: nobody reads the sorted tile once its distinct keys are staged -- in a collection of ten genomes that
+    // is 8 of the 17 bytes per key this kernel moved; the keys stay where they were, unsorted inside their buckets, which is
+    // all a re-sort of the whole array, should the oversize path ask for one, needs)
+    if (!(staged && drop_sorted))
+        for (u32 i = lane; i < cnt; i += 64) keys[s + i] = A[RL_PAD(i)];
 }
 
 // The unfit stretches of the counting finish, sorted where they lie: one workgroup per stretch of the list
@@ -1274,7 +1278,7 @@ template <int KPT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPT == 8 ? RLU_WAVES_EU_SMALL : RLU_WAVES_EU, KPT == 8 ? RLU_WAVES_EU_SMALL : RLU_WAVES_EU)))
 void rs_local_unfit_kernel(u64 *__restrict__ keys, u64 n, const u64 *__restrict__ bnd, u32 nwtiles, u32 *__restrict__ unfit,
                            u32 *__restrict__ nunfit, u32 *__restrict__ over, u32 over_cap, u32 gap_max,
-                           u32 *__restrict__ tcnt, u8 *__restrict__ mchar, u64 *__restrict__ stg) {
+                           u32 *__restrict__ tcnt, u8 *__restrict__ mchar, u64 *__restrict__ stg, int drop_sorted) {
     constexpr int NT = 256;
     constexpr u32 CAP = NT * KPT;
     __shared__ u64 A[CAP + CAP / 16];
@@ -1395,12 +1399,10 @@ void rs_local_unfit_kernel(u64 *__restrict__ keys, u64 n, const u64 *__restrict_
         for (int r = 0; r < KPT; r++)
             if (cr[r] != 0xFFFFFFFFu) A[RL_PAD(cr[r])] = kk[r];
         __syncthreads();
-        for (u32 j = tid; j < cnt; j += NT) {
-            const u64 key = A[RL_PAD(j)];
-            keys[s + j] = key;
-            if (tcnt) mchar[s + j] = (u8)(key & 3ull);
-        }
-        if (tcnt) {
+        if (!tcnt) {
+            for (u32 j = tid; j < cnt; j += NT) keys[s + j] = A[RL_PAD(j)];
+        } else {
+            for (u32 j = tid; j < cnt; j += NT) mchar[s + j] = (u8)(A[RL_PAD(j)] & 3ull);
             // The stretch lies sorted in LDS: its run-length encoding follows here instead of in two more passes over
             // it (rs_unfit_rle_kernel counts, then emits): distinct keys counted into the stretch's raster slot and, few
             // as they are, staged for rs_tile_emit_kernel like those of a wave tile; the list entry is marked RLU_COUNTED.
@@ -1425,6 +1427,9 @@ void rs_local_unfit_kernel(u64 *__restrict__ keys, u64 n, const u64 *__restrict_
                 for (int r = 0; r < KPT; r++)
                     if ((hm >> r) & 1u) { kd[o] = A[RL_PAD(tid * KPT + r)]; id[o] = (unsigned short)(tid * KPT + r); o++; }
             }
+            // (the sorted stretch goes back only when somebody will read it: see rs_local_count_kernel)
+            if (!(staged && drop_sorted))
+                for (u32 j = tid; j < cnt; j += NT) keys[s + j] = A[RL_PAD(j)];
         }
     }
 }
@@ -1855,15 +1860,15 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
         // (the other key buffer takes the distinct keys of the tiles that hold few: it is free until the all-HBM path of
         // oversize stretches, which then works in the buffer of the distinct keys instead)
         rs_local_count_kernel<<<nwtiles, 64, 0, stream>>>(src, n, pshift, mark, rle_bnd, rle_unfit, rle_ctr, rle_tcnt, sink->mchar,
-                                                          sink->no_staging ? nullptr : other);
+                                                          sink->no_staging ? nullptr : other, sink->drop_sorted ? 1 : 0);
         const u32 ugrid = nwtiles < 16384u ? nwtiles : 16384u;
 #if RLU_CLASSIFY
         u64 *const stg = sink->no_staging ? nullptr : other;
         rs_local_unfit_kernel<8><<<ugrid, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, ws.over, ws.over_cap,
-                                                            net_only ? 0u : RLU_GAP_MAX, rle_tcnt, sink->mchar, stg);
+                                                            net_only ? 0u : RLU_GAP_MAX, rle_tcnt, sink->mchar, stg, sink->drop_sorted ? 1 : 0);
         rs_local_unfit_kernel<16><<<ugrid < 4096u ? ugrid : 4096u, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, ws.over,
                                                                                       ws.over_cap, net_only ? 0u : RLU_GAP_MAX,
-                                                                                      rle_tcnt, sink->mchar, stg);
+                                                                                      rle_tcnt, sink->mchar, stg, sink->drop_sorted ? 1 : 0);
 #endif
         rs_local_unfit_net_kernel<<<ugrid, 256, 0, stream>>>(src, n, rle_bnd, nwtiles, rle_unfit, rle_ctr, ws.over, ws.over_cap);
     } else {
