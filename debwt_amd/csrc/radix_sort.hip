@@ -1085,8 +1085,9 @@ __device__ __forceinline__ void rlw_sort(u64 (&k)[16], const u32 lane) {
 // tenth of the keys are distinct: the emit pass reads 1.1 bytes per key instead of 8.
 #define RLT_STAGED 0x80000000u
 #ifndef RLT_STAGE_RATIO
-#define RLT_STAGE_RATIO 4u             // keys per distinct key from which a tile stages (20 bytes per distinct key written and read
-#endif                                 // against 8 per key read; measured: 2 costs a single genome 1.4 % of its sort, 4 nothing)
+#define RLT_STAGE_RATIO 2u             // keys per distinct key from which a tile stages: 10 bytes per distinct key written and read
+#endif                                 // again against 8 per key (since such a tile keeps its sorted keys to itself -- drop_sorted --
+                                       // 2 beats 4: four genomes 669.8 -> 656.5 ms, ten 1498.3 -> 1493.4, one 155.9 -> 154.8)
 #ifndef RLW_WINDOW
 #define RLW_WINDOW 1                   // the tile and both its boundaries out of ONE window of keys (one global round trip per tile)
 #endif
