@@ -1901,9 +1901,21 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
             }
             if (2 * total + 3 * (u64)nover > n) whole = true;
         }
-        if (getenv("DEBWT_TRACE_SORT"))
+        if (getenv("DEBWT_TRACE_SORT")) {
             fprintf(stderr, "key sort of %llu keys: %u oversize stretches with %llu keys (%s)\n", (unsigned long long)n, nover,
                     (unsigned long long)total, whole ? "all keys re-sorted" : "gathered and sorted by all-HBM passes");
+            if (!whole) {
+                u64 hk[40] = {0}; u32 hn[40] = {0};                    // by size class: stretches of [2^b, 2^(b+1)) keys
+                for (u32 i = 0; i < nover; i++) {
+                    const u64 cnt = offs[nover + 2 * i + 1];
+                    int b = 0;
+                    while ((cnt >> (b + 1)) && b < 39) b++;
+                    hk[b] += cnt; hn[b]++;
+                }
+                for (int b = 0; b < 40; b++)
+                    if (hn[b]) fprintf(stderr, "    2^%d..: %u stretches, %llu keys\n", b, hn[b], (unsigned long long)hk[b]);
+            }
+        }
         if (whole) {
             src = rs_lsd(stream, src, other, n, 0, key_bits, ws, nullptr, 0, nullptr);
             staging_lost = true;                                   // both key buffers were overwritten
