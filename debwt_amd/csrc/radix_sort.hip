@@ -131,6 +131,9 @@ __device__ __forceinline__ u32 rs_staged_keys(const TextKeySrc &ts, const TextSt
 // ---------------------------------------------------------------------------------------------------
 // algo 1
 
+#ifndef RS_HIST_UNIFORM
+#define RS_HIST_UNIFORM 1
+#endif
 // AUX = 1 instantiates the same kernels under a second name for the small auxiliary sorts (fact lists, '#' rows),
 // so that profiler averages of the key-sort passes are not diluted by them
 template <int SRC, int AUX>
@@ -147,8 +150,20 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict
         for (u64 i = beg + 2ull * threadIdx.x; i < end; i += 2ull * RS_BLOCK) {
             if (i + 1 < end) {
                 ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + i);
-                atomicAdd(&h[rs_digit<!AUX>(dg, v.x)], 1u);
-                atomicAdd(&h[rs_digit<!AUX>(dg, v.y)], 1u);
+                const u32 d0 = rs_digit<!AUX>(dg, v.x), d1 = rs_digit<!AUX>(dg, v.y);
+#if RS_HIST_UNIFORM
+                // The wave's 128 keys carry one digit (the passes over the oversize stretches of a real genome, whose keys
+                // share their upper digits by the ten thousand): 128 adds to one counter are executed one after the other
+                // -- those passes counted at 2.7 TB/s where the key ranges count at 5.8 -- so one lane adds for all.
+                const u32 f = (u32)__builtin_amdgcn_readfirstlane((int)d0);
+                if (AUX && __ballot(d0 != f || d1 != f) == 0ull) {        // (the key ranges' own passes lose 10 % to the test)
+                    const u64 act = __ballot(1);
+                    if ((threadIdx.x & 63u) == (u32)__ffsll((long long)act) - 1u) atomicAdd(&h[f], 2u * (u32)__popcll(act));
+                    continue;
+                }
+#endif
+                atomicAdd(&h[d0], 1u);
+                atomicAdd(&h[d1], 1u);
             } else {
                 atomicAdd(&h[rs_digit<!AUX>(dg, keys[i])], 1u);
             }
