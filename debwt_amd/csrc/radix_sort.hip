@@ -1608,35 +1608,19 @@ __global__ __launch_bounds__(LONG ? RLU_LONG_NT : 256) void rs_unfit_rle_kernel(
     __shared__ u32 wsum[4];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const u32 nu = LONG ? nunfit[2] : nunfit[0];
-    for (u32 i = blockIdx.x; i < nu; i += gridDim.x) {
-        const u32 entry = LONG ? unfit[nwtiles - 1u - i] : unfit[i];
-        const u32 t = RLU_TILE(entry);
-        if (!LONG && (entry & RLU_COUNTED)) {
-            // counted by the classifying kernel; emitted by rs_tile_emit_kernel when staged (unless the staging buffer was lost)
-            if (!EMIT || ((tcnt[t] & RLT_STAGED) && staging_ok)) continue;
-        }
-        const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
-        const u64 x0 = (u64)t * RLW_H;
-        const u64 K64 = (e - x0) / RLW_H;                                    // raster tiles wholly inside [x0, e)
-        // (a stretch the classifying kernel counted has its whole count in the slot of its first tile: one piece)
-        const u32 K = (K64 < 1 || (!LONG && (entry & RLU_COUNTED))) ? 1u : (u32)K64;
-        if (!LONG && K >= RLU_LONG) continue;                                // the long list's
-        if (LONG && blockIdx.y >= K) continue;                               // no piece of this stretch for this grid row: on to the
-                                                                             // next before its keys are asked for (most stretches
-                                                                             // have fewer pieces than the grid has rows)
-        const u64 kfirst = keys[s];
-        const bool one_run = kfirst == keys[e - 1];                          // sorted: every key of the stretch is equal
-        for (u32 k = LONG ? blockIdx.y : 0u; k < K; k += LONG ? gridDim.y : 1u) {
+    // piece k of the stretch [s, e) listed under raster tile t (K pieces)
+    auto piece = [&](const u32 t, const u64 s, const u64 e, const u32 K, const u32 k, const u64 kfirst, const bool one_run) {
+            const u64 x0 = (u64)t * RLW_H;
             const u64 lo = x0 + (u64)k * RLW_H, hi = k + 1 == K ? e : lo + RLW_H;
             const u64 ps = lo > s ? lo : s, pe = hi;                         // the piece's part of the stretch
             u32 run = EMIT ? tex[t + k] + boff[(t + k) / RLT_BLOCK] : 0u;   // distinct keys before the piece
-            if (ps >= pe) { if (!EMIT && tid == 0) tcnt[t + k] = 0; continue; }
+            if (ps >= pe) { if (!EMIT && tid == 0) tcnt[t + k] = 0; return; }
             if (one_run) {
-                if (!EMIT) { if (tid == 0) tcnt[t + k] = ps == s ? 1u : 0u; continue; }
+                if (!EMIT) { if (tid == 0) tcnt[t + k] = ps == s ? 1u : 0u; return; }
                 if (tid == 0 && ps == s) { dk[run] = kfirst; dstart[run] = (u32)s; }
                 const u8 sy = (u8)(kfirst & 3);
                 for (u64 j = ps + tid; j < pe; j += NT) mchar[j] = sy;
-                continue;
+                return;
             }
             for (u64 p = ps; p < pe; p += STEP) {
                 const u64 j0 = p + (u64)tid * V;
@@ -1687,7 +1671,70 @@ __global__ __launch_bounds__(LONG ? RLU_LONG_NT : 256) void rs_unfit_rle_kernel(
                 __syncthreads();
             }
             if (!EMIT && tid == 0) tcnt[t + k] = run;
+    };
+    if (LONG) {
+        // Stretch i belongs to grid column i mod columns, whose workgroup in row y takes piece y: a stretch of fewer pieces
+        // than the grid has rows -- nearly all of them -- is done with that.  The pieces from the rows' number on are dealt
+        // over ALL workgroups: pieces y, y + rows, ... in the one column left a stretch of 10^5 pieces (a satellite's k-mer:
+        // 131 M of the 543 M oversize keys of real10x3G's first key range) to 64 workgroups, 2,290 pieces each, while the
+        // other 4,032 had finished -- 7.8 + 6.2 ms for the two passes of that range against 0.8 + 1.2 for the others.
+        // Every workgroup finds those stretches itself, NT list entries at a time, one per thread.  (All workgroups walking
+        // the whole list entry by entry was tried first: 7,000 entries x 8,192 waves x 80 instructions, 6 ms a pass.)
+        const u32 gx = gridDim.x, gy = gridDim.y, G = gx * gy, W = blockIdx.y * gx + blockIdx.x;
+        for (u32 i = blockIdx.x; i < nu; i += gx) {
+            const u32 t = RLU_TILE(unfit[nwtiles - 1u - i]);
+            const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
+            const u64 K64 = (e - (u64)t * RLW_H) / RLW_H;                      // raster tiles wholly inside [x0, e)
+            const u32 K = K64 < 1 ? 1u : (u32)K64;
+            if (blockIdx.y >= K) continue;                                     // no piece of this stretch for this grid row: on to the
+                                                                               // next before its keys are asked for
+            const u64 kfirst = keys[s];
+            piece(t, s, e, K, blockIdx.y, kfirst, kfirst == keys[e - 1]);      // (sorted: equal ends = every key of the stretch is equal)
         }
+        __shared__ u32 l_n, l_t[NT];
+        __shared__ u64 l_s[NT], l_e[NT];
+        for (u32 base = 0; base < nu; base += NT) {
+            __syncthreads();
+            if (tid == 0) l_n = 0;
+            __syncthreads();
+            if (base + tid < nu) {
+                const u32 t = RLU_TILE(unfit[nwtiles - 1u - (base + tid)]);
+                const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
+                if ((e - (u64)t * RLW_H) / RLW_H > gy) {
+                    const u32 q = atomicAdd(&l_n, 1u);
+                    l_t[q] = t; l_s[q] = s; l_e[q] = e;
+                }
+            }
+            __syncthreads();
+            const u32 m = l_n;
+            for (u32 q = 0; q < m; q++) {
+                const u32 t = l_t[q];
+                const u64 s = l_s[q], e = l_e[q];
+                const u32 K = (u32)((e - (u64)t * RLW_H) / RLW_H);
+                const u64 k0 = (u64)gy + (W + G - t % G) % G;
+                if (k0 >= K) continue;
+                const u64 kfirst = keys[s];
+                const bool one_run = kfirst == keys[e - 1];
+                for (u64 k = k0; k < K; k += G) piece(t, s, e, K, (u32)k, kfirst, one_run);
+            }
+        }
+        return;
+    }
+    for (u32 i = blockIdx.x; i < nu; i += gridDim.x) {
+        const u32 entry = unfit[i];
+        const u32 t = RLU_TILE(entry);
+        if (entry & RLU_COUNTED) {
+            // counted by the classifying kernel; emitted by rs_tile_emit_kernel when staged (unless the staging buffer was lost)
+            if (!EMIT || ((tcnt[t] & RLT_STAGED) && staging_ok)) continue;
+        }
+        const u64 s = bnd[t], e = t + 1 < nwtiles ? bnd[t + 1] : n;
+        const u64 K64 = (e - (u64)t * RLW_H) / RLW_H;                          // raster tiles wholly inside [x0, e)
+        // (a stretch the classifying kernel counted has its whole count in the slot of its first tile: one piece)
+        const u32 K = (K64 < 1 || (entry & RLU_COUNTED)) ? 1u : (u32)K64;
+        if (K >= RLU_LONG) continue;                                           // the long list's
+        const u64 kfirst = keys[s];
+        const bool one_run = kfirst == keys[e - 1];                            // sorted: every key of the stretch is equal
+        for (u32 k = 0; k < K; k++) piece(t, s, e, K, k, kfirst, one_run);
     }
 }
 
