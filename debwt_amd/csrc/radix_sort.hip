@@ -1803,8 +1803,12 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
     u64 *src = a, *dst = b;
     int p = 0, ev_idx = 0;
     TextKeySrc none{};
-    for (int shift = lo_bit; shift < hi_bit; shift += 8, p++) {
-        int bits = hi_bit - shift < 8 ? hi_bit - shift : 8;
+    // (auxiliary sorts spread their bits evenly over the passes -- 29 bits of block id: 8 + 7 + 7 + 7, not 8 + 8 + 8 + 5: the
+    // histogram of a 5-bit digit adds 128 keys a wave to 32 counters and took 9.2 ms for 3.9 G blue entries where the 8-bit
+    // passes before it took 4.1)
+    for (int shift = lo_bit, bits = 0; shift < hi_bit; shift += bits, p++) {
+        const int left = hi_bit - shift, passes_left = (left + 7) / 8;
+        bits = aux ? (left + passes_left - 1) / passes_left : (left < 8 ? left : 8);
         RsDigit dg{};
         dg.shift = shift; dg.mask = (1u << bits) - 1u;
         const bool from_text = text && p == 0;
