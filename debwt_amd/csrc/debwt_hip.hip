@@ -1301,15 +1301,16 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
             if (!r.B) continue;
             u64 *reg = c->blue.as<u64>() + r.Bbase, *res = reg;
             const int span = r.Q > 1 ? bits_for(r.qbase ^ (r.qbase + r.Q - 1)) : 0;     // bits in which the range's block ids differ
+            bool stripped = false;                                                     // (the last pass strips when it writes to `reg`)
             if (span) {
                 ENSURE(c, c->rs_over, radix_over_bytes(r.B));
                 u64 *tmp = c->keysA.as<u64>();
                 if (c->keysA.cap < r.B * 8 + 64) { ENSURE(c, c->blue_tmp, r.B * 8 + 64); tmp = c->blue_tmp.as<u64>(); }
                 hipError_t e = hipSuccess;
-                res = radix_sort_bits(c->stream, reg, tmp, r.B, qshift, std::min(64, qshift + span), radix_ws(c), &e);
+                res = radix_sort_bits(c->stream, reg, tmp, r.B, qshift, std::min(64, qshift + span), radix_ws(c), &e, qshift, &stripped);
                 if (e != hipSuccess) { c->err = std::string("blue entry sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
             }
-            k_blue_strip<<<grid_for(r.B, 256), 256, 0, c->stream>>>(res, reg, r.B, qshift);
+            if (!stripped) k_blue_strip<<<grid_for(r.B, 256), 256, 0, c->stream>>>(res, reg, r.B, qshift);
         }
     }
     if (route_sort && c->B) {
@@ -1319,9 +1320,10 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
         else { ENSURE(c, c->blue_tmp, c->B * 8 + 64); tmp = c->blue_tmp.as<u64>(); }
         ENSURE(c, c->rs_over, radix_over_bytes(c->B));
         hipError_t e = hipSuccess;
-        u64 *r = radix_sort_bits(c->stream, c->blue.as<u64>(), tmp, c->B, qshift, 64, radix_ws(c), &e);
+        bool stripped = false;                                   // (the last pass strips when it writes to `blue`)
+        u64 *r = radix_sort_bits(c->stream, c->blue.as<u64>(), tmp, c->B, qshift, 64, radix_ws(c), &e, qshift, &stripped);
         if (e != hipSuccess) { c->err = std::string("blue entry sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
-        k_blue_strip<<<grid_for(c->B, 256), 256, 0, c->stream>>>(r, c->blue.as<u64>(), c->B, qshift);
+        if (!stripped) k_blue_strip<<<grid_for(c->B, 256), 256, 0, c->stream>>>(r, c->blue.as<u64>(), c->B, qshift);
     }
     return sp_finish(c, S);
 }

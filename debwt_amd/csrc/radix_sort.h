@@ -57,6 +57,8 @@ struct RsDigit {
     int mode;
     const u8 *tab; int tshift;    // mode 1: tab[key >> tshift]
     const u32 *bounds; u32 nb;    // mode 2: owner of block id key >> tshift
+    int out_strip;                // rs_scatter_kernel<0,2,0> (the last pass of the blue-entry sort): a routed entry
+                                  // (block id << out_strip | SP index << 3 | pred) leaves as a blue entry (pred | SP index << 4)
 };
 
 size_t radix_workspace_bytes(u64 max_keys);
@@ -78,8 +80,10 @@ hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const Te
 // valid positions); pass events are then recorded for the array-to-array passes only.
 // Stable LSD passes over the key bits [lo_bit, hi_bit) only (auxiliary kernels); a: input, b: scratch of n words;
 // returns the buffer that holds the result.
+// strip_last > 0: when the result comes to lie in `a` (an even number of passes), the last pass writes blue entries instead
+// of routed ones (RsDigit::out_strip = strip_last) and *stripped is set; otherwise the caller strips them itself.
 u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
-                     hipError_t *err);
+                     hipError_t *err, int strip_last = 0, bool *stripped = nullptr);
 // sink (optional): when the hybrid path runs, the bucket finish also counts the distinct keys of every tile it has
 // in registers and writes the row symbols key & 3, and the run-length encoding of the sorted keys -- distinct keys,
 // first row of each (row = index in sorted order) -- follows tile by tile without a counting pass over the keys.

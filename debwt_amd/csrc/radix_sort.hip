@@ -516,7 +516,14 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
 
 // F1: the pending line of every digit, 16 lanes per digit.  Parameter words first, then all key reads, then
 // the stores: the LDS round trips of the iterations overlap instead of chaining.
-__device__ __forceinline__ void rs_flush_heads(ScShared &sh, u64 *__restrict__ out) {
+// what a pass stores: the key, or (STRIP: the last pass of the blue-entry sort) the blue entry of a routed entry
+template <int STRIP>
+__device__ __forceinline__ u64 rs_out(const RsDigit &dg, u64 e) {
+    if (!STRIP) return e;
+    return (e & 7ull) | (((e & ((1ull << dg.out_strip) - 1ull)) >> 3) << 4);
+}
+template <int STRIP = 0>
+__device__ __forceinline__ void rs_flush_heads(ScShared &sh, u64 *__restrict__ out, const RsDigit &dg) {
     constexpr u32 NI = RS_RADIX * SC_LINE / SC_NT;
     const u32 s = threadIdx.x % SC_LINE, d0 = threadIdx.x / SC_LINE;
     const u64 *hw = reinterpret_cast<const u64 *>(sh.head);
@@ -534,12 +541,12 @@ __device__ __forceinline__ void rs_flush_heads(ScShared &sh, u64 *__restrict__ o
 #pragma unroll
     for (u32 i = 0; i < NI; i++) {
         const u32 a0 = (u32)h[i], nhead = (u32)(h[i] >> 56);
-        if (s < nhead) out[a0 + s] = v[i];
+        if (s < nhead) out[a0 + s] = rs_out<STRIP>(dg, v[i]);
     }
 }
 // F2: the tile's keys (k[r] = LDS slot tid + r*SC_NT): whole lines go out, the tail behind the last line boundary
 // becomes the carry
-template <int FIXED0>
+template <int FIXED0, int STRIP = 0>
 __device__ __forceinline__ void rs_flush_body(ScShared &sh, const RsDigit &dg, u64 *__restrict__ out,
                                               const u64 (&k)[SC_ITEMS], int tot) {
     const u64 *bw = reinterpret_cast<const u64 *>(sh.body);
@@ -553,7 +560,7 @@ __device__ __forceinline__ void rs_flush_body(ScShared &sh, const RsDigit &dg, u
         const int lo = (short)(b[r] >> 32), fl = (short)(b[r] >> 48);
         if (js >= tot) continue;
         if (js >= fl) sh.carry[d[r]][js - fl] = k[r];
-        else if (js >= lo) out[(u32)b[r] + (u32)js] = k[r];
+        else if (js >= lo) out[(u32)b[r] + (u32)js] = rs_out<STRIP>(dg, k[r]);
     }
 }
 #ifndef SPARSE_DOUBLE_TEST
@@ -599,12 +606,12 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
             u32 vmask = SRC ? rs_load_tile_text(ts, st, tile, end, key) : rs_load_tile<SRC>(in, ts, tile, end, key);
             tot = (int)rs_rank_tile<DG, 0>(key, vmask, dg, sh, oalign);
         }
-        rs_flush_heads(sh, out);
+        rs_flush_heads<AUX == 2>(sh, out, dg);
         u64 k[SC_ITEMS];
 #pragma unroll
         for (int r = 0; r < SC_ITEMS; r++) k[r] = sh.skeys[tid + r * SC_NT];
         lds_barrier();                                         // F1 has read the old carry, every wave holds its slots
-        rs_flush_body<DG>(sh, dg, out, k, tot);
+        rs_flush_body<DG, AUX == 2>(sh, dg, out, k, tot);
         rs_clear_rank_state(sh);                               // the next tile ranks right after the barrier
         lds_barrier();
     }
@@ -613,7 +620,7 @@ void rs_scatter_kernel(const u64 *__restrict__ in, TextKeySrc ts, u64 *__restric
     for (u32 i = 0; i < RS_RADIX * SC_LINE / SC_NT; i++) {
         const u32 p = i * SC_NT + tid, d = p / SC_LINE, s = p % SC_LINE;
         const u32 cc = sh.cc[d];
-        if (s < cc) out[sh.run[d] - cc + s] = sh.carry[d][s];
+        if (s < cc) out[sh.run[d] - cc + s] = rs_out<AUX == 2>(dg, sh.carry[d][s]);
     }
 }
 
@@ -741,7 +748,7 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
                 rs_clear_rank_state(sh);
                 lds_barrier();
                 const int tile_tot = (int)rs_rank_tile<DG, 0>(key, vmask, dg, sh, oalign, R);
-                rs_flush_heads(sh, out);
+                rs_flush_heads(sh, out, dg);
                 u64 k[SC_ITEMS];
 #pragma unroll
                 for (int r = 0; r < SC_ITEMS; r++) k[r] = sh.skeys[tid + r * SC_NT];
@@ -1797,7 +1804,7 @@ size_t radix_over_bytes(u64 max_keys) { return 16 + (size_t)(max_keys / RL_H + 2
 
 static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
                    hipEvent_t *pass_events, int max_pairs, int *npairs, const TextKeySrc *text = nullptr,
-                   bool aux = false) {
+                   bool aux = false, int strip_last = 0) {
     // stable LSD passes over bits [lo_bit, hi_bit), 8 bits per pass starting at lo_bit.  With `text` the first
     // pass reads node keys from the text (its index space is the ts->n positions) and writes them to `a`.
     u64 *src = a, *dst = b;
@@ -1836,7 +1843,10 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
         rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
         rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
         if (ev) (void)hipEventRecord(pass_events[2 * ev_idx], stream);
-        if (aux) rs_scatter_kernel<0, 1, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
+        if (aux && strip_last && shift + bits >= hi_bit) {
+            dg.out_strip = strip_last;
+            rs_scatter_kernel<0, 2, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
+        } else if (aux) rs_scatter_kernel<0, 1, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
         else if (shift >= 32) rs_scatter_kernel<0, 0, 1><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
         else rs_scatter_kernel<0, 0, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
         if (ev) { (void)hipEventRecord(pass_events[2 * ev_idx + 1], stream); ev_idx++; if (npairs) *npairs = ev_idx; }
@@ -1877,10 +1887,13 @@ hipError_t radix_text_hist_ranges(hipStream_t stream, const TextKeySrc &text, co
 }
 
 u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
-                     hipError_t *err) {
+                     hipError_t *err, int strip_last, bool *stripped) {
     *err = hipSuccess;
+    if (stripped) *stripped = false;
     if (n < 2 || hi_bit <= lo_bit) return a;
-    u64 *r = rs_lsd(stream, a, b, n, lo_bit, hi_bit, ws, nullptr, 0, nullptr, nullptr, true);
+    const bool fuse = strip_last > 0 && stripped && ((hi_bit - lo_bit + 7) / 8) % 2 == 0;   // the result comes to lie in `a`
+    if (fuse) *stripped = true;
+    u64 *r = rs_lsd(stream, a, b, n, lo_bit, hi_bit, ws, nullptr, 0, nullptr, nullptr, true, fuse ? strip_last : 0);
     *err = hipGetLastError();
     return r;
 }
