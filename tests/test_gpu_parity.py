@@ -945,6 +945,45 @@ def test_rle_paths_agree(api, kind):
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and a[4] == b[4]
 
 
+@pytest.mark.parametrize("cap", [0, 1 << 20])
+def test_tiles_that_stage_their_distinct_keys_need_not_write_their_sorted_keys_back(api, cap):
+    """Inside debwt_build a tile of the bucket finish that staged its distinct keys keeps its sorted keys to itself
+    (RleSink::drop_sorted): nobody reads them -- the sorted keys can only be fetched after the sort stage of a one-range
+    build driven stage by stage, where they are written as before.  Same BWT with the write-back restored (tune bit 23) and
+    with the separate count + emit passes (tune 256), in one key range and in several, on repeat families (tiles and unfit
+    stretches that stage) and low-complexity runs (oversize stretches, re-sorted in place)."""
+    from debwt_amd import synth
+    rng = np.random.default_rng(23)
+    parts = []
+    for _ in range(120):
+        parts.append(np.full(int(rng.integers(200, 20000)), int(rng.integers(0, 4)), dtype=np.uint8))
+        parts.append(rng.integers(0, 4, size=int(rng.integers(100, 5000))).astype(np.uint8))
+    recs = synth.pan_genome(400_000, 8) + [np.concatenate(parts)]
+    got = []
+    for tune in (0, 1 << 23, 256):
+        d = api.DeBWT(k=32, tune=tune)
+        if cap:
+            d.set_range_cap(cap)
+        d.load_records(recs)
+        d.build()
+        got.append(tuple(d.fetch()) + (d.fetch_array(api.ARR_DISTINCT_KEYS) if not cap else None,))
+        with pytest.raises(api.DebwtError):
+            d.fetch_array(api.ARR_SORTED_KEYS)       # not after a whole build, in one range or several
+        d.close()
+    for other in got[1:]:
+        assert np.array_equal(got[0][0], other[0]) and np.array_equal(got[0][1], other[1]) and got[0][2] == other[2]
+        if not cap:
+            assert np.array_equal(got[0][3], other[3])
+    if not cap:
+        # driven stage by stage the sorted keys are there, whole and in order
+        d = api.DeBWT(k=32)
+        d.load_records(recs)
+        d.kmer_sort_rle()
+        sk = d.fetch_array(api.ARR_SORTED_KEYS)
+        assert bool((sk[1:] >= sk[:-1]).all()) and np.array_equal(np.unique(sk), got[0][3])
+        d.close()
+
+
 def test_randomised_parity_sweep(api, oracle):
     """200 random small collections x random k x random key-range caps x the alternative device paths (cursor atomics,
     64-bit cursors, no tie-group hand-off, separate run-length passes), two builds per context, against the oracle (scripts/gpu_fuzz.py runs the
