@@ -68,6 +68,7 @@ struct debwt_ctx {
     u64 D = 0, Q = 0, Rmo = 0, R = 0, B = 0, S = 0, nlarge = 0, nfacts = 0;
     u64 rQ = 0, rB = 0, rnlarge = 0;   // blocks, blue rows, large blocks of the range just classified
     u64 rn1024 = 0, n1024 = 0;         // blocks of 513..1024 rows (range / context)
+    u64 rn512 = 0, n512 = 0;           // blocks of 257..512 rows
     // Key ranges of this context, sorted and classified one after the other over the resident text (one range unless
     // the node instances exceed range_cap: "bucket streaming" for texts whose keys do not fit HBM at once).
     // D, Rmo and the buffers keysA/keysB/dk/dstart/pflag/mi_*/bstart/facts belong to the range being processed;
@@ -779,7 +780,7 @@ static int sort_begin(debwt_ctx *c) {
     ENSURE(c, c->dstart, maxM * 4 + 64);
     ENSURE(c, c->pflag, maxM + 64);                      // classification byte per distinct key of a range
     ENSURE(c, c->mchar, c->Mctx + 64);
-    c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0; c->Dsum = 0;
+    c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0; c->n512 = 0; c->Dsum = 0;
     c->st.sort_unfit_stretches = c->st.sort_unfit_network = c->st.sort_over_stretches = 0;
     const size_t P = c->ranges.size();
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -984,15 +985,17 @@ static int classify_local(debwt_ctx *c) {
     if ((rc = cp_count(c, fl, Q, cp_area(c, 5), 5))) return rc;
     if ((rc = cp_emit(c, fl, Q, cp_area(c, 5)))) return rc;
     {
-        u32 *cnt = cp_area(c, 6) + CP_MAXCHUNKS + 8;              // a free word behind the area's scan total
-        HIPCHK(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+        u32 *cnt = cp_area(c, 6) + CP_MAXCHUNKS + 8;              // two free words behind the area's scan total
+        HIPCHK(c, hipMemsetAsync(cnt, 0, 8, c->stream));
         if (Q) k_count_blocks<<<std::min<u32>(grid_for(Q, 256), 512u), 256, 0, c->stream>>>(c->mi_freq.as<u32>(), Q, 512u, 1024u, cnt);
-        HIPCHK(c, hipMemcpyAsync(&c->h_scalars[11], cnt, 4, hipMemcpyDeviceToHost, c->stream));
+        if (Q) k_count_blocks<<<std::min<u32>(grid_for(Q, 256), 512u), 256, 0, c->stream>>>(c->mi_freq.as<u32>(), Q, 256u, 512u, cnt + 1);
+        HIPCHK(c, hipMemcpyAsync(&c->h_scalars[11], cnt, 8, hipMemcpyDeviceToHost, c->stream));
     }
     if ((rc = sync_check(c))) return rc;
     c->rB = c->h_scalars[4];
     c->rnlarge = c->h_scalars[5];
     c->rn1024 = c->h_scalars[11];
+    c->rn512 = c->h_scalars[12];
     return DEBWT_OK;
 }
 
@@ -1015,7 +1018,7 @@ static int append_range(debwt_ctx *c, debwt_ctx::KeyRange &r) {
         if (r.qbase)
             k_offset_u32<<<grid_for(c->rnlarge, 256), 256, 0, c->stream>>>(c->large_q.as<u32>() + c->nlarge, c->rnlarge, (u32)r.qbase);
     }
-    c->nfacts_acc += nf; c->Q += Q; c->B += c->rB; c->nlarge += c->rnlarge; c->n1024 += c->rn1024;
+    c->nfacts_acc += nf; c->Q += Q; c->B += c->rB; c->nlarge += c->rnlarge; c->n1024 += c->rn1024; c->n512 += c->rn512;
     if (c->Q >= 0xFFFFFFF0ull) { c->err = "more than 2^32 multi-in blocks"; return DEBWT_ERANGE; }
     c->facts_ready = true;
     return sync_check(c);
@@ -1070,7 +1073,7 @@ extern "C" int debwt_classify(debwt_ctx *c) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc;
     if (!c->local_done) {
-        c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0;      // a repeated call starts over
+        c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0; c->n512 = 0;      // a repeated call starts over
         if ((rc = classify_local(c))) return rc;
         if ((rc = append_range(c, c->ranges[0]))) return rc;
     }
@@ -1532,8 +1535,11 @@ static int blue_sort_part(debwt_ctx *c, const BlueQueue &bq, u64 q0, u64 nq, u64
     // (k_blue_classify); what that finishes is marked in `done` and skipped by the kernels behind it, which take the blocks it
     // left (cfg.reserved bit 19: those kernels alone; bit 20: by classes whatever the number of such blocks -- tests)
     const bool split1024 = c->n1024 >= 1024;
+    // (... or many blocks of 257..512 rows and few above: four genomes -- the four-wave network over those blocks alone took
+    // 64 ms of a 654 ms build, by classes the blue stage is 78 ms instead of 116)
+    const bool by_classes = split1024 || c->n512 >= 1024;
     const u8 *done = nullptr;
-    if ((split1024 || (c->cfg.reserved & 1048576)) && sub.cap && !(c->cfg.reserved & 524288)) {
+    if ((by_classes || (c->cfg.reserved & 1048576)) && sub.cap && !(c->cfg.reserved & 524288)) {
         ENSURE(c, c->blue_done, c->Q + 64);
         u8 *dn = c->blue_done.as<u8>() + q0;
         HIPCHK(c, hipMemsetAsync(dn, 0, Q, c->stream));
@@ -2040,7 +2046,7 @@ extern "C" int debwt_shard_classify_local(debwt_ctx *c, uint64_t *nfacts, uint64
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (!c->local_done) {                                  // one text-fed range: its keys are still there
         if (c->ranges.size() != 1) return DEBWT_ESTATE;
-        c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0;
+        c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0; c->n512 = 0;
         int rc = classify_local(c);
         if (rc) return rc;
         if ((rc = append_range(c, c->ranges[0]))) return rc;
