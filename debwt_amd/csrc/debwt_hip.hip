@@ -1093,9 +1093,14 @@ static int sp_prepare(debwt_ctx *c) {
     const u64 ngroups = (c->n + 31) >> 5;
     ENSURE(c, c->momask, ngroups * 4 + 64);
     ENSURE(c, c->mimask, ngroups * 4 + 64);
-    // node table: 2..4 slots per red node; prefilter: ~8 bits per red node (tuning knob: reserved = delta+8)
+    // node table: 4..8 slots per red node; prefilter: ~8 bits per red node (tuning knob: reserved = delta+8)
+    // (4..8 slots per red node: at 2..4 a collection whose red nodes happened to fill the table by half -- eight genomes --
+    // spent 14 % more on the SP flags than one that filled it by a quarter -- ten --: 329 -> 281 ms of SP stage for 24 Gbp;
+    // ten genomes 364 -> 349, with an Alu-like family 586 -> 540, one genome 32.9 -> 28.6; 8..16 slots: 3 ms more for 30 Gbp)
     int hbits = 10;
-    while ((1ull << hbits) < 2 * c->R) hbits++;
+    u64 slots_per_node = 4;
+    if (const char *e = getenv("DEBWT_NODE_SLOTS")) slots_per_node = std::max<u64>(2, strtoull(e, nullptr, 10));   // A/B
+    while ((1ull << hbits) < slots_per_node * c->R) hbits++;
     // prefilter.  K >= 24: 64-bit words chosen by the node's minimizer, ~2 red nodes per word (stage_kernels.h,
     // k_build_mzfilter) -- a lane that walks 32 consecutive positions fetches ~4 words instead of probing 32 times.
     // Smaller K (or cfg.reserved bit 11: tests): one bit per hashed node, 8 bits per red node; while the node table
