@@ -1101,6 +1101,7 @@ static int sp_prepare(debwt_ctx *c) {
     u64 slots_per_node = 4;
     if (const char *e = getenv("DEBWT_NODE_SLOTS")) slots_per_node = std::max<u64>(2, strtoull(e, nullptr, 10));   // A/B
     while ((1ull << hbits) < slots_per_node * c->R) hbits++;
+    if (hbits > 31 && (1ull << 31) >= 2 * c->R) hbits = 31;      // (slots are 32-bit: 2..4 per node where 4..8 do not fit)
     // prefilter.  K >= 24: 64-bit words chosen by the node's minimizer, ~2 red nodes per word (stage_kernels.h,
     // k_build_mzfilter) -- a lane that walks 32 consecutive positions fetches ~4 words instead of probing 32 times.
     // Smaller K (or cfg.reserved bit 11: tests): one bit per hashed node, 8 bits per red node; while the node table
