@@ -846,8 +846,8 @@ static int sort_range(debwt_ctx *c, size_t i, u64 *imported) {
     RleSink sink{c->dk.as<u64>(), c->dstart.as<u32>(), c->mchar.as<u8>() + r.Mbase, c->rs_rle.p, &c->h_scalars[0],
                  &c->h_scalars[32], 0, (c->cfg.reserved & 131072) != 0,           // bit 17: no staging of distinct keys
                  // the sorted keys can be asked for (debwt_fetch_array) after the sort stage of a one-range build driven
-                 // stage by stage, and by nobody else: every other build keeps the encoding only (tune bit 23: keeps both -- A/B)
-                 (P > 1 || c->exchange || c->whole_build) && !(c->cfg.reserved & 8388608), false};
+                 // stage by stage on one GPU, and by nobody else: every other build keeps the encoding only (tune bit 23: keeps both -- A/B)
+                 (P > 1 || c->exchange || c->whole_build || c->shard_world > 1) && !(c->cfg.reserved & 8388608), false};
     if (imported && r.M < 2) c->sk = c->sort_a;
     else if ((rc = sort_keys(c, c->sort_a, c->sort_b, r.M, 2 * c->cfg.k, &c->sk, i == 0, imported ? nullptr : &ts, true,
                              (c->cfg.reserved & 256) ? nullptr : &sink))) return rc;
@@ -2344,8 +2344,8 @@ extern "C" int debwt_fetch_array(debwt_ctx *c, debwt_array which, void *dst, uin
         case DEBWT_ARR_DISTINCT_KEYS:
             if (c->ranges.size() != 1) { c->err = "sorted keys are not kept by a multi-range build"; return DEBWT_ESTATE; }
             // the key buffers are scratch for the later stages (blue-entry sort), and in exchange mode they are the caller's
-            if (which == DEBWT_ARR_SORTED_KEYS && (c->stage > ST_CLASSIFIED || c->exchange)) {
-                c->err = "sorted keys are only kept until the SP stage reuses their buffer (and not in exchange mode)";
+            if (which == DEBWT_ARR_SORTED_KEYS && (c->stage > ST_CLASSIFIED || c->exchange || c->shard_world > 1)) {
+                c->err = "sorted keys are only kept until the SP stage reuses their buffer (and not by a shard)";
                 return DEBWT_ESTATE;
             }
             if (which == DEBWT_ARR_SORTED_KEYS) { src = c->sk; cnt = c->M; } else { src = c->dk.p; cnt = c->D; }

@@ -328,8 +328,8 @@ const char *debwt_multi_step_name(int step);
 /* ---- intermediates, for stage-by-stage parity ---------------------------------- */
 typedef enum {
     DEBWT_ARR_SORTED_KEYS = 1, /* u64 x n_main: (node<<2|pred) ascending; after debwt_kmer_sort_rle of a one-range
-                                  build driven stage by stage only (debwt_build keeps the run-length encoding alone:
-                                  DEBWT_ESTATE, as in a build of several key ranges and in exchange mode)          */
+                                  build driven stage by stage on one GPU only (debwt_build and shards keep the
+                                  run-length encoding alone: DEBWT_ESTATE, as in a build of several key ranges)    */
     DEBWT_ARR_DISTINCT_KEYS,   /* u64 x distinct_keys                                                 */
     DEBWT_ARR_RED,             /* u64 x red_capacity: node<<2 | multiin<<1 | multiout, ascending      */
     DEBWT_ARR_SP_SYMBOLS,      /* u8  x sp_len: SP symbols 0..5                                       */
