@@ -1316,7 +1316,9 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
                 u64 *tmp = c->keysA.as<u64>();
                 if (c->keysA.cap < r.B * 8 + 64) { ENSURE(c, c->blue_tmp, r.B * 8 + 64); tmp = c->blue_tmp.as<u64>(); }
                 hipError_t e = hipSuccess;
-                res = radix_sort_bits(c->stream, reg, tmp, r.B, qshift, std::min(64, qshift + span), radix_ws(c), &e, qshift, &stripped);
+                // (an odd number of passes rotates through the other key buffer, so that the last one lands -- stripped -- in `reg`)
+                u64 *third = c->keysB.cap >= r.B * 8 + 64 && c->keysB.as<u64>() != tmp ? c->keysB.as<u64>() : nullptr;
+                res = radix_sort_bits(c->stream, reg, tmp, r.B, qshift, std::min(64, qshift + span), radix_ws(c), &e, qshift, &stripped, third);
                 if (e != hipSuccess) { c->err = std::string("blue entry sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
             }
             if (!stripped) k_blue_strip<<<grid_for(r.B, 256), 256, 0, c->stream>>>(res, reg, r.B, qshift);
@@ -1330,7 +1332,8 @@ extern "C" int debwt_sp_generate(debwt_ctx *c) {
         ENSURE(c, c->rs_over, radix_over_bytes(c->B));
         hipError_t e = hipSuccess;
         bool stripped = false;                                   // (the last pass strips when it writes to `blue`)
-        u64 *r = radix_sort_bits(c->stream, c->blue.as<u64>(), tmp, c->B, qshift, 64, radix_ws(c), &e, qshift, &stripped);
+        u64 *third = c->keysB.cap >= c->B * 8 + 64 && c->keysB.as<u64>() != tmp ? c->keysB.as<u64>() : nullptr;
+        u64 *r = radix_sort_bits(c->stream, c->blue.as<u64>(), tmp, c->B, qshift, 64, radix_ws(c), &e, qshift, &stripped, third);
         if (e != hipSuccess) { c->err = std::string("blue entry sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
         if (!stripped) k_blue_strip<<<grid_for(c->B, 256), 256, 0, c->stream>>>(r, c->blue.as<u64>(), c->B, qshift);
     }

@@ -80,10 +80,11 @@ hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const Te
 // valid positions); pass events are then recorded for the array-to-array passes only.
 // Stable LSD passes over the key bits [lo_bit, hi_bit) only (auxiliary kernels); a: input, b: scratch of n words;
 // returns the buffer that holds the result.
-// strip_last > 0: when the result comes to lie in `a` (an even number of passes), the last pass writes blue entries instead
-// of routed ones (RsDigit::out_strip = strip_last) and *stripped is set; otherwise the caller strips them itself.
+// strip_last > 0: when the result comes to lie in `a` (an even number of passes, or an odd number >= 3 with a second scratch
+// buffer `third` of n words to rotate through), the last pass writes blue entries instead of routed ones
+// (RsDigit::out_strip = strip_last) and *stripped is set; otherwise the caller strips them itself.
 u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
-                     hipError_t *err, int strip_last = 0, bool *stripped = nullptr);
+                     hipError_t *err, int strip_last = 0, bool *stripped = nullptr, u64 *third = nullptr);
 // sink (optional): when the hybrid path runs, the bucket finish also counts the distinct keys of every tile it has
 // in registers and writes the row symbols key & 3, and the run-length encoding of the sorted keys -- distinct keys,
 // first row of each (row = index in sorted order) -- follows tile by tile without a counting pass over the keys.

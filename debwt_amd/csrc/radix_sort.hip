@@ -1804,11 +1804,14 @@ size_t radix_over_bytes(u64 max_keys) { return 16 + (size_t)(max_keys / RL_H + 2
 
 static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
                    hipEvent_t *pass_events, int max_pairs, int *npairs, const TextKeySrc *text = nullptr,
-                   bool aux = false, int strip_last = 0) {
+                   bool aux = false, int strip_last = 0, u64 *third = nullptr) {
     // stable LSD passes over bits [lo_bit, hi_bit), 8 bits per pass starting at lo_bit.  With `text` the first
     // pass reads node keys from the text (its index space is the ts->n positions) and writes them to `a`.
+    // third (auxiliary sorts of an odd number of passes >= 3): a second scratch buffer, so that the LAST pass writes into `a`
+    // -- a -> b, b -> third, third -> b, ..., third -> a -- where two buffers would leave the result in b
     u64 *src = a, *dst = b;
     int p = 0, ev_idx = 0;
+    const int npasses = (hi_bit - lo_bit + 7) / 8;
     TextKeySrc none{};
     // (auxiliary sorts spread their bits evenly over the passes -- 29 bits of block id: 8 + 7 + 7 + 7, not 8 + 8 + 8 + 5: the
     // histogram of a 5-bit digit adds 128 keys a wave to 32 counters and took 9.2 ms for 3.9 G blue entries where the 8-bit
@@ -1850,7 +1853,8 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
         else if (shift >= 32) rs_scatter_kernel<0, 0, 1><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
         else rs_scatter_kernel<0, 0, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
         if (ev) { (void)hipEventRecord(pass_events[2 * ev_idx + 1], stream); ev_idx++; if (npairs) *npairs = ev_idx; }
-        u64 *t = src; src = dst; dst = t;
+        if (third) { src = dst; dst = p + 2 == npasses ? a : (src == b ? third : b); }
+        else { u64 *t = src; src = dst; dst = t; }
     }
     return src;
 }
@@ -1887,13 +1891,16 @@ hipError_t radix_text_hist_ranges(hipStream_t stream, const TextKeySrc &text, co
 }
 
 u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
-                     hipError_t *err, int strip_last, bool *stripped) {
+                     hipError_t *err, int strip_last, bool *stripped, u64 *third) {
     *err = hipSuccess;
     if (stripped) *stripped = false;
     if (n < 2 || hi_bit <= lo_bit) return a;
-    const bool fuse = strip_last > 0 && stripped && ((hi_bit - lo_bit + 7) / 8) % 2 == 0;   // the result comes to lie in `a`
+    const int npasses = (hi_bit - lo_bit + 7) / 8;
+    const bool rotate = strip_last > 0 && stripped && third && npasses % 2 == 1 && npasses >= 3;
+    const bool fuse = strip_last > 0 && stripped && (npasses % 2 == 0 || rotate);          // the result comes to lie in `a`
     if (fuse) *stripped = true;
-    u64 *r = rs_lsd(stream, a, b, n, lo_bit, hi_bit, ws, nullptr, 0, nullptr, nullptr, true, fuse ? strip_last : 0);
+    u64 *r = rs_lsd(stream, a, b, n, lo_bit, hi_bit, ws, nullptr, 0, nullptr, nullptr, true, fuse ? strip_last : 0,
+                    rotate ? third : nullptr);
     *err = hipGetLastError();
     return r;
 }
