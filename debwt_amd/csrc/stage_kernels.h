@@ -10,7 +10,9 @@
 //     void emit(u64 i, u32 off, u32 c)  called for EVERY index with its exclusive prefix
 // Chunks are contiguous so output order = input order (deterministic, no atomics).
 
+#ifndef CP_MAXCHUNKS
 #define CP_MAXCHUNKS 2048
+#endif
 
 #define CP_VEC 4   // consecutive elements per thread per iteration (independent loads in flight)
 
