@@ -1533,10 +1533,13 @@ static int blue_sort_part(debwt_ctx *c, const BlueQueue &bq, u64 q0, u64 nq, u64
     u32 g1 = (u32)std::min<u64>(Q, 1u << 16);
     // blocks of up to 16 rows -- in a collection of genomes most blocks: a node's one occurrence per genome -- four to a wave
     // (cfg.reserved bit 24: a wave each, like the other blocks of up to 128 rows -- tests, A/B)
-    const u32 tiny = (c->cfg.reserved & 16777216) ? 0u : BLUE_TINY;
-    if (tiny)
-        k_blue_tiny<<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, c->spn.as<u64>(), c->S, c->mchar.as<u8>(),
-                                              nullptr, nullptr);
+    const u32 tiny = (c->cfg.reserved & 16777216) ? 0u : 2 * BLUE_TINY;   // (17..32 rows: two to a wave)
+    if (tiny) {
+        k_blue_tiny<16><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, c->spn.as<u64>(), c->S, c->mchar.as<u8>(),
+                                                  nullptr, nullptr);
+        k_blue_tiny<32><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, c->spn.as<u64>(), c->S, c->mchar.as<u8>(),
+                                                  nullptr, nullptr);
+    }
     // small blocks are the bulk: a small LDS footprint keeps 32 single-wave workgroups per CU in flight
     k_blue_refine<64, 128, 0><<<g1, 64, 0, c->stream>>>(c->blue.as<u64>(), bst, bfr, bj0, Q, tiny,
                                                        c->spn.as<u64>(), c->S, c->mchar.as<u8>(), nullptr, nullptr, none);
@@ -1595,9 +1598,12 @@ static int blue_sort_part(debwt_ctx *c, const BlueQueue &bq, u64 q0, u64 nq, u64
                 c->S, c->mchar.as<u8>(), sub, nullptr, c->sub_depth.as<u32>(), snap, c->sub_freq.as<u32>());
         }
     }
-    if (tiny)
-        k_blue_tiny<<<gs, 64, 0, c->stream>>>(c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(),
-                                              sub_cap, c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count);
+    if (tiny) {
+        k_blue_tiny<16><<<gs, 64, 0, c->stream>>>(c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(),
+                                                  sub_cap, c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count);
+        k_blue_tiny<32><<<gs, 64, 0, c->stream>>>(c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(),
+                                                  sub_cap, c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count);
+    }
     k_blue_refine<64, 128, 0><<<gs, 64, 0, c->stream>>>(
         c->blue.as<u64>(), c->sub_start.as<u64>(), c->sub_freq.as<u32>(), c->sub_j0.as<u64>(), sub_cap, tiny,
         c->spn.as<u64>(), c->S, c->mchar.as<u8>(), c->sub_depth.as<u32>(), sub_count, none);

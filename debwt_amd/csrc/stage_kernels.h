@@ -1557,23 +1557,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ?
 // of the unresolved rows, stable counting ranks inside the tie group, new groups, census -- so the rows leave in the same
 // order; a group of 16 lanes whose block is finished idles until the other three are.
 #define BLUE_TINY 16u
+// G = lanes (and rows at most) per block: 16 -> four blocks per wave, 32 -> two (blocks of 17..32 rows)
+template <u32 G>
 __global__ __launch_bounds__(64) void k_blue_tiny(u64 *__restrict__ blue, const u64 *__restrict__ bstart,
                                                   const u32 *__restrict__ mi_freq, const u64 *__restrict__ mi_j0, u32 Q,
                                                   const u64 *__restrict__ spn, u64 S, u8 *__restrict__ mchar,
                                                   const u32 *__restrict__ depth0, const u32 *__restrict__ Qdev) {
     __shared__ u64 se[64], sw[64], sx[64];
     __shared__ u32 gcm[64];                                    // per tie group (slot of its first row): rows | symbols << 16
-    const u32 lane = threadIdx.x, grp = lane >> 4, r = lane & 15u, base = grp << 4;
+    constexpr u32 NG = 64u / G;
+    constexpr u64 GM = G == 32 ? 0xFFFFFFFFull : 0xFFFFull;
+    const u32 lane = threadIdx.x, grp = lane / G, r = lane & (G - 1u), base = grp * G;
     if (Qdev) { const u32 qd = *Qdev; Q = qd < Q ? qd : Q; }
     const u32 E = (u64)Q >= (u64)gridDim.x * 64 ? 64u : 1u;     // the table walk of k_blue_refine
     for (u64 q0 = (u64)blockIdx.x * E; q0 < Q; q0 += (u64)gridDim.x * E) {
         const u64 ql = q0 + lane;
         const u32 ml = (lane < E && ql < Q) ? mi_freq[ql] : 0u;
-        u64 todo = __ballot(ml > 0u && ml <= BLUE_TINY);
+        u64 todo = __ballot(ml > (G == 32 ? 16u : 0u) && ml <= G);
         while (todo) {
             u32 pick = 64u;                                    // the table entry of this lane's group (64: none left)
 #pragma unroll
-            for (u32 gi = 0; gi < 4; gi++)
+            for (u32 gi = 0; gi < NG; gi++)
                 if (todo) { const u32 b = (u32)__builtin_ctzll(todo); todo &= todo - 1; if (grp == gi) pick = b; }
             const bool has = pick < 64u;
             const u32 q = has ? (u32)(q0 + pick) : 0u;
@@ -1584,7 +1588,7 @@ __global__ __launch_bounds__(64) void k_blue_tiny(u64 *__restrict__ blue, const 
             u64 e = valid ? blue[b0 + r] : ~0ull;
             u32 syms = valid ? 1u << (e & 15) : 0u;
 #pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) syms |= (u32)__shfl_xor((int)syms, d, 64);   // (lanes r ^ d: the group's own)
+            for (int d = (int)G / 2; d >= 1; d >>= 1) syms |= (u32)__shfl_xor((int)syms, d, 64);   // (lanes r ^ d: the group's own)
             u32 gid = valid ? 0u : 0xFFu;                      // first row of the lane's tie group; 0xFF: no row
             u32 gc = m | (syms << 16);                         // census of the lane's tie group
             bool blk_active = m > 1u && (syms & (syms - 1u)) != 0u;
@@ -1595,9 +1599,9 @@ __global__ __launch_bounds__(64) void k_blue_tiny(u64 *__restrict__ blue, const 
                 u64 w = live ? sp_window(spn, pos) : 0ull, x = live ? sp_window(spn, pos + SP_WIN) : 0ull;
                 se[lane] = e; sw[lane] = w; sx[lane] = x;
                 __builtin_amdgcn_wave_barrier();
-                const u32 hs = base + (gid & 15u);
+                const u32 hs = base + (gid & (G - 1u));
                 const bool differs = unres && (w != sw[hs] || x != sx[hs]);
-                const bool re = blk_active && ((__ballot(differs) >> base) & 0xFFFFull) != 0ull;   // (uniform in the group)
+                const bool re = blk_active && ((__ballot(differs) >> base) & GM) != 0ull;   // (uniform in the group)
                 // stable counting ranks inside the tie groups that are not resolved
                 const bool mv = re && unres;
                 const u32 cnt = GC_CNT(gc);
@@ -1606,7 +1610,7 @@ __global__ __launch_bounds__(64) void k_blue_tiny(u64 *__restrict__ blue, const 
                 for (int d = 32; d >= 1; d >>= 1) { const u32 o = (u32)__shfl_xor((int)mc, d, 64); mc = mc > o ? mc : o; }
                 u32 rank = 0;
                 for (u32 t = 0; t < mc; t++) {
-                    const u32 y = (gid + t) & 15u;
+                    const u32 y = (gid + t) & (G - 1u);
                     const u64 wy = sw[base + y], xy = sx[base + y];
                     const bool less = wy != w ? wy < w : (xy != x ? xy < x : y < r);
                     rank += (mv && t < cnt && less) ? 1u : 0u;
@@ -1620,7 +1624,7 @@ __global__ __launch_bounds__(64) void k_blue_tiny(u64 *__restrict__ blue, const 
                 const u64 wp = __shfl_up(w, 1, 64), xp = __shfl_up(x, 1, 64);
                 u32 run = (r == 0u || gid != gp || w != wp || x != xp) ? r + 1u : 0u;
 #pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
+                for (int d = 1; d < (int)G; d <<= 1) {
                     const u32 o = (u32)__shfl_up((int)run, d, 64);
                     if ((int)r >= d) run = run > o ? run : o;
                 }
@@ -1633,7 +1637,7 @@ __global__ __launch_bounds__(64) void k_blue_tiny(u64 *__restrict__ blue, const 
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (re && valid) gc = gcm[base + gid];
-                const bool left = ((__ballot(valid && GC_UNRES(gc)) >> base) & 0xFFFFull) != 0ull;
+                const bool left = ((__ballot(valid && GC_UNRES(gc)) >> base) & GM) != 0ull;
                 if (blk_active) blk_active = (re ? left : true) && (d0 + depth + 1) * (2 * SP_WIN) < S + 2 * SP_WIN;
                 __builtin_amdgcn_wave_barrier();
             }
