@@ -1559,7 +1559,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ?
 #define BLUE_TINY 16u
 // G = lanes (and rows at most) per block: 16 -> four blocks per wave, 32 -> two (blocks of 17..32 rows)
 template <u32 G>
-__global__ __launch_bounds__(64) void k_blue_tiny(u64 *__restrict__ blue, const u64 *__restrict__ bstart,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blue_tiny(   // (64 VGPRs instead of 68: blue stage 173.7 -> 171.9 ms)
+    u64 *__restrict__ blue, const u64 *__restrict__ bstart,
                                                   const u32 *__restrict__ mi_freq, const u64 *__restrict__ mi_j0, u32 Q,
                                                   const u64 *__restrict__ spn, u64 S, u8 *__restrict__ mchar,
                                                   const u32 *__restrict__ depth0, const u32 *__restrict__ Qdev) {
