@@ -984,6 +984,47 @@ def test_tiles_that_stage_their_distinct_keys_need_not_write_their_sorted_keys_b
         d.close()
 
 
+def test_blocks_of_up_to_32_rows_several_to_a_wave_leave_their_rows_as_a_wave_each_does(api, oracle):
+    """k_blue_tiny holds a block of up to 16 rows in a 16-lane group (four blocks to a wave; 17..32 rows: two) and runs the
+    rounds of k_blue_refine for tie groups of up to 32 rows, stable ranks included: the sorted rows of those blocks -- not only
+    the BWT -- equal those of the wave-per-block kernel (tune bit 24), on ten near-identical genomes (blocks of ten rows that tie
+    for hundreds of SP symbols), on reads (blocks of a few rows) and on periodic stretches."""
+    from debwt_amd import synth
+    rng = np.random.default_rng(31)
+    per = []
+    for _ in range(40):
+        per.append(np.tile(rng.integers(0, 4, size=int(rng.integers(2, 9))).astype(np.uint8), int(rng.integers(20, 300))))
+        per.append(rng.integers(0, 4, size=int(rng.integers(40, 900))).astype(np.uint8))
+    genome = rng.integers(0, 4, size=30_000).astype(np.uint8)
+    reads = [genome[p:p + 100].copy() for p in rng.integers(0, len(genome) - 100, size=3000)]
+    n16 = n32 = 0
+    for recs in (synth.pan_genome(600_000, 10), reads, [np.concatenate(per)]):
+        got = []
+        for tune in (0, 1 << 24):
+            d = api.DeBWT(k=32, tune=tune)
+            d.load_records(recs)
+            d.build()
+            got.append(tuple(d.fetch()) + (d.fetch_array(api.ARR_BLUE),))
+            if tune == 0:
+                bound = d.fetch_array(api.ARR_BLUE_BOUND).astype(np.int64)
+                sizes = np.diff(np.concatenate([[-1], bound]))
+                n16 += int((sizes <= 16).sum()); n32 += int(((sizes > 16) & (sizes <= 32)).sum())
+                small = np.repeat(sizes <= 32, sizes)          # rows of the blocks k_blue_tiny takes
+            d.close()
+        a, b = got
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+        # (the rows of larger blocks may differ in order: a class of one symbol is finished wherever its rows land)
+        assert np.array_equal(a[3][:len(small)][small], b[3][:len(small)][small])
+    assert n16 > 100 and n32 > 0, (n16, n32)
+    ow, oh, od, _ = oracle.build_bwt(oracle.sym_from_codes(reads), 32)
+    d = api.DeBWT(k=32)
+    d.load_records(reads)
+    d.build()
+    w, h, dr = d.fetch()
+    assert np.array_equal(w, ow) and np.array_equal(h, oh) and dr == od
+    d.close()
+
+
 def test_randomised_parity_sweep(api, oracle):
     """200 random small collections x random k x random key-range caps x the alternative device paths (cursor atomics,
     64-bit cursors, no tie-group hand-off, separate run-length passes), two builds per context, against the oracle (scripts/gpu_fuzz.py runs the
