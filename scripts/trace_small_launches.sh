@@ -1,3 +1,6 @@
+#!/bin/bash
+# Long launches of small grids in the kernel trace of a run (three builds), with start time and neighbours
+# usage: scripts/trace_small_launches.sh WORKLOAD
 set -e
 W=$1
 ROOT=$(pwd)
