@@ -45,7 +45,12 @@ for c in range(cases):
     ow, oh, od, ost = O.build_bwt(sym, k)
     d = api.DeBWT(k=k, tune=tune)
     if cap: d.set_range_cap(cap)
-    d.load_records(recs)
+    try:
+        d.load_records(recs)
+    except ValueError as ex:                 # the generator's own records failed validation: say which and how
+        print(f"case {c} kind {kind} k {k} tune {tune} cap {cap}: {ex}; records: "
+              + str([(len(r), str(r.dtype), int(r.max()) if len(r) else None, int((r > 3).sum())) for r in recs][:10]), flush=True)
+        raise
     for rep in range(2):                     # a context is reusable
         d.build()
         w, h, dr = d.fetch()
