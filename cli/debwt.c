@@ -1,12 +1,19 @@
 /*
  * debwt.c -- host program with the reference's command line over libdebwt_hip.so.
  *
- *   deBWT -o OUT [-t T] [-k K] [-j DIR] [--device D | --gpus G [--devices a,b,...] [--keys auto|exchange|rescan] [--exchange peer|rccl]] [--iupac SEED] INPUT.fa[.gz]
+ *   deBWT -o OUT [-t T] [-k K] [-j DIR] [--device D | --gpus G [--devices a,b,...] [--keys auto|exchange|rescan] [--exchange peer|rccl]] [--iupac SEED]
+ *         [--verify] [--dump DIR] INPUT.fa[.gz]
  *
  * Same contract as /root/reference/src/main.c:25-53,175-186: options are `flag value` pairs, INPUT last;
  * -k 12..32 (default 32); -t (default 8) = host threads of the FASTA ingest; -j accepted and ignored (no Jellyfish); OUT is probed by create+remove before any work
  * (src/main.c:55-58); exit status 0 on success, 1 with a message on stderr otherwise.  Output files OUT,
  * OUT.#, OUT.$ are those of src/insertCase3.c:115-131.
+ * --verify (the only flag without a value) runs the job of the reference's unreachable developer mode (src/LFsearch.c:14-48 with
+ * the occ tables of src/insertCase3.c:139-208) on the device after the build: the inverse BWT of the rows must be the input
+ * text; exit status 1 when it is not.  --dump DIR writes the intermediates of every stage into DIR under the reference's file
+ * names and in its byte formats (kmerInfo src/mySort.c:193-195; redSeq, redPoint, blueBound, case3bound
+ * src/INandOut.c:347-366,396-417; spCode, spSpecialIndex, blueTable src/generateSP.c:626-672) and drives the stages one by one
+ * as src/main.c:83-149 does.
  */
 #include <fcntl.h>
 #include <pthread.h>
@@ -38,6 +45,10 @@ static void usage(void) {
                     "       default) or rccl (grouped ncclSend / ncclRecv over xGMI; one distinct GPU per shard)\n"
                     "--iupac (optional): seed; N and other ambiguity letters become pseudo-random bases of their sets\n"
                     "                    (what otherTool/transferN does, reproducibly)\n"
+                    "--verify (optional, takes no value): after the build, the inverse BWT is walked on the GPU and compared with the\n"
+                    "       input (the reference's LFsearch developer mode); exit status 1 on a mismatch\n"
+                    "--dump (optional): directory; kmerInfo, redSeq, redPoint, blueBound, case3bound, spCode, spSpecialIndex and\n"
+                    "       blueTable are written there in the reference's formats (one GPU, texts sorted in one key range)\n"
                     "reference: sequence in fasta format (plain or gzip)\n");
 }
 
@@ -112,9 +123,20 @@ static void *reserve_main(void *arg) {
     return NULL;
 }
 
+/* --verify: one summary line; 0 when the inverse BWT of the rows is the text */
+static int report_verify(int rc, const debwt_verify_report *r, const char *errtext) {
+    if (rc) { fprintf(stderr, "verify: %s %s\n", debwt_strerror(rc), errtext); return 1; }
+    printf("verify: inverse BWT %s: %lu LF steps in %lu segments, %lu mismatches, %lu broken links, %lu search failures "
+           "(index %.1f ms, search %.1f ms, walk %.1f ms)\n", r->ok ? "ok" : "FAILED", (unsigned long)r->steps,
+           (unsigned long)r->segments, (unsigned long)r->mismatches, (unsigned long)r->broken_links,
+           (unsigned long)r->search_failures, r->ms_index, r->ms_search, r->ms_walk);
+    if (!r->ok) fprintf(stderr, "verify: the inverse BWT of the result is NOT the input text\n");
+    return r->ok ? 0 : 1;
+}
+
 /* --gpus G: the same program over G GPUs (debwt_multi_*: one host thread per GPU inside the library) */
 static int multi_main(const char *source, const char *obj, int k, int threads, int iupac, unsigned long long seed, int gpus,
-                      const int *devs, int key_mode, int exchange) {
+                      const int *devs, int key_mode, int exchange, int verify) {
     double t0 = now();
     debwt_config cfg = {k, 0, 0, 0};
     debwt_multi *m = NULL;
@@ -152,14 +174,29 @@ static int multi_main(const char *source, const char *obj, int k, int threads, i
                t3 - t2, t4 - t3, st.key_bytes_in / 1e9, st.blue_bytes_in / 1e9);
         fprintf(stderr, "success output bwt!\n");
     } else fprintf(stderr, "fetch/write: %s\n", debwt_strerror(rc));
+    if (!rc && verify) {
+        debwt_verify_report rep;
+        memset(&rep, 0, sizeof rep);
+        int vrc = debwt_multi_verify(m, &rep);
+        rc = report_verify(vrc, &rep, debwt_multi_last_error(m));
+    }
     free(bwt); free(hash_rows);
     debwt_multi_destroy(m);
     return rc ? 1 : 0;
 }
 
 int main(int argc, char **argv) {
+    int verify = 0;
+    {   /* --verify is a flag without a value: taken out before the reference's pair-wise parse (src/main.c:25-48) */
+        int w = 1;
+        for (int i = 1; i < argc; i++) {
+            if (i < argc - 1 && !strcmp(argv[i], "--verify")) { verify = 1; continue; }
+            argv[w++] = argv[i];
+        }
+        argc = w;
+    }
     if (argc < 4 || (argc & 1) == 1) { usage(); return 1; }            /* src/main.c:25 */
-    const char *source = argv[argc - 1], *obj = NULL;
+    const char *source = argv[argc - 1], *obj = NULL, *dump = NULL;
     int k = 32, device = 0, iupac = 0, gpus = 0, devs[256], ndevs = 0, key_mode = -1, exchange = DEBWT_EXCHANGE_PEER_COPY;
     unsigned long long iupac_seed = 0;
     long threads = 8;
@@ -201,6 +238,7 @@ int main(int argc, char **argv) {
             else if (!strcmp(argv[i + 1], "peer")) exchange = DEBWT_EXCHANGE_PEER_COPY;
             else { usage(); return 1; }
         }
+        else if (!strcmp(argv[i], "--dump")) dump = argv[i + 1];
         else if (!strcmp(argv[i], "--iupac")) { iupac = 1; iupac_seed = strtoull(argv[i + 1], NULL, 10); }
         else { usage(); return 1; }
     }
@@ -216,8 +254,13 @@ int main(int argc, char **argv) {
         fprintf(stderr, "--devices names %d GPUs but --gpus asks for %d\n", ndevs, gpus);
         return 1;
     }
+    if (dump) {
+        struct stat sb;
+        if (gpus) { fprintf(stderr, "--dump: one GPU only (the intermediates of a sharded build are spread over its GPUs)\n"); return 1; }
+        if (stat(dump, &sb) || !S_ISDIR(sb.st_mode)) { fprintf(stderr, "--dump: %s is not a directory\n", dump); return 1; }
+    }
     if (gpus) return multi_main(source, obj, k, (int)(threads > 256 ? 256 : threads), iupac, iupac_seed, gpus,
-                                ndevs ? devs : NULL, key_mode, exchange);
+                                ndevs ? devs : NULL, key_mode, exchange, verify);
     double t0 = now();
     debwt_config cfg = {k, device, 0, 0};
     debwt_ctx *ctx = NULL;
@@ -260,7 +303,22 @@ int main(int argc, char **argv) {
     uint64_t *bwt = job.bwt, *hash_rows = malloc((nrec ? nrec : 1) * 8), dollar = 0;
     int bwt_pinned = bwt != NULL;
     if (!bwt) bwt = malloc(nw * 8);
-    rc = (bwt && hash_rows) ? debwt_build_to_host(ctx, bwt, hash_rows, &dollar) : DEBWT_ENOMEM;
+    if (!bwt || !hash_rows) rc = DEBWT_ENOMEM;
+    else if (!dump) rc = debwt_build_to_host(ctx, bwt, hash_rows, &dollar);
+    else {
+        /* the reference's stage sequence (src/main.c:83-149), the files of every stage written as it ends */
+        const char *what = "kmerInfo";
+        rc = debwt_dump_reference_files(ctx, dump, DEBWT_DUMP_KMERINFO);
+        if (!rc) { what = "kmer sort"; rc = debwt_kmer_sort_rle(ctx); }
+        if (!rc) { what = "classify"; rc = debwt_classify(ctx); }
+        if (!rc) { what = "redSeq / redPoint / blueBound / case3bound"; rc = debwt_dump_reference_files(ctx, dump, DEBWT_DUMP_BLOCKS); }
+        if (!rc) { what = "SP code"; rc = debwt_sp_generate(ctx); }
+        if (!rc) { what = "spCode / spSpecialIndex / blueTable"; rc = debwt_dump_reference_files(ctx, dump, DEBWT_DUMP_SP); }
+        if (!rc) { what = "blue sort"; rc = debwt_blue_sort(ctx); }
+        if (!rc) { what = "assembly"; rc = debwt_bwt_assemble(ctx); }
+        if (!rc) { what = "fetch"; rc = debwt_fetch_bwt(ctx, bwt, hash_rows, &dollar); }
+        if (rc) fprintf(stderr, "--dump %s: stage '%s' failed\n", dump, what);
+    }
     if (rc) fprintf(stderr, "build: %s %s\n", debwt_strerror(rc), debwt_last_error(ctx));
     double t3 = now();
     debwt_stats st;
@@ -284,15 +342,23 @@ int main(int argc, char **argv) {
            t1 - t0, threads, t1b - t1, job.seconds, t1c - t1b, t2 - t1c, t3 - t2, st.ms_total, st.ms_extract, st.ms_sort,
            st.ms_classify, st.ms_sp, st.ms_blue, st.ms_assemble, t4 - t3);
     fprintf(stderr, "success output bwt!\n");
+    if (dump) printf("intermediates in %s: kmerInfo redSeq redPoint blueBound case3bound spCode spSpecialIndex blueTable\n", dump);
+    int vfail = 0;
+    if (verify) {
+        debwt_verify_report rep;
+        memset(&rep, 0, sizeof rep);
+        int vrc = debwt_verify_device(ctx, NULL, NULL, 0, 0, &rep);
+        vfail = report_verify(vrc, &rep, debwt_last_error(ctx));
+    }
     if (n > ((uint64_t)1 << 30) && !getenv("DEBWT_CLI_TEARDOWN")) {
         /* the files are written and closed: a one-shot program leaves the hundreds of GB of device memory and page-locked
          * buffers to the operating system instead of unmapping them one by one first (1.5 s at 30 Gbp) */
         fflush(stdout); fflush(stderr);
-        _exit(0);
+        _exit(vfail);
     }
     if (bwt_pinned) debwt_pinned_free(bwt); else free(bwt);
     free(hash_rows);
     debwt_free_packed(&pt);
     debwt_destroy(ctx);
-    return 0;
+    return vfail;
 }

@@ -9,6 +9,7 @@ from . import _lib
 
 ARR_SORTED_KEYS, ARR_DISTINCT_KEYS, ARR_RED, ARR_SP_SYMBOLS, ARR_BLUE, ARR_BLUE_BOUND, ARR_CASE3_BOUND, \
     ARR_ROW_SYMBOLS = range(1, 9)
+DUMP_KMERINFO, DUMP_BLOCKS, DUMP_SP = 1, 2, 3
 _ARR_DTYPE = {ARR_SP_SYMBOLS: np.uint8, ARR_ROW_SYMBOLS: np.uint8}
 
 
@@ -200,6 +201,12 @@ class DeBWT:
         self._chk(self._L.debwt_fetch_array(self._h, which, out.ctypes.data_as(ctypes.c_void_p), cnt.value,
                                             ctypes.byref(cnt)))
         return out[:cnt.value]
+
+    def dump_reference_files(self, directory, stage):
+        """Intermediates of the stage just run as files in the reference's byte formats (debwt_dump_reference_files):
+        stage DUMP_KMERINFO (kmerInfo), DUMP_BLOCKS after classify() (redSeq, redPoint, blueBound, case3bound),
+        DUMP_SP after sp_generate() (spCode, spSpecialIndex, blueTable)."""
+        self._chk(self._L.debwt_dump_reference_files(self._h, str(directory).encode(), int(stage)))
 
     def kmer_count_sorted(self):
         """(kmers left-aligned, counts): the contents of the reference's kmerInfo (src/mySort.c:193-195)."""

@@ -288,11 +288,18 @@ extern "C" const char *debwt_strerror(int code) {
         case DEBWT_ESTATE: return "stage called out of order";
         case DEBWT_ERANGE: return "input exceeds a capacity of this build";
         case DEBWT_EINTERNAL: return "internal consistency check failed";
+        case DEBWT_EIO: return "file could not be written";
         default: return "unknown error";
     }
 }
 
 extern "C" const char *debwt_last_error(const debwt_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+extern "C" int debwt_get_config(const debwt_ctx *ctx, debwt_config *out) {
+    if (!ctx || !out) return DEBWT_EINVAL;
+    *out = ctx->cfg;
+    return DEBWT_OK;
+}
 
 extern "C" int debwt_create(const debwt_config *cfg, debwt_ctx **out) {
     if (!cfg || !out || cfg->k < 12 || cfg->k > 32) return DEBWT_EINVAL;   // src/main.c:41-47

@@ -31,6 +31,7 @@ extern "C" {
 #define DEBWT_ESTATE (-4)   /* stage called out of order */
 #define DEBWT_ERANGE (-5)   /* input exceeds a capacity of this build (see debwt_last_error) */
 #define DEBWT_EINTERNAL (-6)/* consistency check failed */
+#define DEBWT_EIO (-7)      /* a file could not be created or written (debwt_dump_reference_files) */
 
 typedef struct debwt_ctx debwt_ctx;
 
@@ -74,6 +75,7 @@ int debwt_create(const debwt_config *cfg, debwt_ctx **out);
 void debwt_destroy(debwt_ctx *ctx);
 const char *debwt_strerror(int code);
 const char *debwt_last_error(const debwt_ctx *ctx);   /* text of the last HIP/internal failure */
+int debwt_get_config(const debwt_ctx *ctx, debwt_config *out);   /* the configuration the context was created with */
 
 /* Replaces `collect`'s text hand-over (src/collect#$.c:61-90,100-113: files `reference`,
  * `specialSA`).  packed: ceil((n+32)/32) words in the format above (host memory, must stay valid
@@ -340,6 +342,23 @@ typedef enum {
 } debwt_array;
 /* Copies up to `capacity` elements; *count receives the element count of the array. */
 int debwt_fetch_array(debwt_ctx *ctx, debwt_array which, void *dst, uint64_t capacity, uint64_t *count);
+
+/* The same intermediates written as files in the byte formats of the reference's own temp files and global arrays, so
+ * that a build can be bisected stage by stage against the reference (cli/deBWT --dump DIR drives this; the names are the
+ * reference's, `oracle/_ref/ref_driver` in the build container writes the same set as OUT.<name>):
+ *   DEBWT_DUMP_KMERINFO  any time after the load (runs debwt_kmer_count_sorted: the pipeline is back at "text loaded"):
+ *                        kmerInfo = D x {u64 k-mer left-aligned, u64 count} (src/mySort.c:193-195);
+ *   DEBWT_DUMP_BLOCKS    after debwt_classify: redSeq, redPoint (src/INandOut.c:396-405), blueBound (:359-361),
+ *                        case3bound (:347-353), raw u64 arrays;
+ *   DEBWT_DUMP_SP        after debwt_sp_generate, before debwt_blue_sort: spCode (ceil(S / 32) words, 2 bits per symbol,
+ *                        separators as 3; src/generateSP.c:626-660), spSpecialIndex (N x u64, :630-641), blueTable
+ *                        (B x u64 pred | spIndex << 4, :666-672; the order INSIDE a block is the arrival order of the
+ *                        scan -- thread-dependent in the reference too -- only the set per block is defined).
+ * One-range builds driven stage by stage on one GPU (as debwt_fetch_array).  DEBWT_EIO: dir missing or not writable. */
+#define DEBWT_DUMP_KMERINFO 1
+#define DEBWT_DUMP_BLOCKS 2
+#define DEBWT_DUMP_SP 3
+int debwt_dump_reference_files(debwt_ctx *ctx, const char *dir, int stage);
 
 /* ---- primitives exposed for measurement and parity ------------------------------------------- */
 

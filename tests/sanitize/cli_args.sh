@@ -26,6 +26,15 @@ expect 0 $X -o $D/o --gpus 2 --exchange rccl $F
 expect 0 $X -o $D/o --gpus 2 --exchange peer --keys exchange $F
 expect 1 $X -o $D/o --gpus 2 --exchange pigeon $F
 expect 1 $X -o $D/o --gpus 2 $D/missing.fa
+expect 0 $X -o $D/o --verify $F
+expect 0 $X --verify -o $D/o -k 16 $F
+expect 0 $X -o $D/o --gpus 2 --verify $F
+DEBWT_STUB_VERIFY_FAIL=1 expect 1 $X -o $D/o --verify $F
+DEBWT_STUB_VERIFY_FAIL=1 expect 1 $X -o $D/o --gpus 2 --verify $F
+mkdir $D/dump; expect 0 $X -o $D/o --dump $D/dump --verify $F
+[ -f $D/dump/stage1 ] && [ -f $D/dump/stage2 ] && [ -f $D/dump/stage3 ] || { echo "--dump wrote no files"; bad=1; }
+expect 1 $X -o $D/o --dump $D/nodir $F
+expect 1 $X -o $D/o --gpus 2 --dump $D/dump $F
 L=$(python3 -c "print(','.join(['0']*400))"); expect 1 $X -o $D/o --devices $L $F
 expect 0 $X -o $D/o --gpus 2 $F          # (a failed run has removed OUT: the reference's create+remove probe, src/main.c:55-58)
 [ "$(wc -c < $D/o)" = 32 ] && [ "$(wc -c < $D/o.#)" = 16 ] && [ "$(wc -c < $D/o.\$)" = 8 ] || { echo "output sizes wrong"; bad=1; }

@@ -71,3 +71,29 @@ int debwt_multi_get_stats(const debwt_multi *m, debwt_multi_stats *st, debwt_sta
 int debwt_multi_fetch_bwt(debwt_multi *m, uint64_t *bwt, uint64_t *hash_rows, uint64_t *dollar) {
     (void)m; memset(bwt, 0x1B, ((N_ROWS + 31) / 32) * 8); hash_rows[0] = 5; hash_rows[1] = 9; *dollar = 77; return 0;
 }
+/* --verify / --dump (round 6).  DEBWT_STUB_VERIFY_FAIL in the environment makes the stub's verifier report a mismatch. */
+#include <stdio.h>
+static int stub_verify(debwt_verify_report *r) {
+    memset(r, 0, sizeof *r);
+    r->segments = 4; r->steps = N_ROWS; r->ok = getenv("DEBWT_STUB_VERIFY_FAIL") ? 0 : 1; r->mismatches = r->ok ? 0 : 3;
+    return 0;
+}
+int debwt_verify_device(debwt_ctx *c, const uint64_t *d_words, const uint64_t *hash_rows, uint64_t dollar_row, uint64_t segments,
+                        debwt_verify_report *r) {
+    (void)c; (void)d_words; (void)hash_rows; (void)dollar_row; (void)segments; return stub_verify(r);
+}
+int debwt_multi_verify(debwt_multi *m, debwt_verify_report *r) { (void)m; return stub_verify(r); }
+int debwt_kmer_sort_rle(debwt_ctx *c) { return c->loaded ? 0 : DEBWT_ESTATE; }
+int debwt_classify(debwt_ctx *c) { return c->loaded ? 0 : DEBWT_ESTATE; }
+int debwt_sp_generate(debwt_ctx *c) { return c->loaded ? 0 : DEBWT_ESTATE; }
+int debwt_blue_sort(debwt_ctx *c) { return c->loaded ? 0 : DEBWT_ESTATE; }
+int debwt_bwt_assemble(debwt_ctx *c) { return c->loaded ? 0 : DEBWT_ESTATE; }
+int debwt_dump_reference_files(debwt_ctx *c, const char *dir, int stage) {
+    (void)c;
+    char path[1024];
+    snprintf(path, sizeof path, "%s/stage%d", dir, stage);
+    FILE *f = fopen(path, "wb");
+    if (!f) return DEBWT_EIO;
+    fclose(f);
+    return 0;
+}

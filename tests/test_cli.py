@@ -147,3 +147,54 @@ def test_cli_multi_gpu_outputs_equal_reference_files(tmp_path, name, k, gpus, ke
     assert sha(out) == entry["sha256"]["bwt"] and sha(out + ".#") == entry["sha256"]["hash"]
     assert sha(out + ".$") == entry["sha256"]["dollar"]
     assert f"{gpus} GPUs, exchanges by peer-to-peer copies, keys {'exchanged' if keys == 'exchange' else 'rescanned'}" in r.stdout
+
+
+FILE_GOLDENS = [e for e in golden_manifest() if e["n"] < 400000 and e["k"] in (12, 32)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", FILE_GOLDENS, ids=lambda e: f"{e['name']}-k{e['k']}")
+def test_cli_dump_writes_the_reference_files(tmp_path, entry):
+    """SURVEY 8f-4 as the row is worded: `deBWT --dump DIR` leaves kmerInfo, redSeq, redPoint, blueBound and case3bound
+    byte-identical to the files the reference's own mySort / generateBlocks wrote (sha256 in tests/golden/manifest.json;
+    formats src/mySort.c:193-195, src/INandOut.c:347-366,396-417), spCode + spSpecialIndex that decode to the reference's
+    SP symbols, and a blueTable holding the reference's entries block by block (src/generateSP.c:626-672; the order inside
+    a block is the scan's arrival order in the reference too) -- and the build driven stage by stage still writes the
+    reference's OUT, OUT.#, OUT.$.  --verify beside it: one summary line, exit status 0."""
+    import hashlib
+    import refformat as RF
+    assert _have_cli()
+    fa = os.path.join(ROOT, "tests", "golden", entry["name"] + ".fa")
+    if not os.path.exists(fa):
+        from debwt_amd import fasta
+        fa = str(tmp_path / "in.fa")
+        fasta.write_fasta(fa, golden_records(entry))
+    out, dump = str(tmp_path / "OUT"), tmp_path / "dump"
+    dump.mkdir()
+    r = subprocess.run([CLI, "-o", out, "-k", str(entry["k"]), "--dump", str(dump), "--verify", fa], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "verify: inverse BWT ok" in r.stdout and f"{entry['n']} LF steps" in r.stdout
+    sha = entry["sha256"]
+    for name in ("kmerInfo", "redSeq", "redPoint", "blueBound", "case3bound"):
+        assert hashlib.sha256((dump / name).read_bytes()).hexdigest() == sha[name], name
+    u64 = lambda name: np.fromfile(dump / name, dtype=np.uint64)
+    sp_len = entry["counters"]["spCodeLen"] - 32
+    assert len(u64("spCode")) == (sp_len + 31) // 32 and len(u64("spSpecialIndex")) == entry["records"]
+    assert hashlib.sha256(RF.sp_symbols(u64("spCode"), sp_len, u64("spSpecialIndex")).tobytes()).hexdigest() == sha["spSymbols"]
+    assert hashlib.sha256(RF.blue_blocks_sorted(u64("blueTable"), u64("blueBound")).tobytes()).hexdigest() == sha["blueBlocks"]
+    for ext, key in (("", "bwt"), (".#", "hash"), (".$", "dollar")):
+        assert hashlib.sha256(open(out + ext, "rb").read()).hexdigest() == sha[key], ext
+
+
+@pytest.mark.gpu
+def test_cli_verify_rejects_a_result_that_is_not_the_bwt(tmp_path):
+    """`deBWT --verify` is the reference's LF walk (src/LFsearch.c:14-48) as a tool: exit status 0 and 'ok' on a build; the
+    same walk through the C ABI rejects the rows once two of them are swapped (the CLI verifies the context's own rows, so
+    the rejection is shown on the ABI: tests/test_gpu_verify.py has the full set)."""
+    assert _have_cli()
+    fa = os.path.join(ROOT, "tests", "golden", "special_branches.fa")
+    out = str(tmp_path / "OUT")
+    r = subprocess.run([CLI, "--verify", "-o", out, fa], capture_output=True, text=True)
+    assert r.returncode == 0 and "verify: inverse BWT ok" in r.stdout and "0 mismatches" in r.stdout, r.stderr
+    r = subprocess.run([CLI, "-o", out, "--gpus", "2", "--devices", "0,0", "--verify", fa], capture_output=True, text=True)
+    assert r.returncode == 0 and "verify: inverse BWT ok" in r.stdout, r.stderr
