@@ -227,6 +227,11 @@ def _strip_flags(argv, flags):
     return out
 
 
+try:                                 # (optional: ends the whole process tree of an extra; without it the launcher alone is ended)
+    import psutil
+except ImportError:
+    psutil = None
+
 _CHILD = {"p": None}                 # the child launch that is running now (launch_ranks' signal handler ends exactly it)
 
 
@@ -234,7 +239,16 @@ def _end_tree(p, grace=15.0):
     """End the child `p` and every process it started (exact PIDs: the children stay in this process group, so whoever
     ends bench.py by group ends them too): SIGTERM to the launcher -- torch.distributed.run hands it on to its workers --
     then SIGKILL to whatever is left after `grace` seconds."""
-    import psutil
+    if psutil is None:                                        # no psutil: the launcher alone (it hands SIGTERM on to its workers)
+        try:
+            p.terminate()
+            p.wait(grace)
+        except Exception:                                     # noqa: BLE001 -- still there after `grace`, or already gone
+            try:
+                p.kill()
+            except OSError:
+                pass
+        return
     try:
         tree = [psutil.Process(p.pid)] + psutil.Process(p.pid).children(recursive=True)
     except psutil.Error:
@@ -674,11 +688,21 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and args.k == 32 and world == 1:
             try:
+                import hashlib
                 j = json.load(open(pmc))
-                if j.get("workload") == args.workload:      # the PMC passes were run on this workload
+                src = os.path.join(ROOT, "debwt_amd", "csrc", "radix_sort.hip")
+                now = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+                then = (j.get("kernel_source") or {}).get("sha256")
+                if j.get("workload") != args.workload:      # the PMC passes were run on another workload
+                    pass
+                elif then is None or then != now:           # ... or on another version of the kernel: a stale counter is no counter
+                    traffic_source = ("dropped: profiles/pmc_latest.json was measured on radix_sort.hip "
+                                      f"{(then or 'unknown')[:12]}, this tree holds {(now or 'none')[:12]} -- rerun scripts/pmc_30g.sh")
+                else:
                     traffic = j.get("rs_scatter_bytes_per_launch")
                     traffic_source = ("profiles/pmc_latest.json: the builder's rocprofv3 --pmc passes on this workload "
-                                      f"({j.get('source', 'scripts/pmc_30g.sh')}), NOT a counter of this run")
+                                      f"({j.get('source', 'scripts/pmc_30g.sh')}) with radix_sort.hip {now[:12]} = the kernel of "
+                                      "this tree; NOT a counter of this run")
             except Exception:
                 traffic = None
         if sharded:
@@ -690,6 +714,8 @@ def main():
             par = "one GPU, k-mer-prefix key ranges sorted one after the other over the resident text"
         line = {
             "metric": METRIC, "value": round(value, 4), "unit": "Gbp/s", "n_gpus": args.gpus,
+            "timed_region": "packed text and result resident in HBM (debwt_build); SURVEY 8d's host DRAM -> host DRAM region, "
+                            "PCIe both ways inside, is the key `host_to_host`",
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak" if (world > 1 and not sharded) else "strong",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",

@@ -78,7 +78,7 @@ SYMBOLS = [
     "debwt_multi_verify", "debwt_multi_shard", "debwt_pinned_alloc", "debwt_pinned_free", "debwt_shard_key_mode",
     "debwt_multi_set_key_mode", "debwt_special_compare", "debwt_build_to_host", "debwt_multi_set_exchange", "debwt_reserve",
     "debwt_multi_set_serial", "debwt_multi_get_shard_report", "debwt_multi_step_name", "debwt_get_config",
-    "debwt_dump_reference_files",
+    "debwt_dump_reference_files", "debwt_shard_scratch",
 ]
 
 
@@ -244,6 +244,8 @@ def lib():
     L.debwt_bwt_census.argtypes = [vp, u64p]
     L.debwt_set_range_cap.restype = ctypes.c_int
     L.debwt_set_range_cap.argtypes = [vp, ctypes.c_uint64]
+    L.debwt_shard_scratch.restype = ctypes.c_int
+    L.debwt_shard_scratch.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), u64p]
     L.debwt_get_config.restype = ctypes.c_int
     L.debwt_get_config.argtypes = [vp, ctypes.POINTER(DebwtConfig)]
     L.debwt_dump_reference_files.restype = ctypes.c_int

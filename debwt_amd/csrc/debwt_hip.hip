@@ -102,6 +102,7 @@ struct debwt_ctx {
     bool shared_hist = false;   // the first-pass histograms of all ranges came from one scan of the text
     u64 Qtotal = 0;             // multi-in blocks of the whole text (all shards)
     u64 S_rank = 0, B_rank = 0; // SP symbols / multi-in positions of this shard's text slice (all its sub-slices)
+    u64 *routed = nullptr;      // ... and its routed blue entries (debwt_shard_sp_emit): a key buffer when one is free, else facts_tmp
     struct SubSlice { u64 g0, g1, S, B; };
     std::vector<SubSlice> sub;  // the slice in pieces of < 2^32 positions
     std::thread special_thread; // host special-region module, runs beside the key sort of the first range
@@ -1108,7 +1109,8 @@ static int sp_prepare(debwt_ctx *c) {
     u64 slots_per_node = 4;
     if (const char *e = getenv("DEBWT_NODE_SLOTS")) slots_per_node = std::max<u64>(2, strtoull(e, nullptr, 10));   // A/B
     while ((1ull << hbits) < slots_per_node * c->R) hbits++;
-    if (hbits > 31 && (1ull << 31) >= 2 * c->R) hbits = 31;      // (slots are 32-bit: 2..4 per node where 4..8 do not fit)
+    if (hbits > 32 && (1ull << 32) >= 2 * c->R) hbits = 32;      // (slot numbers are 32-bit: 2..4 per node where 4..8 do not fit --
+                                                                 //  k = 16 on a 3.1 Gbp text: 1.07 G branching 15-mers, a 64 GB table)
     // prefilter.  K >= 24: 64-bit words chosen by the node's minimizer, ~2 red nodes per word (stage_kernels.h,
     // k_build_mzfilter) -- a lane that walks 32 consecutive positions fetches ~4 words instead of probing 32 times.
     // Smaller K (or cfg.reserved bit 11: tests): one bit per hashed node, 8 bits per red node; while the node table
@@ -1129,8 +1131,9 @@ static int sp_prepare(debwt_ctx *c) {
         pb = (c->cfg.reserved & 15) ? hbits + (c->cfg.reserved & 15) - 8
                                      : (hbits <= 24 ? std::max(hbits, std::min(hbits + 3, 24)) : hbits + 3);
         if (pb < 10) pb = 10;
+        if (pb > 31) pb = 31;                                     // (a 256 MB bitmap: nearly every node of so small a K branches anyway)
     }
-    if (pb > 31 || hbits > 31) { c->err = "red table too large for 32-bit slots"; return DEBWT_ERANGE; }
+    if (pb > 31 || hbits > 32) { c->err = "more than 2^31 branching nodes: the node table has 2^32 slots"; return DEBWT_ERANGE; }
     c->hbits = hbits; c->pbits = pb;
     // absolute 32-bit fill cursors unless the context's blue slots need more bits (cfg.reserved bit 4 forces the
     // 64-bit form: tests)
@@ -1401,8 +1404,10 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
     std::vector<LsBlock> desc;
     std::vector<u32> bigidx;
     u32 round = 0;
-    static const u32 bin_rows = getenv("DEBWT_LS_BIN_ROWS") ? (u32)atoi(getenv("DEBWT_LS_BIN_ROWS")) : LS_BIN_ROWS;
-    static const u32 oversample = getenv("DEBWT_LS_OVERSAMPLE") ? (u32)atoi(getenv("DEBWT_LS_OVERSAMPLE")) : LS_OVERSAMPLE;
+    // sweep knobs (scripts/ls_sweep.sh), clamped: a range aims at >= 64 rows, >= 1 sample per range, and never fewer samples
+    // than ranges (k_ls_splitters takes sample (b + 1) * (ns / nb) - 1: ns / nb == 0 would index below the array)
+    static const u32 bin_rows = getenv("DEBWT_LS_BIN_ROWS") ? (u32)std::min(std::max(atoi(getenv("DEBWT_LS_BIN_ROWS")), 64), 1 << 20) : LS_BIN_ROWS;
+    static const u32 oversample = getenv("DEBWT_LS_OVERSAMPLE") ? (u32)std::min(std::max(atoi(getenv("DEBWT_LS_OVERSAMPLE")), 1), 64) : LS_OVERSAMPLE;
     const bool trace = getenv("DEBWT_TRACE_LARGE") != nullptr;
     while (!work.empty()) {
         next.clear();
@@ -1420,6 +1425,7 @@ static int sort_large_blocks(debwt_ctx *c, const BlueSub &sub, u64 l0, u64 nl) {
                 while (nb < LS_MAXBINS && (u64)nb * bin_rows < wk.m) nb <<= 1;
                 u32 ns = 64;
                 while (ns < LS_SAMPLES && ns < nb * oversample) ns <<= 1;        // a power of two (bitonic sort), a multiple of nb
+                while (nb > ns) nb >>= 1;                                          // (ns is capped at LS_SAMPLES: at least one sample per range)
                 desc.push_back(LsBlock{wk.b0, wk.j0, rows, wk.m, nb, ns, (u32)wgs, (u32)slots, wk.depth, wk.pivot, ns > 256u ? nbig : 0u});
                 if (ns > 256u) { bigidx.push_back((u32)(w1 - w0)); nbig++; }
                 rows += (wk.m + 1u) & ~1u;
@@ -1998,10 +2004,15 @@ extern "C" int debwt_shard_plan(debwt_ctx *c, const uint64_t *hist4096, uint32_t
         // exchange == 2 (keys rescanned, SP code and blue entries sliced): the caller's two blue-entry buffers come
         // after the sort, ~2 bytes per position of the share (8 bytes x 2 x ~0.1 multi-in positions per base); a sliced
         // SP stage (exchange != 0) keeps the block ids of the slice's multi-in positions (4 bytes each) between its passes
+        // exchange == 2 since round 6: the two blue-entry buffers ARE the key buffers (debwt_shard_scratch) and the routed
+        // entries sit in one of them, so what stays beside a range's workspace is what a one-GPU build holds: per position
+        // of the share 1 byte of row symbols, ~1.25 of blue entries and block ids, 0.25 of rows (3 with room for denser
+        // collections), per position of the text 0.6 of text, separator bits and flag masks, ~0.35 of SP code and its gather
+        // buffers, ~0.3 of node table, 0.25 of concatenated rows (1.5)
         const u64 share = c->n / (u64)c->shard_world;
-        int rc = default_range_cap(c, exchange == 1 ? 40 : 30,
-                                   share / 2 * 7 + (exchange ? share / 2 : 0) + (exchange == 2 ? share * 2 : 0) + c->n / 4 * 5 + (8ull << 30),
-                                   caller_held_bytes, &cap);
+        int rc = exchange == 2 ? default_range_cap(c, 30, share * 3 + c->n / 2 * 3 + (8ull << 30), caller_held_bytes, &cap)
+                               : default_range_cap(c, exchange == 1 ? 40 : 30, share / 2 * 7 + (exchange ? share / 2 : 0) + c->n / 4 * 5 + (8ull << 30),
+                                                   caller_held_bytes, &cap);
         if (rc) return rc;
     }
     int rc = cut_ranges(c, reinterpret_cast<const u64 *>(hist4096), bin_lo, bin_hi, cap, m);
@@ -2181,8 +2192,13 @@ extern "C" int debwt_shard_sp_emit(debwt_ctx *c, uint64_t sp_offset, uint8_t *d_
         c->err = "a routed blue entry cannot hold block id and SP index in 61 bits";
         return DEBWT_ERANGE;
     }
-    ENSURE(c, c->facts_tmp, c->B_rank * 8 + 64);
-    u64 *routed = c->facts_tmp.as<u64>();
+    // the routed entries of the slice: in key buffer A when the keys were read off the text (the buffer is free since the
+    // ranges were classified; debwt_shard_scratch hands B to the caller as its send buffer and A -- after the route -- as
+    // its receive buffer, so that a sliced SP stage holds no exchange buffer of its own beside the key buffers)
+    u64 *routed;
+    if (!c->exchange && c->keysA.cap >= c->B_rank * 8 + 64) routed = c->keysA.as<u64>();
+    else { ENSURE(c, c->facts_tmp, c->B_rank * 8 + 64); routed = c->facts_tmp.as<u64>(); }
+    c->routed = routed;
     u64 off = sp_offset, bseen = 0;
     int rc;
     for (const auto &sl : c->sub) {
@@ -2227,7 +2243,8 @@ extern "C" int debwt_shard_blue_route(debwt_ctx *c, const uint32_t *first_block_
     if (!c->B_rank) return sync_check(c);
     RsDigit dg{};
     dg.mode = 2; dg.bounds = c->qbounds.as<u32>(); dg.nb = w; dg.tshift = routed_qshift(c);
-    hipError_t e = radix_partition_by_shard(c->stream, c->facts_tmp.as<u64>(), nullptr, c->B_rank, (u64 *)d_out, dg, w,
+    if (!c->routed || (u64 *)d_out == c->routed) { c->err = "blue route: no routed entries, or the output is their own buffer"; return DEBWT_ESTATE; }
+    hipError_t e = radix_partition_by_shard(c->stream, c->routed, nullptr, c->B_rank, (u64 *)d_out, dg, w,
                                             radix_ws(c), (u64 *)offs, false, capacity);
     if (e != hipSuccess) { c->err = hipGetErrorString(e); return DEBWT_EDEVICE; }
     return DEBWT_OK;
@@ -2247,6 +2264,18 @@ extern "C" int debwt_shard_blue_place(debwt_ctx *c, uint64_t *d_entries, uint64_
     // bit 5.)
     if (count >= 2 && count < 0xFFFFFFF0ull - (1ull << 20) && !(c->cfg.reserved & 32)) {
         ENSURE(c, c->rs_over, radix_over_bytes(count));
+        // the passes of debwt_sp_generate's entry sort: bits spread evenly, the strip folded into the stores of the last one,
+        // which writes `blue`; an even number of passes takes its first hop through a free key buffer
+        {
+            u64 *third = nullptr;
+            for (DevBuf *kb : {&c->keysB, &c->keysA})
+                if (!third && kb->cap >= count * 8 + 64 && kb->as<u64>() != (u64 *)d_entries && !(c->exchange && kb == &c->keysA)) third = kb->as<u64>();
+            hipError_t e = hipSuccess;
+            if (radix_sort_bits_into(c->stream, (u64 *)d_entries, c->blue.as<u64>(), third, count, qshift, 64, radix_ws(c), &e, qshift)) {
+                if (e != hipSuccess) { c->err = std::string("blue entry sort: ") + hipGetErrorString(e); return DEBWT_EDEVICE; }
+                return sync_check(c);
+            }
+        }
         u64 *src = reinterpret_cast<u64 *>(d_entries), *dst = c->blue.as<u64>();
         for (int shift = qshift; shift < 64; shift += 8) {
             hipError_t e = hipSuccess;
@@ -2265,6 +2294,15 @@ extern "C" int debwt_shard_blue_place(debwt_ctx *c, uint64_t *d_entries, uint64_
                                                                                  c->qcursor.as<u32>(), c->blk_start.as<u64>(),
                                                                                  c->blue.as<u64>());
     return sync_check(c);
+}
+
+extern "C" int debwt_shard_scratch(debwt_ctx *c, int which, void **ptr, uint64_t *bytes) {
+    if (!c || !ptr || !bytes || which < 0 || which > 1) return DEBWT_EINVAL;
+    *ptr = nullptr; *bytes = 0;
+    if (c->stage < ST_CLASSIFIED || c->exchange) return DEBWT_OK;        // exchange mode: key buffer A is the caller's own
+    DevBuf &b = which == DEBWT_SCRATCH_SEND ? c->keysB : c->keysA;
+    *ptr = b.p; *bytes = b.cap;
+    return DEBWT_OK;
 }
 
 // Final concatenation: the shards' packed row ranges, each packed from its own first row, are

@@ -141,6 +141,7 @@ struct debwt_multi {
     std::vector<int> dev;
     std::vector<hipStream_t> stream;
     std::vector<DevMem> xa, xb, facts, allfacts, sp, allsp, part;
+    std::vector<void *> bsend;             // per shard: where its routed blue entries lie for the peers (a key buffer of its context, or xa)
     DevMem parts, out;                     // on the first GPU: the gathered row ranges, the concatenated BWT
     uint64_t n = 0, nrec = 0;
     debwt_packed_text own{};                // text packed by debwt_multi_load_fasta (the contexts read it during a build)
@@ -153,6 +154,8 @@ struct debwt_multi {
     Rccl rccl;
     std::vector<ncclComm_t> comm;           // one communicator per shard (ncclCommInitAll), created by the first RCCL build
     bool comm_dead = false;                 // an exchange failed inside its group: the communicators were aborted (abort_comms)
+    int posting = 0;                        // shards between "communicators alive" and the end of their group (under rv.m)
+    std::condition_variable posted;         // ... signalled when one of them leaves
     debwt_multi_stats st{};
     std::vector<debwt_shard_report> rep;    // per shard: wall ms per step, bytes per exchange, sizes (debwt_multi_get_shard_report)
     // what the threads publish for each other
@@ -198,7 +201,9 @@ long long xchg(debwt_multi *m, int r, void *dst, size_t esz, PtrOf ptr_of, OffOf
     std::vector<uint64_t> roff(G);                                 // where source s lands in dst (bytes)
     for (int s = 0; s < G; s++) { roff[s] = o * esz; o += cnt_of(s, r); }
     for (size_t k = 0; k < pieces; k++) {
-        { std::lock_guard<std::mutex> lk(m->rv.m); if (m->comm_dead) return -1; }
+        // check and registration are one step: abort_comms lets every registered shard finish posting (or times out on
+        // one that hangs inside RCCL, which is what ncclCommAbort is for) before the handles go
+        { std::lock_guard<std::mutex> lk(m->rv.m); if (m->comm_dead) return -1; m->posting++; }
         ncclResult_t e = m->rccl.GroupStart();
         for (int d = 0; d < G && e == ncclSuccess; d++) {
             const size_t bytes = cnt_of(r, d) * esz, a = std::min(bytes, k * RCCL_PIECE), b = std::min(bytes, (k + 1) * RCCL_PIECE);
@@ -209,6 +214,8 @@ long long xchg(debwt_multi *m, int r, void *dst, size_t esz, PtrOf ptr_of, OffOf
             if (b > a) e = m->rccl.Recv((char *)dst + roff[s] + a, b - a, ncclUint8, s, m->comm[r], m->stream[r]);
         }
         const ncclResult_t e2 = m->rccl.GroupEnd();
+        { std::lock_guard<std::mutex> lk(m->rv.m); m->posting--; }
+        m->posted.notify_all();
         if (e != ncclSuccess || e2 != ncclSuccess) {
             std::lock_guard<std::mutex> lk(m->rv.m);
             if (m->err.empty()) m->err = std::string("RCCL exchange: ") + m->rccl.GetErrorString(e != ncclSuccess ? e : e2);
@@ -247,9 +254,10 @@ struct StepTimer {
 // comm_dead set and posts nothing; debwt_multi_build drops the handles afterwards)
 void abort_comms(debwt_multi *m) {
     {
-        std::lock_guard<std::mutex> lk(m->rv.m);
+        std::unique_lock<std::mutex> lk(m->rv.m);
         if (m->comm_dead) return;
-        m->comm_dead = true;
+        m->comm_dead = true;                   // nobody registers from here on
+        m->posted.wait_for(lk, std::chrono::seconds(5), [&] { return m->posting == 0; });
     }
     for (ncclComm_t cm : m->comm) if (cm) (void)m->rccl.CommAbort(cm);
 }
@@ -383,19 +391,31 @@ void shard_thread(debwt_multi *m, int r) {
              [&](int s, int) { return m->slen[s]; });
     if (!rc) STEP(S_SP_IMPORT, debwt_shard_sp_import(c, (const uint8_t *)m->allsp[r].p, sp_total), "shard_sp_import");
 
-    // 5. blue entries of the slice -> the owners of their blocks
-    if (!rc) rc = m->xa[r].ensure((bloc + 64) * 8) ? 0 : DEBWT_ENOMEM;
-    if (!rc) STEP(S_BLUE_ROUTE, debwt_shard_blue_route(c, first_block.data(), (uint64_t *)m->xa[r].p, m->xa[r].cap / 8, m->boffs[r].data()),
+    // 5. blue entries of the slice -> the owners of their blocks.  The send and the receive buffer are the shard's own key
+    //    buffers where the keys were read off the text (free since the sort; debwt_shard_scratch), else allocations
+    void *bsend = nullptr, *brcv = nullptr;
+    uint64_t bsend_bytes = 0, brcv_bytes = 0;
+    if (!rc) { rc = debwt_shard_scratch(c, DEBWT_SCRATCH_SEND, &bsend, &bsend_bytes); if (rc) set_err(m, r, "shard_scratch"); }
+    if (!rc && bsend_bytes < (bloc + 64) * 8) {
+        rc = m->xa[r].ensure((bloc + 64) * 8) ? 0 : DEBWT_ENOMEM;
+        bsend = m->xa[r].p; bsend_bytes = m->xa[r].cap;
+    }
+    m->bsend[r] = bsend;
+    if (!rc) STEP(S_BLUE_ROUTE, debwt_shard_blue_route(c, first_block.data(), (uint64_t *)bsend, bsend_bytes / 8, m->boffs[r].data()),
                   "shard_blue_route");
     if (!barrier(rc)) return;
     uint64_t brecv = 0;
     for (int s = 0; s < G; s++) brecv += m->boffs[s][r + 1] - m->boffs[s][r];
-    rc = m->xb[r].ensure((brecv + 64) * 8) ? 0 : DEBWT_ENOMEM;
-    EXCHANGE(S_XBLUE, X_BLUE, m->xb[r].p, 8, [&](int s) { return m->xa[s].p; }, [&](int s, int d) { return m->boffs[s][d]; },
+    rc = debwt_shard_scratch(c, DEBWT_SCRATCH_RECV, &brcv, &brcv_bytes);       // (the routed entries it held are in the send buffer now)
+    if (!rc && brcv_bytes < (brecv + 64) * 8) {
+        rc = m->xb[r].ensure((brecv + 64) * 8) ? 0 : DEBWT_ENOMEM;
+        brcv = m->xb[r].p;
+    }
+    EXCHANGE(S_XBLUE, X_BLUE, brcv, 8, [&](int s) { return m->bsend[s]; }, [&](int s, int d) { return m->boffs[s][d]; },
              [&](int s, int d) { return m->boffs[s][d + 1] - m->boffs[s][d]; });
     if (r == 0) { uint64_t moved = 0; for (int s = 1; s < G; s++) moved += m->boffs[s][1] - m->boffs[s][0]; m->st.blue_bytes_in = moved * 8; }
     if (!barrier(rc)) return;
-    STEP(S_BLUE_PLACE, debwt_shard_blue_place(c, (uint64_t *)m->xb[r].p, brecv), "shard_blue_place");
+    STEP(S_BLUE_PLACE, debwt_shard_blue_place(c, (uint64_t *)brcv, brecv), "shard_blue_place");
 
     // 6. owned blocks and rows
     if (!rc) STEP(S_BLUE_SORT, debwt_blue_sort(c), "blue_sort");
@@ -455,6 +475,7 @@ extern "C" int debwt_multi_create(const debwt_config *cfg, const int *devices, i
     m->cuts.assign(ngpus, {});
     for (auto *v : {&m->nfacts, &m->nblocks, &m->brows, &m->slen, &m->rowbase, &m->rows, &m->nhash, &m->drow}) v->assign(ngpus, 0);
     m->hrows.assign(ngpus, {});
+    m->bsend.assign(ngpus, nullptr);
     m->rep.assign(ngpus, debwt_shard_report{});
     m->rv.n = ngpus;
     int rc = DEBWT_OK;
@@ -553,6 +574,18 @@ extern "C" int debwt_multi_build(debwt_multi *m) {
         m->err = "serial mode takes the shards one at a time: an RCCL exchange needs all of them at once (use peer copies)";
         return DEBWT_EINVAL;
     }
+    if (m->exchange_backend == DEBWT_EXCHANGE_RCCL && m->comm.empty()) {
+        // the communicators of the last build were aborted after a failed exchange: new ones, or a clear error -- never a
+        // silent change of the backend the caller configured
+        m->comm.assign(m->G, nullptr);
+        const ncclResult_t e = m->rccl.CommInitAll(m->comm.data(), m->G, m->dev.data());
+        if (e != ncclSuccess) {
+            m->comm.clear();
+            m->err = std::string("ncclCommInitAll after an aborted exchange: ") + m->rccl.GetErrorString(e) +
+                     " (debwt_multi_set_exchange(m, DEBWT_EXCHANGE_PEER_COPY) builds without RCCL)";
+            return DEBWT_EDEVICE;
+        }
+    }
     m->rv.failed = 0; m->rv.waiting = 0; m->rv.turn = 0;
     m->st = debwt_multi_stats{};
     m->rep.assign(m->G, debwt_shard_report{});
@@ -563,9 +596,8 @@ extern "C" int debwt_multi_build(debwt_multi *m) {
     shard_thread(m, 0);
     for (auto &t : th) t.join();
     m->st.ms_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (m->comm_dead) {                                           // aborted communicators are gone: the next RCCL build asks again
+    if (m->comm_dead) {      // aborted communicators are gone; the configured backend stays: the next build makes new ones (above)
         m->comm.clear(); m->comm_dead = false;
-        m->exchange_backend = DEBWT_EXCHANGE_PEER_COPY;
     }
     if (m->rv.failed) return m->rv.failed;
     m->built = true;

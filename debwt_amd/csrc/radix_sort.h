@@ -85,6 +85,11 @@ hipError_t radix_partition_by_shard(hipStream_t stream, const u64 *src, const Te
 // (RsDigit::out_strip = strip_last) and *stripped is set; otherwise the caller strips them itself.
 u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
                      hipError_t *err, int strip_last = 0, bool *stripped = nullptr, u64 *third = nullptr);
+// The same with the result in `dst`, another buffer than the input `a` (scratch afterwards), stripped by the last pass when
+// strip_last > 0; an even number of passes takes its first hop through `third` (n words).  Returns false, with nothing
+// launched, when that buffer is missing or the sort is trivial (n < 2, no bits).
+bool radix_sort_bits_into(hipStream_t stream, u64 *a, u64 *dst, u64 *third, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
+                          hipError_t *err, int strip_last = 0);
 // sink (optional): when the hybrid path runs, the bucket finish also counts the distinct keys of every tile it has
 // in registers and writes the row symbols key & 3, and the run-length encoding of the sorted keys -- distinct keys,
 // first row of each (row = index in sorted order) -- follows tile by tile without a counting pass over the keys.

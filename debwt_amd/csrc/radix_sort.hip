@@ -769,6 +769,163 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
     }
 }
 
+// The same pass with the waves of a workgroup scanning on their own (round 6; the default for AUX == 0).  What the kernel
+// above pays for beside the ranking is its collection: per round of 512 words a workgroup-wide scan and two barriers, and the
+// waves in lockstep.  Here wave w owns an eighth of the workgroup's words and an eighth of the tile buffer (SEG = 512
+// slots): it reads, tests and appends batch after batch of 64 words with nothing but a wave scan between them, until its
+// segment is full or its words are used up -- what does not fit stays in the lanes' masks for the next tile -- and only the
+// ranking and the flush of the tile are workgroup-wide (one barrier per tile where the collection took two per round).
+// The first pass may deal a chunk's keys to its digits' runs in any order (there is no earlier pass whose order it would
+// have to keep), and the chunk histograms it is handed count keys per chunk, whatever wave finds them.  The prefix tests
+// work on 32-bit windows (v_alignbit): a window lies in the range when (x - lo << 20) < (span << 20), and the borrow of
+// that comparison is shifted into the mask by an add-with-carry.
+typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
+template <int HI, int K31>
+__global__ __launch_bounds__(SC_NT) __attribute__((amdgpu_waves_per_eu(RS_WAVES_EU, RS_WAVES_EU)))
+void rs_scatter_sparse_waves_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 chunk, RsDigit dg,
+                                    const u32 *__restrict__ offsets, const u32 *__restrict__ digit_base, u32 nchunks) {
+    constexpr int DG = HI ? 2 : 1;
+    constexpr u32 SEG = RS_TILE / SC_WAVES;
+    static_assert(SEG == 64 * SC_ITEMS, "a wave's segment is its eight rounds of 64 keys");
+    __shared__ ScShared sh;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid < RS_RADIX) {
+        sh.run[tid] = offsets[(u64)tid * nchunks + blockIdx.x] + digit_base[tid];
+        sh.cc[tid] = 0;
+    }
+    const u32 oalign = (u32)(reinterpret_cast<uintptr_t>(out) >> 3) & (SC_LINE - 1u);
+    const u64 beg = (u64)blockIdx.x * chunk;                  // a multiple of RS_TILE: word-aligned
+    const u64 end = beg + chunk < n ? beg + chunk : n;
+    const int K = ts.K, nsh = 64 - 2 * K, kb = 2 * K + 2;
+    const u64 kmask = (1ull << K) - 1ull;
+    const u32 lo12 = (u32)(ts.key_lo >> (kb - 12)), hi12 = ts.key_hi ? (u32)(ts.key_hi >> (kb - 12)) : 4096u;
+    // a proper key range: span < 4096 bins, so both bounds fit the 16-bit windows the tests work on
+    const u32 lo16 = lo12 << 4, span16 = (hi12 - lo12) << 4;
+    const rs_u16x2 lo16v = {(unsigned short)lo16, (unsigned short)lo16}, span16v = {(unsigned short)span16, (unsigned short)span16};
+    lds_barrier();
+    const u64 nwords = beg < end ? (end - beg + 31) >> 5 : 0;
+    const u64 per = ((nwords + SC_WAVES - 1) / SC_WAVES + 63) & ~63ull;
+    u64 wcur = (u64)w * per < nwords ? (u64)w * per : nwords;         // this wave's words: [wcur, wend)
+    const u64 wend = wcur + per < nwords ? wcur + per : nwords;
+    u64 nw0 = 0, nw1 = 0, nwp = 0, nsa = 0, nsb = 0;
+    auto fetch = [&](u64 wb) {                                        // the batch after the one being worked on
+        const u64 i0 = beg + ((wb + lane) << 5);
+        if (wb + lane < wend && i0 < end) {
+            const u64 p = ts.pos0 + i0, g = p >> 5;
+            nw0 = ts.text[g]; nw1 = ts.text[g + 1];
+            nwp = g ? ts.text[g - 1] : 3ull;                   // the 'T' that stands at separators goes before the text
+            nsa = ts.sepbits[p >> 6]; nsb = ts.sepbits[(p >> 6) + 1];
+        }
+    };
+    fetch(wcur);
+    // the current batch of this lane: A = the symbol before its word and the word's first 31 symbols, B1 = (its last symbol
+    // and the next word's first 31) >> 1 -- the 64-bit window that starts one symbol before position t is
+    // (A << 2t) | (B1 >> (63 - 2t)) for every t in 0..31, no special case
+    u64 A = 0, B1 = 0;
+    u32 m = 0;
+    bool pending = false;                                             // (wave-uniform) keys of the current batch left in the masks
+    for (;;) {
+        u32 fill = 0;                                                 // (wave-uniform) keys in this wave's segment
+        for (;;) {
+            if (!pending) {
+                if (wcur >= wend) break;
+                const u64 idx0 = beg + ((wcur + lane) << 5);
+                const bool mine = wcur + lane < wend && idx0 < end;
+                const u64 w0 = nw0, w1 = nw1;
+                A = (nwp << 62) | (w0 >> 2);
+                B1 = ((w0 & 3ull) << 61) | (w1 >> 3);
+                const u64 sa = nsa, sbw = nsb;
+                wcur += 64;
+                if (wcur < wend) fetch(wcur);
+                m = 0;
+                if (mine) {
+                    const u32 a0 = (u32)(w0 >> 32), a1 = (u32)w0, a2 = (u32)(w1 >> 32);
+                    // the 32-bit window at position t holds the 16-bit windows of t (high half) and t + 8 (low half): one
+                    // packed subtract, one packed saturating subtract (span - y: non-zero exactly when y < span) and one
+                    // packed minimum with 1 test both; eight windows cover 16 positions
+                    u32 acc0 = 0, acc1 = 0;
+#pragma unroll
+                    for (int t = 7; t >= 0; t--) {
+                        const u32 x0 = t == 0 ? a0 : __builtin_amdgcn_alignbit(a0, a1, 32 - 2 * t);
+                        const u32 x1 = t == 0 ? a1 : __builtin_amdgcn_alignbit(a1, a2, 32 - 2 * t);
+                        const rs_u16x2 one = {1, 1};
+                        const rs_u16x2 y0 = __builtin_bit_cast(rs_u16x2, x0) - lo16v, y1 = __builtin_bit_cast(rs_u16x2, x1) - lo16v;
+                        const rs_u16x2 z0 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(span16v, y0), one);
+                        const rs_u16x2 z1 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(span16v, y1), one);
+                        acc0 = (acc0 << 1) | __builtin_bit_cast(u32, z0);
+                        acc1 = (acc1 << 1) | __builtin_bit_cast(u32, z1);
+                    }
+                    // acc: bits 16..23 = positions 0..7 of its half-word, bits 0..7 = positions 8..15
+                    m = ((acc0 >> 16) & 0xFFu) | ((acc0 & 0xFFu) << 8) | (((acc1 >> 16) & 0xFFu) << 16) | ((acc1 & 0xFFu) << 24);
+                    const u32 shp = (u32)((ts.pos0 + idx0) & 63ull);  // 0 or 32
+                    const u64 sb = shp ? (sa >> 32) | (sbw << 32) : sa;
+                    if (sb) {                                         // a separator within 64 positions: rare, tested apart
+#pragma unroll
+                        for (u32 t = 0; t < 32; t++)
+                            if ((sb >> t) & kmask) m &= ~(1u << t);
+                    }
+                    const u32 lim = end - idx0 < 32 ? (u32)(end - idx0) : 32u;
+                    if (lim < 32) m &= (1u << lim) - 1u;
+                }
+            }
+            const u32 cnt = (u32)__popc(m);
+            const u32 incl = wave_scan_incl(cnt);
+            const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            const u32 room = SEG - fill;
+            const u32 woff = incl - cnt;
+            u32 take = woff >= room ? 0u : (cnt < room - woff ? cnt : room - woff);
+            u32 o = w * SEG + fill + woff;
+            while (take--) {
+                const u32 s2 = 2u * ((u32)__ffs(m) - 1u);
+                m &= m - 1u;
+                const u64 W = (A << s2) | (B1 >> (63u - s2));          // pred(t), then the 31 symbols from t on
+                if (K31) sh.skeys[o++] = (W << 2) | (W >> 62);          // node << 2 | pred: a rotation
+                else sh.skeys[o++] = (((W << 2) >> nsh) << 2) | (W >> 62);
+            }
+            pending = tot > room;
+            fill = pending ? SEG : fill + tot;
+            if (fill == SEG) break;
+        }
+        const bool more = pending || wcur < wend;
+        if (lane == 0) sh.scan_tmp[w] = fill | (more ? 0x10000u : 0u);
+        // this wave's keys: its own segment (LDS serves a wave in order: its appends are there)
+        u64 key[SC_ITEMS];
+        u32 vmask = 0;
+#pragma unroll
+        for (int r = 0; r < SC_ITEMS; r++) {
+            const bool have = (u32)r * 64u + lane < fill;
+            key[r] = have ? sh.skeys[w * SEG + (u32)r * 64u + lane] : ~0ull;
+            vmask |= (have ? 1u : 0u) << r;
+        }
+        lds_barrier();                                                // every wave holds its keys: skeys becomes rank state
+        u32 total = 0, maxfill = 0, anymore = 0;
+#pragma unroll
+        for (u32 i = 0; i < SC_WAVES; i++) {
+            const u32 v = sh.scan_tmp[i], f = v & 0xFFFFu;
+            total += f; maxfill = f > maxfill ? f : maxfill; anymore |= v >> 16;
+        }
+        if (total) {                                                  // (workgroup-uniform)
+            rs_clear_rank_state(sh);
+            lds_barrier();
+            const int tile_tot = (int)rs_rank_tile<DG, 0>(key, vmask, dg, sh, oalign, (maxfill + 63u) / 64u);
+            rs_flush_heads(sh, out, dg);
+            u64 k[SC_ITEMS];
+#pragma unroll
+            for (int r = 0; r < SC_ITEMS; r++) k[r] = sh.skeys[tid + r * SC_NT];
+            lds_barrier();
+            rs_flush_body<DG>(sh, dg, out, k, tile_tot);
+            lds_barrier();
+        }
+        if (!anymore) break;
+    }
+#pragma unroll
+    for (u32 i = 0; i < RS_RADIX * SC_LINE / SC_NT; i++) {
+        const u32 p = i * SC_NT + tid, d = p / SC_LINE, s2 = p % SC_LINE;
+        const u32 cc = sh.cc[d];
+        if (s2 < cc) out[sh.run[d] - cc + s2] = sh.carry[d][s2];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // hybrid: local finish of prefix buckets in LDS
 
@@ -1804,14 +1961,18 @@ size_t radix_over_bytes(u64 max_keys) { return 16 + (size_t)(max_keys / RL_H + 2
 
 static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
                    hipEvent_t *pass_events, int max_pairs, int *npairs, const TextKeySrc *text = nullptr,
-                   bool aux = false, int strip_last = 0, u64 *third = nullptr) {
+                   bool aux = false, int strip_last = 0, u64 *third = nullptr, u64 *final_dst = nullptr) {
     // stable LSD passes over bits [lo_bit, hi_bit), 8 bits per pass starting at lo_bit.  With `text` the first
     // pass reads node keys from the text (its index space is the ts->n positions) and writes them to `a`.
     // third (auxiliary sorts of an odd number of passes >= 3): a second scratch buffer, so that the LAST pass writes into `a`
     // -- a -> b, b -> third, third -> b, ..., third -> a -- where two buffers would leave the result in b
+    // final_dst (auxiliary sorts whose result belongs in ANOTHER buffer than their input): pass i of P writes into final_dst
+    // when P - i is even and else into whichever of `a` / `third` it does not read -- a -> final_dst -> a -> final_dst for an
+    // odd P, a -> third -> final_dst -> a -> final_dst for an even one (`b` is not used then)
     u64 *src = a, *dst = b;
     int p = 0, ev_idx = 0;
     const int npasses = (hi_bit - lo_bit + 7) / 8;
+    if (final_dst) dst = (npasses - 1) % 2 == 0 ? final_dst : third;
     TextKeySrc none{};
     // (auxiliary sorts spread their bits evenly over the passes -- 29 bits of block id: 8 + 7 + 7 + 7, not 8 + 8 + 8 + 5: the
     // histogram of a 5-bit digit adds 128 keys a wave to 32 counters and took 9.2 ms for 3.9 G blue entries where the 8-bit
@@ -1833,7 +1994,15 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
             rs_scan_digit_kernel<<<RS_RADIX, 1024, 0, stream>>>(ws.counts, nchunks, digit_tot);
             rs_scan_tot_kernel<<<1, RS_RADIX, 0, stream>>>(digit_tot);
             const bool sparse = text->key_lo || text->key_hi;                  // a key range: most positions yield nothing
-            if (sparse && shift >= 32) rs_scatter_sparse_kernel<1><<<nchunks, SC_NT, 0, stream>>>(*text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
+            // a key range read off the text: the waves of a workgroup scan on their own (DEBWT_SPARSE_LOCKSTEP=1: the kernel of
+            // rounds 3-5, whose waves collect a tile together -- A/B); a range that is the whole key space of a shard's bin
+            // table (AUX) and ranges of 4096 bins keep the old kernel
+            static const bool lockstep = getenv("DEBWT_SPARSE_LOCKSTEP") != nullptr;
+            const bool waves = sparse && !lockstep && (text->pos0 & 31ull) == 0;
+            if (waves && shift >= 32 && text->K == 31) rs_scatter_sparse_waves_kernel<1, 1><<<nchunks, SC_NT, 0, stream>>>(*text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
+            else if (waves && shift >= 32) rs_scatter_sparse_waves_kernel<1, 0><<<nchunks, SC_NT, 0, stream>>>(*text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
+            else if (waves) rs_scatter_sparse_waves_kernel<0, 0><<<nchunks, SC_NT, 0, stream>>>(*text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
+            else if (sparse && shift >= 32) rs_scatter_sparse_kernel<1><<<nchunks, SC_NT, 0, stream>>>(*text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
             else if (sparse) rs_scatter_sparse_kernel<0><<<nchunks, SC_NT, 0, stream>>>(*text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
             else if (shift >= 32) rs_scatter_kernel<1, 0, 1><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
             else rs_scatter_kernel<1, 0, 0><<<nchunks, SC_NT, 0, stream>>>(nullptr, *text, a, text->n, chunk, dg, ws.counts, digit_tot, nchunks);
@@ -1853,7 +2022,8 @@ static u64 *rs_lsd(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int hi
         else if (shift >= 32) rs_scatter_kernel<0, 0, 1><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
         else rs_scatter_kernel<0, 0, 0><<<nchunks, SC_NT, 0, stream>>>(src, none, dst, n, chunk, dg, ws.counts, digit_tot, nchunks);
         if (ev) { (void)hipEventRecord(pass_events[2 * ev_idx + 1], stream); ev_idx++; if (npairs) *npairs = ev_idx; }
-        if (third) { src = dst; dst = p + 2 == npasses ? a : (src == b ? third : b); }
+        if (final_dst) { src = dst; dst = (npasses - (p + 2)) % 2 == 0 ? final_dst : (src == a ? third : a); }
+        else if (third) { src = dst; dst = p + 2 == npasses ? a : (src == b ? third : b); }
         else { u64 *t = src; src = dst; dst = t; }
     }
     return src;
@@ -1903,6 +2073,19 @@ u64 *radix_sort_bits(hipStream_t stream, u64 *a, u64 *b, u64 n, int lo_bit, int 
                     rotate ? third : nullptr);
     *err = hipGetLastError();
     return r;
+}
+
+// The same sort with the result -- stripped by the last pass when strip_last > 0 -- in `dst` (another buffer than the input
+// `a`, which is scratch afterwards); an even number of passes needs `third` for its first hop.  False: that buffer is missing
+// (nothing was launched).
+bool radix_sort_bits_into(hipStream_t stream, u64 *a, u64 *dst, u64 *third, u64 n, int lo_bit, int hi_bit, const RadixWorkspace &ws,
+                          hipError_t *err, int strip_last) {
+    *err = hipSuccess;
+    const int npasses = (hi_bit - lo_bit + 7) / 8;
+    if (n < 2 || npasses < 1 || (npasses % 2 == 0 && !third) || a == dst) return false;
+    u64 *r = rs_lsd(stream, a, nullptr, n, lo_bit, hi_bit, ws, nullptr, 0, nullptr, nullptr, true, strip_last, third, dst);
+    *err = hipGetLastError();
+    return r == dst;
 }
 
 u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, const RadixWorkspace &ws, int algo,

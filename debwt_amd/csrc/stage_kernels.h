@@ -545,6 +545,7 @@ struct __attribute__((aligned(16))) HSlot {
     u32 q;      // global block id
 };
 #define HCURSOR_SKIP 0xFFFFFFFFu
+__device__ __forceinline__ u32 hmask(int hbits) { return hbits >= 32 ? 0xFFFFFFFFu : (1u << hbits) - 1u; }   // up to 2^32 slots (64 GB)
 __device__ __forceinline__ u32 red_hash(u64 node, int bits) { return (u32)((node * 0x9E3779B97F4A7C15ull) >> (64 - bits)); }
 __device__ __forceinline__ u32 red_hash2(u64 node, int bits) { return (u32)((node * 0xC2B2AE3D27D4EB4Full) >> (64 - bits)); }
 
@@ -586,7 +587,7 @@ __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__re
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const u64 v = red[r], node = v >> 2;
-    const u32 mask = (1u << hbits) - 1u;
+    const u32 mask = hmask(hbits);
     u32 h = 0;
     bool placed = false;
     if (mzK) {
@@ -636,7 +637,7 @@ __global__ void k_build_mzfilter(const u64 *__restrict__ red, u64 R, int K, int 
 
 // returns the slot (or 0xFFFFFFFF) and the flags of `node`; mzK > 0: the table is addressed by minimizer (k_build_hash)
 __device__ __forceinline__ u32 red_lookup(const HSlot *__restrict__ htab, int hbits, u64 node, u32 *flags, int mzK = 0) {
-    const u32 mask = (1u << hbits) - 1u;
+    const u32 mask = hmask(hbits);
     if (mzK) {
         u32 o;
         const u32 m = mz_of_node(node, mzK, &o);
@@ -658,7 +659,7 @@ __device__ __forceinline__ u32 red_lookup(const HSlot *__restrict__ htab, int hb
 
 // the same with the slot read as one 16-byte word: flags and the block id of `node` (q is meaningful for a multi-in node)
 __device__ __forceinline__ u32 red_lookup_q(const HSlot *__restrict__ htab, int hbits, u64 node, u32 *q) {
-    const u32 mask = (1u << hbits) - 1u;
+    const u32 mask = hmask(hbits);
     u32 h = red_hash(node, hbits);
     for (;;) {
         const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&htab[h]);
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_
             u32 fl, q = 0;
             if ((v[b].x >> 2) == nd[b]) { fl = (u32)(v[b].x & 3ull); q = (u32)(v[b].y >> 32); }
             else {                                              // the home slot holds another node: on along the line
-                const u32 mask = (1u << hbits) - 1u;
+                const u32 mask = hmask(hbits);
                 u32 h = (hh[b] + 1u) & mask;
                 fl = 0;
                 for (;;) {
@@ -1076,7 +1077,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_blue_fill(const ulonglong2 *__r
     ulonglong2 it = mi_list[b];
     u32 fl;
     u32 h = red_lookup(htab, hbits, it.x, &fl, mzK);
-    if (h == 0xFFFFFFFFu) return;
+    if (!fl) return;                                                        // (a red node carries a flag; with 2^32 slots every h is a slot)
     if (ABS32) {
         if (htab[h].cur == HCURSOR_SKIP) return;                            // block owned by another shard
         u32 slot = atomicAdd(&htab[h].cur, 1u);                             // absolute slot: starts at the block start

@@ -263,6 +263,7 @@ class Workspace:
         self.d, self.mode = d, mode
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.buf = {}
+        self.blue_bufs = None       # (send, receive) buffers of the last blue-entry exchange
         self.result = None          # rank 0 after a build: (words tensor on the GPU, hash_rows, dollar_row)
         self.built = False          # build_sharded ran (on every rank: the final concat is a collective)
         self.n = d.n
@@ -279,6 +280,23 @@ class Workspace:
             t = torch.empty(int(numel + numel // 16 + 64), dtype=dtype, device=self.device)
             self.buf[name] = t
         return t
+
+
+class _DevPtr:
+    """A device buffer of the library seen through __cuda_array_interface__ (torch.as_tensor wraps it without a copy)."""
+
+    def __init__(self, ptr, numel):
+        self.__cuda_array_interface__ = {"shape": (int(numel),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+def _scratch_tensor(d, which, numel, device):
+    """The context's free key buffer `which` (0 send, 1 receive; debwt_shard_scratch) as an int64 tensor of all its words,
+    or None when there is none of at least `numel` words."""
+    p, nbytes = ctypes.c_void_p(), ctypes.c_uint64()
+    _chk(d, _lib.lib().debwt_shard_scratch(d._h, which, ctypes.byref(p), ctypes.byref(nbytes)))
+    if not p.value or nbytes.value < numel * 8 or os.environ.get("DEBWT_NO_SCRATCH_ALIAS"):
+        return None
+    return torch.as_tensor(_DevPtr(p.value, nbytes.value // 8), device=device)
 
 
 def generate_text_all_gather(syn, text, device):
@@ -408,14 +426,20 @@ def build_sharded(d, ws=None, mode=None, device=None):
             raise RuntimeError(f"gathered {got_sp} SP symbols, the slices announced {sp_total}")
         _chk(d, L.debwt_shard_sp_import(d._h, ctypes.c_void_p(allsp.data_ptr()), sp_total))
 
-        # 5. blue entries of my slice -> the owners of their blocks
-        xa = ws.get("xa", b_loc.value + 64, torch.int64)
+        # 5. blue entries of my slice -> the owners of their blocks.  Send and receive buffer: the context's own key buffers
+        #    where they are free and large enough (keys read off the text; debwt_shard_scratch), else tensors of this workspace
+        xa = _scratch_tensor(d, 0, b_loc.value + 64, device) if not exchange else None
+        if xa is None:
+            xa = ws.get("xa", b_loc.value + 64, torch.int64)
         boffs = np.zeros(world + 1, dtype=np.uint64)
         _chk(d, L.debwt_shard_blue_route(d._h, first_block.ctypes.data_as(u32p), ctypes.c_void_p(xa.data_ptr()),
                                          xa.numel(), boffs.ctypes.data_as(u64p)))
         send = [int(boffs[i + 1] - boffs[i]) for i in range(world)]
         recv = [int(x) for x in _all_gather_small(send)[:, rank]]
-        xb = ws.get("xb", sum(recv) + 64, torch.int64)
+        xb = _scratch_tensor(d, 1, sum(recv) + 64, device) if not exchange else None     # (its routed entries are in xa now)
+        if xb is None:
+            xb = ws.get("xb", sum(recv) + 64, torch.int64)
+        ws.blue_bufs = (xa, xb)                  # the final concat reuses them (both are free once the entries are placed)
         t0 = time.perf_counter()
         got = _all_to_all(xb, xa, recv, send)
         sync()
@@ -457,7 +481,7 @@ def _concat_on_rank0(d, ws, dst=0):
     allr = _all_gather_small([rb, rows, nh])
     maxw = int(max((int(r) + 31) // 32 for r in allr[:, 1])) + 1               # one spare word behind every part
     # after the exchanges the key buffers are free: the shard's rows leave from xb, the parts arrive in xa
-    xa, xb = ws.buf.get("xa"), ws.buf.get("xb")
+    xa, xb = getattr(ws, "blue_bufs", None) or (ws.buf.get("xa"), ws.buf.get("xb"))
     mine = xb if xb is not None and xb.numel() >= maxw else ws.get("part", maxw, torch.int64)
     _chk(d, L.debwt_shard_export(d._h, ctypes.c_void_p(mine.data_ptr()), maxw))
     torch.cuda.synchronize(ws.device)

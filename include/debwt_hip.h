@@ -223,8 +223,8 @@ int debwt_shard_set_range(debwt_ctx *ctx, uint32_t bin_lo, uint32_t bin_hi, uint
 /* the same from the summed census hist4096 (host), cut into as many key ranges as the free HBM (or debwt_set_range_cap)
  * asks for: the reference's segCount balancing (src/mySort.c:104-110) applied twice, over GPUs and over rounds.
  * exchange: 1 = the keys of every range will arrive through debwt_shard_sort_range; 0 = the shard reads them from
- * its text (debwt_kmer_sort_rle); 2 = the same, and the caller will allocate the two buffers of the blue-entry
- * exchange after the sort (room is left for them).  caller_held_bytes: device memory the caller already holds for
+ * its text (debwt_kmer_sort_rle); 2 = the same with a sliced SP stage whose blue-entry exchange runs in the key buffers
+ * (debwt_shard_scratch).  caller_held_bytes: device memory the caller already holds for
  * the exchanges of this build (counted as available: it is reused). */
 int debwt_shard_plan(debwt_ctx *ctx, const uint64_t *hist4096, uint32_t bin_lo, uint32_t bin_hi, uint64_t m_base,
                      int exchange, uint64_t caller_held_bytes, uint32_t *nranges);
@@ -253,6 +253,16 @@ int debwt_shard_sp_import(debwt_ctx *ctx, const uint8_t *d_src, uint64_t sp_tota
 /* first_block_of_shard: world+1 host words (exclusive scan of the shards' block counts) */
 int debwt_shard_blue_route(debwt_ctx *ctx, const uint32_t *first_block_of_shard, uint64_t *d_out, uint64_t capacity,
                            uint64_t *offs);
+/* Exchange buffers without an allocation: after the sort stage of a shard whose keys were read off the text (plan mode 0
+ * or 2) its two key buffers are free until the next build.  DEBWT_SCRATCH_SEND: the buffer to route into
+ * (debwt_shard_blue_route's d_out; the peers read it during the exchange); DEBWT_SCRATCH_RECV: the buffer to receive into
+ * (debwt_shard_blue_place's d_entries) -- it holds the routed entries of the slice until debwt_shard_blue_route has run,
+ * so it may be written only after that call.  *bytes = 0: none (keys exchanged: the receive buffer is the caller's own).
+ * A host uses a scratch buffer when it is large enough and its own allocation otherwise; debwt_shard_plan mode 2 leaves
+ * no room for exchange buffers beside the key buffers. */
+#define DEBWT_SCRATCH_SEND 0
+#define DEBWT_SCRATCH_RECV 1
+int debwt_shard_scratch(debwt_ctx *ctx, int which, void **d_ptr, uint64_t *bytes);
 /* d_entries: the `count` routed entries this shard received (DEVICE); the buffer is used as scratch and holds nothing
  * meaningful afterwards */
 int debwt_shard_blue_place(debwt_ctx *ctx, uint64_t *d_entries, uint64_t count);
@@ -300,7 +310,10 @@ int debwt_multi_set_key_mode(debwt_multi *m, int key_mode);
 /* What carries the exchanges between the shards (k-mer buckets, facts, SP symbols, blue entries, final row ranges):
  * DEBWT_EXCHANGE_PEER_COPY (default): every shard pulls its segments with device-to-device copies;
  * DEBWT_EXCHANGE_RCCL: one grouped ncclSend / ncclRecv alltoallv per exchange, one communicator per GPU of this process
- * (ncclCommInitAll; RCCL is loaded on demand -- DEBWT_EDEVICE where it is missing -- and needs one distinct GPU per shard). */
+ * (ncclCommInitAll; RCCL is loaded on demand -- DEBWT_EDEVICE where it is missing -- and needs one distinct GPU per shard).
+ * The configured backend stays until this call changes it: when an RCCL exchange fails inside a build, every communicator
+ * is aborted (the build returns the error), and the NEXT debwt_multi_build makes new communicators first -- or returns
+ * DEBWT_EDEVICE with the reason in debwt_multi_last_error; it never falls back to peer copies by itself. */
 #define DEBWT_EXCHANGE_PEER_COPY 0
 #define DEBWT_EXCHANGE_RCCL 1
 int debwt_multi_set_exchange(debwt_multi *m, int backend);

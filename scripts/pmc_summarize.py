@@ -5,8 +5,10 @@
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: counter values are KiB;
 on gfx950 FETCH_SIZE reports half of a wide coalesced streaming read, so reads are doubled -- and the factor is
 re-derived inside the same run from rs_hist_kernel<0,0>, which reads exactly 8 B x KEYS; WRITE_SIZE is taken as is."""
-import csv, json, re, sys
+import csv, hashlib, json, os, re, sys
 from collections import defaultdict
+
+KERNEL_SOURCE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "debwt_amd", "csrc", "radix_sort.hip")
 
 
 def per_kernel(path, counter):
@@ -41,6 +43,8 @@ def main():
                        "write_GB_per_large_launch": round(w.get("mean_of_large_KiB", 0) * 1024 / 1e9, 4)}
     res = {
         "workload": workload,
+        # bench.py reports `roofline.traffic` from this file only while the kernel's source is the one measured here
+        "kernel_source": {"file": "debwt_amd/csrc/radix_sort.hip", "sha256": hashlib.sha256(open(KERNEL_SOURCE, "rb").read()).hexdigest()},
         "per_kernel_GB": table,
         "calibration": {"kernel": hist + " reads exactly 8 B x %d keys" % keys, "known_KiB": known_kib,
                         "FETCH_SIZE_KiB": F[hist]["mean_of_large_KiB"], "factor": factor},
