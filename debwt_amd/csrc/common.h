@@ -68,6 +68,19 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Positions of a text word whose K-symbol window holds a separator.  sb: bit j = a separator at the word's first position
+// + j (64 positions); returns bit t (t < 32) set when one of the positions t .. t + K - 1 is a separator: every set bit is
+// smeared down over the K - 1 positions before it in five or six shift-or steps.  (The 32-iteration form `(sb >> t) & kmask`
+// this replaces was if-converted by the compiler in every kernel that holds it -- ~190 64-bit operations per text word,
+// executed whether or not a separator was near: profiles/r06_experiments.txt.)  Callers test `sb` with a wave-uniform branch.
+__device__ __forceinline__ u32 sep_blocked(u64 sb, int K) {
+    u64 x = sb;
+    int r = K - 1;
+    for (int s = 1; r > 0; s <<= 1) { const int take = s < r ? s : r; x |= x >> take; r -= take; }
+    return (u32)x;
+}
+__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }     // uniform: a scalar branch, never if-converted
+
 // ---- wave / block scans ----------------------------------------------------------------------------
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }

@@ -496,7 +496,10 @@ int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, s
                 size_t len = 0;
                 int br = inflate_bgzf((const unsigned char *)zm, (size_t)st.st_size, threads, &buf, &len);
                 if (br == 1 && !getenv("DEBWT_GZ_SERIAL")) {
-                    br = inflate_gzip_parallel((const unsigned char *)zm, (size_t)st.st_size, threads, &buf, &len) == 0 ? 0 : 1;
+                    // several plain members (their headers are found first: a file of one member is told apart at once), else
+                    // the one member in pieces
+                    br = inflate_gzip_members((const unsigned char *)zm, (size_t)st.st_size, threads, &buf, &len);
+                    if (br == 1) br = inflate_gzip_parallel((const unsigned char *)zm, (size_t)st.st_size, threads, &buf, &len) == 0 ? 0 : 1;
                     if (br == 1 && getenv("DEBWT_GZ_REQUIRE_PARALLEL")) {            // tests: no silent serial fall-back
                         munmap(zm, (size_t)st.st_size); close(fd);
                         return fail(err, errlen, "the parallel gzip path declined the file");

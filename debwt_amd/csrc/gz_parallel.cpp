@@ -39,6 +39,30 @@ typedef uint16_t sym_t;                       // < 256: a byte; >= MARK: byte (v
 constexpr sym_t MARK = 0x8000;
 constexpr size_t WIN = 32768;
 
+// the symbols of a piece's head: a plain growing array that is NOT cleared when it grows (std::vector::resize zero-filled
+// the slack behind every deflate block: O(n) per block)
+struct SymVec {
+    sym_t *p = nullptr; size_t n = 0, cap = 0;
+    SymVec() = default;
+    SymVec(const SymVec &) = delete;
+    SymVec &operator=(const SymVec &) = delete;
+    SymVec(SymVec &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    ~SymVec() { free(p); }
+    size_t size() const { return n; }
+    sym_t &operator[](size_t i) { return p[i]; }
+    const sym_t &operator[](size_t i) const { return p[i]; }
+    void clear() { n = 0; }
+    void release() { free(p); p = nullptr; n = cap = 0; }
+    bool reserve(size_t want) {                // false: out of memory (the old array stays)
+        if (want <= cap) return true;
+        sym_t *q = (sym_t *)realloc(p, want * sizeof(sym_t));
+        if (!q) return false;
+        p = q; cap = want;
+        return true;
+    }
+    bool push_back(sym_t v) { if (n == cap && !reserve(cap + cap / 2 + ((size_t)1 << 16))) return false; p[n++] = v; return true; }
+};
+
 struct Bits {                                 // LSB-first bit reader over the whole file; pos = absolute bit offset.  The
     const unsigned char *z; size_t nbits, pos; // deflate data is followed by the 8-byte gzip trailer, so the 8-byte loads
     bool over = false;                         // below never leave the file
@@ -136,7 +160,7 @@ const Fixed FIXED;
 // strict: literals must be text (the block-start search).  Returns 0 ok (b.pos behind the block, *last = BFINAL), -1 not
 // a valid block / out of input, -2 out of memory.  max_out bounds the growth of `out` (search: a wrong start must not
 // decode for ever).
-int block(Bits &b, std::vector<sym_t> &out, bool strict, int *last, size_t max_out) {
+int block(Bits &b, SymVec &out, bool strict, int *last, size_t max_out) {
     *last = (int)b.get(1);
     const unsigned type = b.get(2);
     if (b.over || type == 3) return -1;
@@ -149,7 +173,7 @@ int block(Bits &b, std::vector<sym_t> &out, bool strict, int *last, size_t max_o
         const unsigned char *p = b.z + (b.pos >> 3);
         for (unsigned i = 0; i < len; i++) {
             if (strict && !is_text(p[i])) return -1;
-            out.push_back(p[i]);
+            if (!out.push_back(p[i])) return -2;
         }
         b.pos += 8 * (size_t)len;
         return 0;
@@ -189,16 +213,15 @@ int block(Bits &b, std::vector<sym_t> &out, bool strict, int *last, size_t max_o
         L = &lit; D = &dist;
     }
     size_t n = out.size();
-    if (out.capacity() < n + 65536 + 258) out.reserve(n + n / 2 + ((size_t)1 << 20));
-    out.resize(out.capacity());                               // written through a pointer; cut back to n on every way out
-    sym_t *v = out.data();
-    size_t cap = out.size();
+    if (out.cap < n + 65536 + 258 && !out.reserve(n + n / 2 + ((size_t)1 << 20))) return -2;
+    sym_t *v = out.p;                                         // written through a pointer; out.n is set on every way out
+    size_t cap = out.cap;
     int rc = -1;
     for (;;) {
         if (n + 258 > cap) {
             if (n + 258 > max_out) break;
-            out.resize(n); out.reserve(n + n / 2 + ((size_t)1 << 20)); out.resize(out.capacity());
-            v = out.data(); cap = out.size();
+            if (!out.reserve(n + n / 2 + ((size_t)1 << 20))) { rc = -2; break; }
+            v = out.p; cap = out.cap;
         }
         const int s = decode(b, *L);
         if (s < 0) break;
@@ -227,7 +250,7 @@ int block(Bits &b, std::vector<sym_t> &out, bool strict, int *last, size_t max_o
             n += len;
         }
     }
-    out.resize(n);
+    out.n = n;
     return rc;
 }
 
@@ -237,7 +260,7 @@ int block(Bits &b, std::vector<sym_t> &out, bool strict, int *last, size_t max_o
 // a valid run of fixed-code symbols and a stored block proves itself with 16 bits; gzip writes dynamic blocks for text of
 // any size worth cutting into pieces.
 size_t find_block(const unsigned char *z, size_t nbits, size_t from, size_t to) {
-    std::vector<sym_t> tmp, t2;
+    SymVec tmp, t2;
     for (size_t p = from; p < to; p++) {
         const unsigned hdr = (z[p >> 3] >> (p & 7)) | ((p >> 3) + 1 < (nbits + 7) >> 3 ? (unsigned)z[(p >> 3) + 1] << (8 - (p & 7)) : 0u);
         if ((hdr & 7u) != 4u) continue;                       // BFINAL = 0, BTYPE = 2 (bits LSB first: 0, then 0 1)
@@ -256,7 +279,7 @@ size_t find_block(const unsigned char *z, size_t nbits, size_t from, size_t to) 
 
 struct Piece {
     size_t start_bit = 0, end_bit = 0;       // decoded from / up to (the next piece's start_bit, or the end of the final block)
-    std::vector<sym_t> head;                  // symbols decoded with the unknown window (may hold markers)
+    SymVec head;                              // symbols decoded with the unknown window (may hold markers)
     char *body = nullptr; size_t body_len = 0, body_cap = 0;   // what zlib decoded behind them (final bytes)
     std::vector<char> head_bytes;             // head, resolved
     bool final_block = false;
@@ -321,7 +344,7 @@ void decode_piece(const unsigned char *z, size_t zlen, size_t stop_bit, bool fir
         // (a text whose copies keep reaching back -- tandem repeats -- never sheds its markers: beyond 2^26 symbols of head
         // the file is left to the serial path rather than decoded at this decoder's pace)
         const int r = block(b, p.head, false, &last, (size_t)1 << 26);
-        if (r != 0) { p.status = 1; return; }
+        if (r != 0) { p.status = r == -2 ? -1 : 1; return; }
         (void)before;
         clean = 0;                                            // marker-free symbols at the end, as far as it matters
         for (size_t i = p.head.size(); i > 0 && clean < WIN && p.head[i - 1] < MARK; i--) clean++;
@@ -351,8 +374,12 @@ int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char
     const size_t nbits = 8 * (zlen - 8);                      // the trailer is not deflate data
     // pieces: the compressed bytes cut evenly (DEBWT_GZ_PIECE_BYTES for tests), at least 1 MB each, two per thread (every piece
     // but the first pays for a head of 0.5 - 3 MB at our own decoder's pace, whatever its size)
+    // ... and at most 16 MB: more pieces than threads are dealt out as the threads get free, a piece whose markers never clear
+    // (gzip -1: copies keep reaching back) stays below the 2^26 symbols a head may grow to, and no thread holds more than one
+    // piece's head at our decoder's pace however large the file is
     size_t piece_bytes = (zlen / ((size_t)threads * 2)) + 1;
     if (piece_bytes < ((size_t)1 << 20)) piece_bytes = (size_t)1 << 20;
+    if (piece_bytes > ((size_t)16 << 20)) piece_bytes = (size_t)16 << 20;
     if (const char *e = getenv("DEBWT_GZ_PIECE_BYTES")) { const long long v = atoll(e); if (v >= 4096) piece_bytes = (size_t)v; }
     const size_t npieces_max = (zlen - q + piece_bytes - 1) / piece_bytes;
     if (npieces_max < 2) return 1;
@@ -404,7 +431,7 @@ int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char
         if (!lastp && p.end_bit != pc[i + 1].start_bit) { st = 1; break; }
     }
     if (!st && ((pc.back().end_bit + 7) >> 3) != zlen - 8) { GZ_TRACE("bytes behind the final block\n"); st = 1; }   // another member
-    if (st) { cleanup(); return st; }
+    if (st) { GZ_TRACE("declined after %.3f s of decoding (status %d)\n", since(), st); cleanup(); return st; }
     // 3. markers resolved piece by piece with the 32 KB before them; total length
     std::vector<size_t> off(pc.size() + 1, 0);
     for (size_t i = 0; i < pc.size(); i++) off[i + 1] = off[i] + pc[i].head.size() + pc[i].body_len;
@@ -457,7 +484,7 @@ int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char
                     else if ((size_t)(s - MARK) >= wbase) dst[j] = win[(size_t)(s - MARK) - wbase];
                     else { bad = 1; break; }
                 }
-                std::vector<sym_t>().swap(p.head);
+                p.head.release();
                 if (p.body_len) memcpy(dst + (off[i + 1] - off[i] - p.body_len), p.body, p.body_len);
                 free(p.body); p.body = nullptr;
                 uLong c = crc32(0L, Z_NULL, 0);
@@ -483,3 +510,170 @@ int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char
     *out_buf = buf; *out_len = total;
     return 0;
 }
+
+// ---- several plain members ---------------------------------------------------------------------------------------------
+// `cat a.fa.gz b.fa.gz`, one member per chromosome or per genome: members are independent deflate streams, but nothing says
+// where the next one starts except the end of the one before.  Member HEADERS are found by their fixed bytes (ID1 ID2 CM = 1f
+// 8b 08, reserved flag bits zero, XFL 0 / 2 / 4, a known OS byte -- ~10^-11 false positives per byte), every candidate is
+// inflated on its own -- many members: by as many threads, each with zlib; few and large ones: one after the other, each cut
+// into pieces by inflate_gzip_parallel -- and checked against the CRC32 and ISIZE that follow its final block; then the
+// chain is walked from byte 0: every member must start exactly where the one before ended and the last must end the file.
+// A candidate that does not inflate to a checked member (a false positive) is on no chain.  Returns 1 (inflate serially) for
+// one member, a broken chain or bytes behind the last member; -1 out of memory.
+namespace {
+
+// data offset of the member whose header starts at p, or 0
+size_t member_data(const unsigned char *z, size_t zlen, size_t p) {
+    if (p + 18 > zlen || z[p] != 0x1f || z[p + 1] != 0x8b || z[p + 2] != 8 || (z[p + 3] & 0xE0)) return 0;
+    const unsigned flg = z[p + 3], xfl = z[p + 8], os = z[p + 9];
+    if ((xfl != 0 && xfl != 2 && xfl != 4) || (os > 13 && os != 255)) return 0;
+    size_t q = p + 10;
+    if (flg & 4) { if (q + 2 > zlen) return 0; q += 2 + (z[q] | ((size_t)z[q + 1] << 8)); }
+    if (flg & 8) { while (q < zlen && z[q]) q++; q++; }
+    if (flg & 16) { while (q < zlen && z[q]) q++; q++; }
+    if (flg & 2) q += 2;
+    return q + 8 <= zlen ? q : 0;
+}
+
+struct Member { size_t start = 0, end = 0; char *out = nullptr; size_t len = 0; int status = 1; };   // status 0: inflated and checked
+
+// one member with zlib from its header at m.start; `hint`: compressed bytes up to the next candidate (sizes the first buffer)
+void inflate_member(const unsigned char *z, size_t zlen, size_t hint, Member &m) {
+    const size_t q = member_data(z, zlen, m.start);
+    if (!q) return;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { m.status = -1; return; }
+    size_t cap = std::max<size_t>(hint * 4, (size_t)1 << 20), in_done = q;
+    char *out = (char *)malloc(cap);
+    uLong crc = crc32(0L, Z_NULL, 0);
+    size_t len = 0;
+    int st = out ? 1 : -1;
+    while (out) {
+        if (cap - len < ((size_t)1 << 16)) {
+            char *nb = (char *)realloc(out, cap * 2);
+            if (!nb) { st = -1; break; }
+            out = nb; cap *= 2;
+        }
+        const size_t chunk_in = std::min(zlen - in_done, (size_t)1 << 30), room = std::min(cap - len, (size_t)1 << 30);
+        zs.next_in = const_cast<Bytef *>(z + in_done); zs.avail_in = (uInt)chunk_in;
+        zs.next_out = (Bytef *)out + len; zs.avail_out = (uInt)room;
+        const int r = inflate(&zs, Z_NO_FLUSH);
+        const size_t got = room - zs.avail_out;
+        crc = crc32(crc, (const Bytef *)out + len, (uInt)got);
+        in_done += chunk_in - zs.avail_in;
+        len += got;
+        if (r == Z_STREAM_END) {
+            if (in_done + 8 > zlen) break;
+            const unsigned char *t = z + in_done;
+            const uLong want_crc = t[0] | ((uLong)t[1] << 8) | ((uLong)t[2] << 16) | ((uLong)t[3] << 24);
+            const size_t want_len = t[4] | ((size_t)t[5] << 8) | ((size_t)t[6] << 16) | ((size_t)t[7] << 24);
+            if (want_crc == crc && want_len == (len & 0xFFFFFFFFull)) { st = 0; m.end = in_done + 8; }
+            break;
+        }
+        if (r != Z_OK && r != Z_BUF_ERROR) break;              // not a deflate stream: a false candidate (or a damaged file)
+        if (r == Z_BUF_ERROR && got == 0 && chunk_in == zs.avail_in) break;   // no progress: the input ends inside the stream
+    }
+    inflateEnd(&zs);
+    if (st == 0) { m.out = out; m.len = len; } else free(out);
+    m.status = st;
+}
+
+}  // namespace
+
+int inflate_gzip_members(const unsigned char *z, size_t zlen, int threads, char **out_buf, size_t *out_len) {
+    const bool trace = getenv("DEBWT_TRACE_GZ") != nullptr;
+    if (threads < 1) threads = 1;
+    if (!member_data(z, zlen, 0)) return 1;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    // 1. candidate headers, by slices of the file
+    std::vector<std::vector<size_t>> found((size_t)threads);
+    {
+        auto work = [&](int t) {
+            const size_t a = zlen / (size_t)threads * (size_t)t, b = t + 1 == threads ? zlen : zlen / (size_t)threads * (size_t)(t + 1);
+            for (size_t p = a; p < b;) {
+                const void *hit = memchr(z + p, 0x1f, b - p);
+                if (!hit) break;
+                p = (size_t)((const unsigned char *)hit - z);
+                if (member_data(z, zlen, p)) found[(size_t)t].push_back(p);
+                p++;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    std::vector<size_t> cand;
+    for (auto &f : found) cand.insert(cand.end(), f.begin(), f.end());
+    GZ_TRACE("%zu candidate member headers after %.3f s\n", cand.size(), since());
+    if (cand.size() < 2) return 1;                            // one member: inflate_gzip_parallel's case
+    std::vector<Member> chain;
+    auto cleanup = [&](std::vector<Member> &v) { for (Member &m : v) { free(m.out); m.out = nullptr; } };
+    if (cand.size() * 2 > (size_t)threads) {
+        // many members: every candidate on its own, by all threads (a false candidate fails within its first block)
+        std::vector<Member> mem(cand.size());
+        for (size_t i = 0; i < cand.size(); i++) mem[i].start = cand[i];
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t i; (i = next.fetch_add(1)) < mem.size();)
+                inflate_member(z, zlen, (i + 1 < cand.size() ? cand[i + 1] : zlen) - cand[i], mem[i]);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; t++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+        GZ_TRACE("candidates inflated after %.3f s\n", since());
+        size_t cur = 0, i = 0;
+        bool ok = true, oom = false;
+        for (const Member &m : mem) oom = oom || m.status < 0;
+        while (ok && !oom && cur < zlen) {
+            while (i < mem.size() && mem[i].start < cur) i++;
+            if (i == mem.size() || mem[i].start != cur || mem[i].status != 0) { ok = false; break; }
+            chain.push_back(mem[i]); mem[i].out = nullptr;     // (the buffer moves to the chain)
+            cur = chain.back().end;
+        }
+        cleanup(mem);
+        if (oom) { cleanup(chain); return -1; }
+        if (!ok) { GZ_TRACE("the members do not chain from byte %zu on: left to the serial path\n", cur); cleanup(chain); return 1; }
+    } else {
+        // few members, so large ones: one after the other, each by all threads
+        size_t cur = 0, i = 0;
+        while (cur < zlen) {
+            while (i < cand.size() && cand[i] <= cur) i++;
+            const size_t nxt = i < cand.size() ? cand[i] : zlen;
+            Member m;
+            m.start = cur;
+            if (inflate_gzip_parallel(z + cur, nxt - cur, threads, &m.out, &m.len) == 0) { m.end = nxt; m.status = 0; }
+            else inflate_member(z, zlen, nxt - cur, m);         // small, not text, or a false candidate cut it short: zlib finds its end
+            if (m.status < 0) { cleanup(chain); return -1; }
+            if (m.status) { GZ_TRACE("no member at byte %zu: left to the serial path\n", cur); cleanup(chain); return 1; }
+            chain.push_back(m);
+            cur = m.end;
+        }
+        GZ_TRACE("%zu members inflated one after the other after %.3f s\n", chain.size(), since());
+    }
+    // 2. one buffer
+    std::vector<size_t> off(chain.size() + 1, 0);
+    for (size_t j = 0; j < chain.size(); j++) off[j + 1] = off[j] + chain[j].len;
+    char *buf = (char *)malloc(off.back() + 1);
+    if (!buf) { cleanup(chain); return -1; }
+    {
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t j; (j = next.fetch_add(1)) < chain.size();) {
+                if (chain[j].len) memcpy(buf + off[j], chain[j].out, chain[j].len);
+                free(chain[j].out); chain[j].out = nullptr;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads && (size_t)t < chain.size(); t++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    GZ_TRACE("%zu members, %zu bytes after %.3f s\n", chain.size(), off.back(), since());
+    *out_buf = buf; *out_len = off.back();
+    return 0;
+}
+

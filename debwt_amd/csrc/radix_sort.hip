@@ -235,7 +235,6 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_ranges_words_kernel(TextKeyS
     __syncthreads();
     const u64 beg = (u64)blockIdx.x * chunk;
     const u64 end = beg + chunk < ts.n ? beg + chunk : ts.n;
-    const u64 kmask = (1ull << K) - 1ull;
     for (u64 idx0 = beg + ((u64)threadIdx.x << 5); idx0 < end; idx0 += (u64)RS_BLOCK << 5) {
         const u64 p = ts.pos0 + idx0, g = p >> 5;
         const u64 w0 = ts.text[g], w1 = ts.text[g + 1];
@@ -243,11 +242,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_ranges_words_kernel(TextKeyS
         const u64 sb = (p & 32ull) ? (sa >> 32) | (sbw << 32) : sa;        // bit t: separator at the word's position + t
         const u32 lim = end - idx0 < 32 ? (u32)(end - idx0) : 32u;
         u32 ok = lim < 32 ? (1u << lim) - 1u : 0xFFFFFFFFu;
-        if (sb) {                                              // a separator within 64 positions: rare, tested apart
-#pragma unroll
-            for (u32 t = 0; t < 32; t++)
-                if ((sb >> t) & kmask) ok &= ~(1u << t);
-        }
+        if (wave_any(sb != 0ull)) ok &= ~sep_blocked(sb, K);   // a separator within 64 positions: rare, a uniform branch
 #pragma unroll
         for (u32 t = 0; t < 32; t++) {
             const u32 top = t ? (u32)(((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) >> 32) : (u32)(w0 >> 32);
@@ -655,7 +650,6 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
     const u64 beg = (u64)blockIdx.x * chunk;                  // a multiple of RS_TILE: word-aligned
     const u64 end = beg + chunk < n ? beg + chunk : n;
     const int K = ts.K, nsh = 64 - 2 * K, kb = 2 * K + 2;
-    const u64 kmask = (1ull << K) - 1ull;
     const u32 lo12 = (u32)(ts.key_lo >> (kb - 12)), hi12 = ts.key_hi ? (u32)(ts.key_hi >> (kb - 12)) : 4096u;
     const u32 span12 = hi12 - lo12;
     lds_barrier();
@@ -705,11 +699,7 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
                 m &= m2;
             }
 #endif
-            if (sb) {                                          // a separator within 64 positions: rare, tested apart
-#pragma unroll
-                for (u32 t = 0; t < 32; t++)
-                    if ((sb >> t) & kmask) m &= ~(1u << t);
-            }
+            if (wave_any(sb != 0ull)) m &= ~sep_blocked(sb, K); // a separator within 64 positions: rare, a uniform branch
             if (lim < 32) m &= (1u << lim) - 1u;
         }
         for (;;) {
@@ -779,7 +769,6 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
 // have to keep), and the chunk histograms it is handed count keys per chunk, whatever wave finds them.  The prefix tests
 // work on 32-bit windows (v_alignbit): a window lies in the range when (x - lo << 20) < (span << 20), and the borrow of
 // that comparison is shifted into the mask by an add-with-carry.
-typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
 template <int HI, int K31>
 __global__ __launch_bounds__(SC_NT) __attribute__((amdgpu_waves_per_eu(RS_WAVES_EU, RS_WAVES_EU)))
 void rs_scatter_sparse_waves_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 chunk, RsDigit dg,
@@ -797,11 +786,10 @@ void rs_scatter_sparse_waves_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n,
     const u64 beg = (u64)blockIdx.x * chunk;                  // a multiple of RS_TILE: word-aligned
     const u64 end = beg + chunk < n ? beg + chunk : n;
     const int K = ts.K, nsh = 64 - 2 * K, kb = 2 * K + 2;
-    const u64 kmask = (1ull << K) - 1ull;
     const u32 lo12 = (u32)(ts.key_lo >> (kb - 12)), hi12 = ts.key_hi ? (u32)(ts.key_hi >> (kb - 12)) : 4096u;
     // a proper key range: span < 4096 bins, so both bounds fit the 16-bit windows the tests work on
     const u32 lo16 = lo12 << 4, span16 = (hi12 - lo12) << 4;
-    const rs_u16x2 lo16v = {(unsigned short)lo16, (unsigned short)lo16}, span16v = {(unsigned short)span16, (unsigned short)span16};
+    const u32 lo16p = lo16 | (lo16 << 16), span16p = span16 | (span16 << 16), one16p = 0x00010001u;    // packed pairs
     lds_barrier();
     const u64 nwords = beg < end ? (end - beg + 31) >> 5 : 0;
     const u64 per = ((nwords + SC_WAVES - 1) / SC_WAVES + 63) & ~63ull;
@@ -848,24 +836,26 @@ void rs_scatter_sparse_waves_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n,
                     for (int t = 7; t >= 0; t--) {
                         const u32 x0 = t == 0 ? a0 : __builtin_amdgcn_alignbit(a0, a1, 32 - 2 * t);
                         const u32 x1 = t == 0 ? a1 : __builtin_amdgcn_alignbit(a1, a2, 32 - 2 * t);
-                        const rs_u16x2 one = {1, 1};
-                        const rs_u16x2 y0 = __builtin_bit_cast(rs_u16x2, x0) - lo16v, y1 = __builtin_bit_cast(rs_u16x2, x1) - lo16v;
-                        const rs_u16x2 z0 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(span16v, y0), one);
-                        const rs_u16x2 z1 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(span16v, y1), one);
-                        acc0 = (acc0 << 1) | __builtin_bit_cast(u32, z0);
-                        acc1 = (acc1 << 1) | __builtin_bit_cast(u32, z1);
+                        // (inline assembly: the compiler turns the generic vector form into two 16-bit compares and two selects)
+                        u32 y0, y1, z0, z1;
+                        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(y0) : "v"(x0), "v"(lo16p));
+                        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(y1) : "v"(x1), "v"(lo16p));
+                        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(z0) : "v"(span16p), "v"(y0));     // span - y, saturating: non-zero iff y < span
+                        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(z1) : "v"(span16p), "v"(y1));
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(z0) : "v"(z0), "v"(one16p));
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(z1) : "v"(z1), "v"(one16p));
+                        acc0 = (acc0 << 1) | z0;
+                        acc1 = (acc1 << 1) | z1;
                     }
                     // acc: bits 16..23 = positions 0..7 of its half-word, bits 0..7 = positions 8..15
                     m = ((acc0 >> 16) & 0xFFu) | ((acc0 & 0xFFu) << 8) | (((acc1 >> 16) & 0xFFu) << 16) | ((acc1 & 0xFFu) << 24);
-                    const u32 shp = (u32)((ts.pos0 + idx0) & 63ull);  // 0 or 32
-                    const u64 sb = shp ? (sa >> 32) | (sbw << 32) : sa;
-                    if (sb) {                                         // a separator within 64 positions: rare, tested apart
-#pragma unroll
-                        for (u32 t = 0; t < 32; t++)
-                            if ((sb >> t) & kmask) m &= ~(1u << t);
-                    }
                     const u32 lim = end - idx0 < 32 ? (u32)(end - idx0) : 32u;
                     if (lim < 32) m &= (1u << lim) - 1u;
+                }
+                {   // a separator within 64 positions: rare, behind a wave-uniform branch
+                    const u32 shp = (u32)((ts.pos0 + idx0) & 63ull);  // 0 or 32
+                    const u64 sb = mine ? (shp ? (sa >> 32) | (sbw << 32) : sa) : 0ull;
+                    if (wave_any(sb != 0ull)) m &= ~sep_blocked(sb, K);
                 }
             }
             const u32 cnt = (u32)__popc(m);

@@ -165,16 +165,17 @@ __global__ __launch_bounds__(DEBWT_BLOCK) void k_prefix_hist_words(const u64 *__
     __shared__ u32 h[SHARD_BINS];
     for (u32 b = threadIdx.x; b < SHARD_BINS; b += DEBWT_BLOCK) h[b] = 0;
     __syncthreads();
-    const u64 kmask = (1ull << K) - 1ull;
     const u64 g1 = (p1 + 31) >> 5;
     for (u64 g = (p0 >> 5) + (u64)blockIdx.x * DEBWT_BLOCK + threadIdx.x; g < g1; g += (u64)gridDim.x * DEBWT_BLOCK) {
         const u64 w0 = text[g], w1 = text[g + 1], i0 = g << 5;
         const u64 sb = sep_window(sepbits, i0);
         const u32 lim = p1 - i0 < 32 ? (u32)(p1 - i0) : 32u;
+        u32 ok = lim < 32 ? (1u << lim) - 1u : 0xFFFFFFFFu;
+        if (wave_any(sb != 0ull)) ok &= ~sep_blocked(sb, K);
 #pragma unroll
         for (u32 t = 0; t < 32; t++) {
             const u32 pre = t <= 26 ? (u32)(w0 >> (52 - 2 * t)) & 0xFFFu : (u32)(((w0 << (2 * t)) | (w1 >> (64 - 2 * t))) >> 52);
-            if (t < lim && ((sb >> t) & kmask) == 0ull) atomicAdd(&h[pre], 1u);
+            if ((ok >> t) & 1u) atomicAdd(&h[pre], 1u);
         }
     }
     __syncthreads();
@@ -727,7 +728,6 @@ __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_
     if (active) {
     const u64 w0 = text[g], w1 = text[g + 1];
     const u64 sb = sep_window(sepbits, g << 5);
-    const u64 kmask = (1ull << K) - 1ull;
     const u64 i0 = g << 5;
     u32 lim = (n - i0) < 32 ? (u32)(n - i0) : 32u;
     const u32 inrange = lim == 32 ? 0xFFFFFFFFu : ((1u << lim) - 1u);
@@ -776,10 +776,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_
         cand |= bit << t;
     }
     }
-    if (sb) {                                                    // a separator within 64 positions: rare, tested apart
-#pragma unroll
-        for (u32 t = 0; t < 32; t++) spec |= (((sb >> t) & kmask) ? 1u : 0u) << t;
-    }
+    if (wave_any(sb != 0ull)) spec = sep_blocked(sb, K);         // a separator within 64 positions: rare, a uniform branch
     cand &= inrange & ~spec;
     spec &= inrange;
     // phase 2: only the candidates pay for the table search

@@ -33,10 +33,20 @@ with open(f"{d}/x.bgzf.fa.gz", "wb") as f:
         co = zlib.compressobj(1, zlib.DEFLATED, -15); body = co.compress(chunk) + co.flush()
         f.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1))
         f.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+# several plain members: one per record (24 chromosome-like members) and the text cut into 3 (few, large members)
+starts = [i for i in range(len(data)) if data[i:i + 1] == b">"] if len(data) < (1 << 20) else None
+import re
+starts = [m.start() for m in re.finditer(b">", data)] + [len(data)]
+with open(f"{d}/x.members24.fa.gz", "wb") as f:
+    for a, b_ in zip(starts[:-1], starts[1:]): f.write(gzip.compress(data[a:b_], compresslevel=6, mtime=0))
+third = [0, starts[len(starts) // 3], starts[2 * len(starts) // 3], len(data)]
+with open(f"{d}/x.members3.fa.gz", "wb") as f:
+    for a, b_ in zip(third[:-1], third[1:]): f.write(gzip.compress(data[a:b_], compresslevel=6, mtime=0))
 print(f"{mbp} Mbp FASTA: {len(data) / 1e9:.2f} GB; gzip -1 and -6 written in {t1 - t0:.0f} s, BGZF in {time.time() - t1:.0f} s; {threads} host threads", flush=True)
 ref = None
 for name, env in (("x.fa", {}), ("x.gzip1.fa.gz", {"DEBWT_GZ_SERIAL": "1"}), ("x.gzip1.fa.gz", {}), ("x.gzip6.fa.gz", {"DEBWT_GZ_SERIAL": "1"}),
-                  ("x.gzip6.fa.gz", {}), ("x.bgzf.fa.gz", {})):
+                  ("x.gzip6.fa.gz", {}), ("x.bgzf.fa.gz", {}), ("x.members24.fa.gz", {"DEBWT_GZ_SERIAL": "1"}), ("x.members24.fa.gz", {}),
+                  ("x.members3.fa.gz", {})):
     best = None
     os.environ.pop("DEBWT_GZ_SERIAL", None)
     os.environ.update(env)

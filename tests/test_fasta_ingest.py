@@ -358,9 +358,9 @@ def test_pack_one_member_gzip_default_pieces(tmp_path, monkeypatch):
 
 
 def test_pack_gzip_shapes_the_parallel_path_declines(tmp_path, monkeypatch):
-    """What the parallel path does not take is inflated serially as before, with the same result: several plain members
-    (the final block comes in the middle), stored blocks only (gzip -0: no dynamic block to start from), a file too small to
-    cut; a FASTQ .gz of one member IS taken; a stream damaged in the middle is an error, not a wrong text."""
+    """What the parallel paths do not take is inflated serially as before, with the same result: stored blocks only (gzip -0:
+    no dynamic block to start from), a file too small to cut (several plain members are taken since round 6:
+    test_pack_several_plain_gzip_members_in_parallel); a FASTQ .gz of one member IS taken; a stream damaged in the middle is an error, not a wrong text."""
     rng = np.random.default_rng(31)
     recs = [rng.integers(0, 4, size=int(rng.integers(100_000, 400_000))).astype(np.uint8) for _ in range(6)]
     plain = str(tmp_path / "m.fa")
@@ -368,7 +368,7 @@ def test_pack_gzip_shapes_the_parallel_path_declines(tmp_path, monkeypatch):
     data = open(plain, "rb").read()
     monkeypatch.setenv("DEBWT_GZ_PIECE_BYTES", "65536")
     cut = data.index(b">", len(data) // 2)
-    shapes = {"two_members": _gz_members([data[:cut], data[cut:]]), "stored": gzip.compress(data, compresslevel=0, mtime=0),
+    shapes = {"stored": gzip.compress(data, compresslevel=0, mtime=0),
               "tiny": gzip.compress(data[:data.index(b"\n>", 1) + 1], mtime=0)}
     for name, blob in shapes.items():
         p = str(tmp_path / (name + ".fa.gz"))
@@ -399,3 +399,44 @@ def test_pack_gzip_shapes_the_parallel_path_declines(tmp_path, monkeypatch):
     open(bad, "wb").write(gzip.compress(data, mtime=0)[:-40000])
     with pytest.raises(api.DebwtError):
         api.pack_fasta(bad, 4)
+
+
+@pytest.mark.parametrize("members,threads", [(2, 8), (3, 2), (7, 3), (40, 4)])
+def test_pack_several_plain_gzip_members_in_parallel(tmp_path, monkeypatch, members, threads):
+    """`cat a.fa.gz b.fa.gz ...` (one member per chromosome or genome; the reference reads it through gzread,
+    src/collect#$.c:26,34-90): the member headers are found by their fixed bytes, every member is inflated on its own -- many
+    members by as many threads, few large ones one after the other in pieces -- checked against its CRC32 and ISIZE, and the
+    members must chain from byte 0 to the end.  Same packed text as from the plain file, no serial fall-back
+    (DEBWT_GZ_REQUIRE_PARALLEL).  One member holds the bytes of a gzip header in its data (a false candidate): it is on no
+    chain.  Bytes behind the last member: left to the serial path, which reads what gzread reads."""
+    rng = np.random.default_rng(500 + members)
+    recs = [rng.integers(0, 4, size=int(rng.integers(60_000, 300_000))).astype(np.uint8) for _ in range(max(members, 6))]
+    plain = str(tmp_path / "m.fa")
+    _write(plain, recs, width=70)
+    data = open(plain, "rb").read()
+    starts = [0] + sorted({data.index(b">", len(data) * i // members) for i in range(1, members)}) + [len(data)]
+    parts = [data[a:b] for a, b in zip(starts[:-1], starts[1:]) if b > a]
+    blob = _gz_members(parts, level=6)
+    p = str(tmp_path / "members.fa.gz")
+    open(p, "wb").write(blob)
+    assert gzip.open(p, "rb").read() == data
+    monkeypatch.setenv("DEBWT_GZ_REQUIRE_PARALLEL", "1")
+    monkeypatch.setenv("DEBWT_GZ_PIECE_BYTES", "65536")
+    _check(p, recs, threads)
+    # a false candidate: a comment line that holds the fixed bytes of a member header, in a member of stored blocks
+    fake = b">x " + bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 3]) + b" header bytes in a name\n" + b"ACGT" * 20 + b"\n"
+    blob2 = gzip.compress(parts[0], mtime=0) + gzip.compress(fake, compresslevel=0, mtime=0) + _gz_members(parts[1:])
+    p2 = str(tmp_path / "fake.fa.gz")
+    open(p2, "wb").write(blob2)
+    w, n, sep, _, _ = api.pack_fasta(p2, threads)
+    plain2 = str(tmp_path / "fake.fa")
+    open(plain2, "wb").write(parts[0] + fake + b"".join(parts[1:]))
+    w0, n0, sep0, _, _ = api.pack_fasta(plain2, threads)
+    assert n == n0 and np.array_equal(sep, sep0) and np.array_equal(w, w0)
+    # bytes behind the last member: not this path's case
+    p3 = str(tmp_path / "trail.fa.gz")
+    open(p3, "wb").write(blob + b"\0" * 100)
+    with pytest.raises(api.DebwtError, match="declined"):
+        api.pack_fasta(p3, threads)
+    monkeypatch.delenv("DEBWT_GZ_REQUIRE_PARALLEL")
+    _check(p3, recs, threads)
