@@ -86,13 +86,18 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-// inclusive scan across the 64 lanes of a wave
+// inclusive scan across the 64 lanes of a wave: DPP row shifts inside the rows of 16 lanes, then the row totals broadcast
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- six adds whose operands arrive by the data-parallel
+// primitives of the VALU, where the __shfl_up form went through the LDS crossbar six times (ds_bpermute + wait + select)
 __device__ __forceinline__ u32 wave_scan_incl(u32 v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 t = __shfl_up(v, d, 64);
-        if ((int)lane_id() >= d) v += t;
-    }
+#define DEBWT_DPP_ADD(ctrl, rmask) v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false)
+    DEBWT_DPP_ADD(0x111, 0xf);      // row_shr:1
+    DEBWT_DPP_ADD(0x112, 0xf);      // row_shr:2
+    DEBWT_DPP_ADD(0x114, 0xf);      // row_shr:4
+    DEBWT_DPP_ADD(0x118, 0xf);      // row_shr:8
+    DEBWT_DPP_ADD(0x142, 0xa);      // row_bcast:15 -> rows 1, 3
+    DEBWT_DPP_ADD(0x143, 0xc);      // row_bcast:31 -> rows 2, 3
+#undef DEBWT_DPP_ADD
     return v;
 }
 

@@ -102,6 +102,7 @@ struct debwt_ctx {
     bool shared_hist = false;   // the first-pass histograms of all ranges came from one scan of the text
     u64 Qtotal = 0;             // multi-in blocks of the whole text (all shards)
     u64 S_rank = 0, B_rank = 0; // SP symbols / multi-in positions of this shard's text slice (all its sub-slices)
+    bool reclaim_ok = false;    // an allocation that fails may release the idle buffers of the other stages (reclaim)
     u64 *routed = nullptr;      // ... and its routed blue entries (debwt_shard_sp_emit): a key buffer when one is free, else facts_tmp
     struct SubSlice { u64 g0, g1, S, B; };
     std::vector<SubSlice> sub;  // the slice in pieces of < 2^32 positions
@@ -134,6 +135,33 @@ namespace {
         }                                                                                      \
     } while (0)
 
+// Out of memory inside a build: the buffers of the stages that are over (or have not begun) hold nothing the build still
+// needs -- after the classification the workspace of the key ranges (key buffers, distinct keys, their first rows: 30 bytes per
+// key), during the key sort what the SP stage and the blue sort of the build BEFORE left behind (node table, work lists,
+// split scratch) -- and are released, largest users first, before the allocation is tried once more.  k = 16 on a 3.1 Gbp text
+// (1.07 G branching 15-mers: a 64 GB node table, 3 G blue rows) builds this way on one GPU; a text that fits keeps every
+// buffer from build to build as before.  Returns the bytes released.
+// Only at the two points where no pointer into those buffers is held and every one of them is allocated again before its
+// next use (reclaim_ok): the allocations at the start of the key sort and at the start of the SP stage.
+size_t reclaim(debwt_ctx *c, const DevBuf *keep) {
+    if (!c->reclaim_ok) return 0;
+    std::vector<DevBuf *> idle;
+    if (c->stage >= ST_CLASSIFIED) {
+        idle = {&c->keysB, &c->dk, &c->dstart, &c->rs_rle, &c->pflag};
+        if (!c->exchange) idle.push_back(&c->keysA);
+        c->sk = nullptr; c->routed = nullptr;
+    } else {
+        idle = {&c->htab, &c->mi_list, &c->qlist, &c->qwave, &c->blue_tmp, &c->ls_buf, &c->vidx, &c->vtmp, &c->large_k0,
+                &c->large_en, &c->rowsym, &c->spn, &c->spsym, &c->rbits, &c->blue, &c->momask, &c->mimask};
+    }
+    size_t freed = 0;
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : idle)
+        if (b != keep && b->p) { freed += b->cap; (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    if (getenv("DEBWT_TRACE_ALLOC")) fprintf(stderr, "reclaim: %.2f GB of idle buffers released\n", freed / 1e9);
+    return freed;
+}
+
 int ensure(debwt_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return DEBWT_OK;
     static const bool trace = getenv("DEBWT_TRACE_ALLOC") != nullptr;
@@ -142,7 +170,14 @@ int ensure(debwt_ctx *c, DevBuf &b, size_t bytes) {
     if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     const auto t1 = std::chrono::steady_clock::now();
     size_t want = bytes + bytes / 16 + 256;
-    HIPCHK(c, hipMalloc(&b.p, want));
+    hipError_t me = hipMalloc(&b.p, want);
+    if (me == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        b.p = nullptr;
+        if (reclaim(c, &b)) me = hipMalloc(&b.p, want);
+        if (me == hipErrorOutOfMemory) { (void)hipGetLastError(); want = bytes + 256; me = hipMalloc(&b.p, want); }   // without the slack
+    }
+    if (me != hipSuccess) { b.p = nullptr; c->err = std::string("hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(me); return me == hipErrorOutOfMemory ? DEBWT_ENOMEM : DEBWT_EDEVICE; }
     b.cap = want;
     if (trace && want > (64u << 20))
         fprintf(stderr, "ensure: %.2f GB (was %.2f): sync+free %.1f ms, malloc %.1f ms\n", want / 1e9, old / 1e9,
@@ -776,10 +811,13 @@ static int special_device_build(debwt_ctx *c, bool release_arena = true) {
 // plans the ranges, sizes the range workspace, starts the host special-region module
 static int sort_begin(debwt_ctx *c) {
     const u64 n = c->n;
+    if (c->stage > ST_LOADED) c->stage = ST_LOADED;       // a new build: what the stages of the last one left is scratch (reclaim)
     int rc = plan_ranges(c);
     if (rc) return rc;
     u64 maxM = 0;
     for (auto &r : c->ranges) maxM = std::max(maxM, r.M);
+    struct ReclaimScope { debwt_ctx *c; ~ReclaimScope() { c->reclaim_ok = false; } } rscope{c};
+    c->reclaim_ok = true;                                 // (nothing of the last build's SP stage and blue sort is needed again)
     if (!c->exchange) ENSURE(c, c->keysA, maxM * 8 + 64);          // exchange mode: the received keys are buffer A
     ENSURE(c, c->keysB, maxM * 8 + 64);
     ENSURE(c, c->rs_skew, (maxM / 2048 + 2) * 4);
@@ -788,6 +826,7 @@ static int sort_begin(debwt_ctx *c) {
     ENSURE(c, c->dstart, maxM * 4 + 64);
     ENSURE(c, c->pflag, maxM + 64);                      // classification byte per distinct key of a range
     ENSURE(c, c->mchar, c->Mctx + 64);
+    c->reclaim_ok = false;
     c->Q = c->B = c->nlarge = 0; c->nfacts_acc = 0; c->n1024 = 0; c->n512 = 0; c->Dsum = 0;
     c->st.sort_unfit_stretches = c->st.sort_unfit_network = c->st.sort_over_stretches = 0;
     const size_t P = c->ranges.size();
@@ -1098,6 +1137,9 @@ extern "C" int debwt_classify(debwt_ctx *c) {
 // node table + prefilter from the red table; flag masks sized for the whole text
 static int sp_prepare(debwt_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    // (the range workspace of the key sort is idle from here on: an allocation of this function that fails may release it)
+    struct ReclaimScope { debwt_ctx *c; ~ReclaimScope() { c->reclaim_ok = false; } } rscope{c};
+    c->reclaim_ok = true;
     const u64 ngroups = (c->n + 31) >> 5;
     ENSURE(c, c->momask, ngroups * 4 + 64);
     ENSURE(c, c->mimask, ngroups * 4 + 64);
@@ -2412,6 +2454,7 @@ extern "C" int debwt_fetch_array(debwt_ctx *c, debwt_array which, void *dst, uin
                 return DEBWT_ESTATE;
             }
             if (which == DEBWT_ARR_SORTED_KEYS) { src = c->sk; cnt = c->M; } else { src = c->dk.p; cnt = c->D; }
+            if (!src && cnt) { c->err = "the keys were released when the build ran out of memory"; return DEBWT_ESTATE; }
             break;
         case DEBWT_ARR_RED: src = c->red.p; cnt = c->R; need = ST_CLASSIFIED; break;
         case DEBWT_ARR_SP_SYMBOLS: src = c->spsym.p; cnt = c->S; esz = 1; need = ST_SP; break;

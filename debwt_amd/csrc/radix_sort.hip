@@ -509,6 +509,61 @@ __device__ __forceinline__ u32 rs_rank_tile(const u64 (&key)[SC_ITEMS], u32 vmas
     return tile_total;
 }
 
+// The same for a pass that owes no order to an earlier one (the first pass of a key range): a key's place inside its digit's
+// run of the tile is whatever one returning LDS add on the digit's counter hands out -- one LDS operation per key where the
+// stable ranking takes three (OR, read, store) and a count per (32-lane unit, digit) that a digit's thread then has to sum over
+// sixteen units.  Which key of a digit comes first differs from run to run; the sorted result cannot (equal keys are equal
+// words, and every later pass is stable).  Counters: the first 256 words of the tile buffer, cleared by the caller.
+template <int FIXED0>
+__device__ __forceinline__ u32 rs_rank_tile_any(const u64 (&key)[SC_ITEMS], u32 vmask, const RsDigit &dg, ScShared &sh, u32 oalign, u32 nrounds) {
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    u32 *cnt = reinterpret_cast<u32 *>(sh.skeys);
+    u32 pk[SC_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SC_ITEMS; r++) {
+        pk[r] = 0;
+        if ((u32)r >= nrounds) continue;                               // (workgroup-uniform)
+        if ((vmask >> r) & 1u) {
+            const u32 d = rs_digit<FIXED0>(dg, key[r]);
+            pk[r] = __hip_atomic_fetch_add(&cnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | (d << 16);
+        }
+    }
+    lds_barrier();
+    u32 len = tid < RS_RADIX ? cnt[tid] : 0u;
+    u32 incl = wave_scan_incl(len);
+    if (lane == 63) sh.scan_tmp[w] = incl;
+    lds_barrier();
+    u32 tile_total = 0;
+    if (tid < RS_RADIX) {
+        u32 ls = incl - len;
+#pragma unroll
+        for (u32 i = 0; i < RS_RADIX / 64; i++) { u32 t = sh.scan_tmp[i]; if (i < w) ls += t; tile_total += t; }
+        sh.wavecnt[0][tid] = (unsigned short)ls;                       // first slot of the digit's run
+        const u32 run = sh.run[tid], cc = sh.cc[tid];
+        const u32 a0 = run - cc, e = run + len;
+        const u32 ae = ((e + oalign) & ~(SC_LINE - 1u)) - oalign;           // last line boundary <= e
+        const u32 hl = ((a0 + oalign) | (SC_LINE - 1u)) + 1u - oalign;       // first line boundary > a0
+        const bool flush = (int)(ae - a0) > 0;                               // a line completes in this tile
+        const u32 delta = run - ls;           // mod 2^32
+        sh.head[tid] = ScHead{a0, (unsigned short)ls, (u8)cc, (u8)(flush ? hl - a0 : 0u)};
+        sh.body[tid] = ScBody{delta, (short)((flush ? hl : a0) - delta), (short)((flush ? ae : a0) - delta)};
+        sh.run[tid] = e;
+        sh.cc[tid] = flush ? e - ae : cc + len;
+    } else {
+#pragma unroll
+        for (u32 i = 0; i < RS_RADIX / 64; i++) tile_total += sh.scan_tmp[i];
+    }
+    lds_barrier();                                                     // the counters are read: the keys may take their place
+    u32 slot[SC_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SC_ITEMS; r++) slot[r] = sh.wavecnt[0][pk[r] >> 16] + (pk[r] & 0xFFFFu);
+#pragma unroll
+    for (int r = 0; r < SC_ITEMS; r++)
+        if ((vmask >> r) & 1u) sh.skeys[slot[r]] = key[r];
+    lds_barrier();
+    return tile_total;
+}
+
 // F1: the pending line of every digit, 16 lanes per digit.  Parameter words first, then all key reads, then
 // the stores: the LDS round trips of the iterations overlap instead of chaining.
 // what a pass stores: the key, or (STRIP: the last pass of the blue-entry sort) the blue entry of a routed entry
@@ -796,16 +851,18 @@ void rs_scatter_sparse_waves_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n,
     u64 wcur = (u64)w * per < nwords ? (u64)w * per : nwords;         // this wave's words: [wcur, wend)
     const u64 wend = wcur + per < nwords ? wcur + per : nwords;
     u64 nw0 = 0, nw1 = 0, nwp = 0, nsa = 0, nsb = 0;
-    auto fetch = [&](u64 wb) {                                        // the batch after the one being worked on
-        const u64 i0 = beg + ((wb + lane) << 5);
-        if (wb + lane < wend && i0 < end) {
-            const u64 p = ts.pos0 + i0, g = p >> 5;
-            nw0 = ts.text[g]; nw1 = ts.text[g + 1];
-            nwp = g ? ts.text[g - 1] : 3ull;                   // the 'T' that stands at separators goes before the text
-            nsa = ts.sepbits[p >> 6]; nsb = ts.sepbits[(p >> 6) + 1];
-        }
+    // the batch after the one being worked on (wb < wend, wave-uniform).  The loads are UNCONDITIONAL -- lanes behind the wave's
+    // last word read that word again and ignore it -- and their results are touched only when the batch is taken up: a load
+    // under a per-lane condition is merged with the old value right behind it, and the wait for it with that (the loads of
+    // the lockstep kernel were waited for where they were issued).
+    auto fetch = [&](u64 wb) {
+        const u64 wl = wb + lane < wend ? wb + lane : wend - 1;
+        const u64 p = ts.pos0 + beg + (wl << 5), g = p >> 5;
+        nw0 = ts.text[g]; nw1 = ts.text[g + 1];
+        nwp = ts.text[g ? g - 1 : 0];                          // (word 0 has no word before it: see where the batch is taken up)
+        nsa = ts.sepbits[p >> 6]; nsb = ts.sepbits[(p >> 6) + 1];
     };
-    fetch(wcur);
+    if (wcur < wend) fetch(wcur);
     // the current batch of this lane: A = the symbol before its word and the word's first 31 symbols, B1 = (its last symbol
     // and the next word's first 31) >> 1 -- the 64-bit window that starts one symbol before position t is
     // (A << 2t) | (B1 >> (63 - 2t)) for every t in 0..31, no special case
@@ -820,7 +877,8 @@ void rs_scatter_sparse_waves_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n,
                 const u64 idx0 = beg + ((wcur + lane) << 5);
                 const bool mine = wcur + lane < wend && idx0 < end;
                 const u64 w0 = nw0, w1 = nw1;
-                A = (nwp << 62) | (w0 >> 2);
+                const u64 wp_ = ts.pos0 + idx0 ? nwp : 3ull;  // the 'T' that stands at separators goes before the text
+                A = (wp_ << 62) | (w0 >> 2);
                 B1 = ((w0 & 3ull) << 61) | (w1 >> 3);
                 const u64 sa = nsa, sbw = nsb;
                 wcur += 64;
@@ -895,9 +953,9 @@ void rs_scatter_sparse_waves_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n,
             total += f; maxfill = f > maxfill ? f : maxfill; anymore |= v >> 16;
         }
         if (total) {                                                  // (workgroup-uniform)
-            rs_clear_rank_state(sh);
+            if (tid < RS_RADIX) reinterpret_cast<u32 *>(sh.skeys)[tid] = 0u;      // the digits' counters (rs_rank_tile_any)
             lds_barrier();
-            const int tile_tot = (int)rs_rank_tile<DG, 0>(key, vmask, dg, sh, oalign, (maxfill + 63u) / 64u);
+            const int tile_tot = (int)rs_rank_tile_any<DG>(key, vmask, dg, sh, oalign, (maxfill + 63u) / 64u);
             rs_flush_heads(sh, out, dg);
             u64 k[SC_ITEMS];
 #pragma unroll

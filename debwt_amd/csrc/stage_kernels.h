@@ -1155,6 +1155,50 @@ __device__ __forceinline__ u64 sp_window(const u64 *__restrict__ spn, u64 s) {
     return v >> 1;                              // 21 symbols
 }
 
+// A PAIR of windows (42 symbols from s on) lies in three consecutive words: fetched as three loads that depend on nothing
+// but s, so that a thread holding several rows has all their words in flight before it shifts any of them -- the loops that
+// asked for one row's windows, shifted them, stored them and only then went on to the next row kept two to four loads in
+// flight per lane, and the gather rate of the SP code rises with the requests in flight (52 G window gathers a second at four
+// per lane and eight waves per SIMD, scripts/micro/gather16.hip).  Bit-identical to sp_window(s), sp_window(s + SP_WIN).
+struct SpTriple { u64 a0, a1, a2; u32 sh; };
+__device__ __forceinline__ SpTriple sp_fetch3(const u64 *__restrict__ spn, u64 s) {
+    const u64 b = 3 * s, w = b >> 6;
+    return SpTriple{spn[w], spn[w + 1], spn[w + 2], (u32)(b & 63)};     // (the packed code ends in two groups of zeros)
+}
+__device__ __forceinline__ void sp_pair(const SpTriple &t, u64 *w, u64 *x) {
+    const u64 v1 = t.sh ? ((t.a0 << t.sh) | (t.a1 >> (64 - t.sh))) : t.a0;
+    // the second window starts 63 bits on: bit 63 of a0 when sh == 0, else bit sh - 1 of a1
+    const u64 v2 = t.sh == 0 ? ((t.a0 << 63) | (t.a1 >> 1)) : (t.sh == 1 ? t.a1 : ((t.a1 << (t.sh - 1)) | (t.a2 >> (65 - t.sh))));
+    *w = v1 >> 1; *x = v2 >> 1;
+}
+// rows x = x0 + i * stride (i < NB) below m: sw / sx <- their window pair at depth `dd` pairs in, 0 for rows that are not
+// `wanted` or start behind the code.  All the words first, then the shifts and the LDS stores.
+template <int NB, class Wanted>
+__device__ __forceinline__ void sp_gather_pairs(const u64 *__restrict__ spn, u64 S, const u64 *se, u64 *sw, u64 *sx, u32 x0, u32 stride,
+                                                u32 m, u64 dd, Wanted wanted) {
+    SpTriple t[NB];
+    bool live[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const u32 x = x0 + (u32)i * stride;
+        live[i] = false;
+        if (x < m) {
+            const u64 pos = (se[x] >> 4) + dd * (2 * SP_WIN);
+            live[i] = pos < S && wanted(x);
+            if (live[i]) t[i] = sp_fetch3(spn, pos);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const u32 x = x0 + (u32)i * stride;
+        if (x < m) {
+            u64 w = 0ull, v = 0ull;
+            if (live[i]) sp_pair(t[i], &w, &v);
+            sw[x] = w; sx[x] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // blue-block sort (sortBlue/myQsort/cmpSP, src/sortBlue.c:109-280)
 
@@ -1274,12 +1318,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ?
             // into BINS ranges of the first 42 SP symbols (splitters from a sorted sample of 64 rows) and queue every
             // range as a block of its own for the wave-per-block kernels -- ranges are ordered among themselves and
             // rows with equal windows share a range, so sorting the ranges sorts the block.
-            for (u32 x = tid; x < m; x += NT) {
-                const u64 pos = (se[x] >> 4) + d0 * (2 * SP_WIN);
-                const bool live = pos < S;
-                sw[x] = live ? sp_window(spn, pos) : 0ull;
-                sx[x] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
-            }
+            for (u32 x = tid; x < m; x += 4 * NT)
+                sp_gather_pairs<4>(spn, S, se, sw, sx, x, NT, m, d0, [](u32) { return true; });
             if (tid < BINS) { bin_cnt[tid] = 0; bin_cur[tid] = 0; }
             __syncthreads();
             if (tid < SAMPLES) { const u32 i = (u32)(((u64)tid * m) / SAMPLES); smp_w[tid] = sw[i]; smp_x[tid] = sx[i]; }
@@ -1379,14 +1419,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CAP <= 128 ?
         for (u64 depth = 0; active; depth++) {
             // 1. next window of every unresolved row (the sample-sort split has loaded those of its round already)
             if (!(preloaded && depth == 0))
-            for (u32 x = tid; x < m; x += NT) {
-                u32 g = sg[x];
-                bool unresolved = GC_UNRES(gcm[g]);
-                u64 pos = (se[x] >> 4) + (d0 + depth) * (2 * SP_WIN);
-                bool live = unresolved && pos < S;
-                sw[x] = live ? sp_window(spn, pos) : 0ull;
-                sx[x] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
-            }
+            for (u32 x = tid; x < m; x += 4 * NT)
+                sp_gather_pairs<4>(spn, S, se, sw, sx, x, NT, m, d0 + depth, [&](u32 y) { return GC_UNRES(gcm[sg[y]]); });
             __syncthreads();
             {   // Rows that tie deeply -- the copies of a repeat in every genome of a collection share hundreds of SP
                 // symbols -- have equal windows round after round: when no unresolved row differs from the first row of
@@ -1686,13 +1720,28 @@ void k_blue_classify(u64 *__restrict__ blue, const u64 *bstart, const u32 *mi_fr
         ccnt[tid] = 0; ccnt[tid + NT] = 0; cmsk[tid] = 0; cmsk[tid + NT] = 0;
         __syncthreads();
         u32 mask = 0;
-        for (u32 x = tid; x < m; x += NT) {
-            const u64 e = blue[b0 + x];
-            se[x] = e; mask |= 1u << (e & 15);
-            const u64 pos = (e >> 4) + (u64)d0 * (2 * SP_WIN);
-            const bool live = pos < S;
-            sw[x] = live ? sp_window(spn, pos) : 0ull;
-            sx[x] = live ? sp_window(spn, pos + SP_WIN) : 0ull;
+        {   // the entries, then the words of all their window pairs, then shifts and stores (see sp_gather_pairs)
+            u64 ee[EPT];
+#pragma unroll
+            for (int r = 0; r < EPT; r++) { const u32 x = (u32)r * NT + tid; ee[r] = x < m ? blue[b0 + x] : 0ull; }
+            SpTriple t3[EPT];
+            bool live[EPT];
+#pragma unroll
+            for (int r = 0; r < EPT; r++) {
+                const u32 x = (u32)r * NT + tid;
+                const u64 pos = (ee[r] >> 4) + (u64)d0 * (2 * SP_WIN);
+                live[r] = x < m && pos < S;
+                if (live[r]) t3[r] = sp_fetch3(spn, pos);
+            }
+#pragma unroll
+            for (int r = 0; r < EPT; r++) {
+                const u32 x = (u32)r * NT + tid;
+                if (x < m) {
+                    u64 w = 0ull, v = 0ull;
+                    if (live[r]) sp_pair(t3[r], &w, &v);
+                    se[x] = ee[r]; sw[x] = w; sx[x] = v; mask |= 1u << (ee[r] & 15);
+                }
+            }
         }
         if (mask) atomicOr(&flag, mask);
         __syncthreads();

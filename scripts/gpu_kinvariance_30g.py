@@ -17,7 +17,12 @@ for k in ks:
     d = api.DeBWT(k=k)
     d.load_packed(text.a, syn.n, sep)
     t0 = time.time(); d.build(); t1 = time.time() - t0
+    t0 = time.time(); d.build(); t2 = time.time() - t0           # warm: the workspace is there
     st = d.stats()
+    ver = d.verify_device()                                       # inverse BWT on the device against the loaded text
+    print(f"k={k}: warm build {t2 * 1e3:.1f} ms (sort {st['ms_sort']:.1f} classify {st['ms_classify']:.1f} SP {st['ms_sp']:.1f} blue {st['ms_blue']:.1f}), "
+          f"inverse BWT ok: {ver['inverse_bwt_ok']}", flush=True)
+    if not ver["inverse_bwt_ok"]: print("VERIFY FAILED"); sys.exit(1)
     d.fetch_into(out.a, oh.a, od.a)
     d.close()
     crc = zlib.crc32(out.a.view(np.uint8)); hcrc = zlib.crc32(oh.a[:syn.nrec - 1].view(np.uint8))
