@@ -124,6 +124,24 @@ def emit_line(line):
     os.write(1, (json.dumps(line) + "\n").encode())
 
 
+def promote_c_host(py_line, c_line):
+    """N > 1 on real GPUs: north_star's host is C -- one process, one host thread per GPU, exchanges as grouped ncclSend / ncclRecv
+    over RCCL (debwt_multi_build, what `cli/deBWT --gpus N --exchange rccl` runs).  When that run came back whole, ITS line is the
+    line of the bench and the python ranks' measurement (one process per GPU, torch.distributed) goes under `host_python`;
+    otherwise the python ranks' line stays, with what became of the C host under `host_c`."""
+    ok = (isinstance(c_line, dict) and c_line.get("host") == "c" and isinstance(c_line.get("value"), (int, float)) and c_line["value"] > 0
+          and c_line.get("steps") == py_line.get("steps") and (c_line.get("check") is None or c_line["check"].get("inverse_bwt_ok", True)))
+    if not ok:
+        return py_line
+    out = dict(c_line)
+    out["host"] = "c (one process, one host thread per GPU, debwt_multi_build); host_python: the same collection by one process per GPU"
+    out["host_python"] = {k_: py_line[k_] for k_ in ("value", "unit", "ms_per_step", "steps", "warmup", "stages_ms", "exchange", "link_probe",
+                                                    "key_modes_ms", "first_build_s", "check", "config") if k_ in py_line}
+    for k_ in ("cpu_baseline", "vs_baseline"):
+        out.setdefault(k_, py_line.get(k_))
+    return out
+
+
 def run_c_host(args):
     """--host c: ONE process, one host thread per GPU inside the library (debwt_multi_build -- what `cli/deBWT --gpus N`
     runs), the same collection, the same checks, the same line with "host": "c".  With --backend gloo (the one-GPU test
@@ -367,6 +385,7 @@ def launch_ranks(n_ranks, args):
     no_check = ["--no-check"] if "--no-check" in base else []
     base = [a_ for a_ in base if a_ not in ("--no-check", "--no-cpu-baseline", "--no-other-mode")]
     steps = str(max(1, min(3, held.get("steps", 1))))
+    c_full = None
     try:
         if want_other:
             chosen = held["exchange"].get("keys", "rescan")
@@ -393,7 +412,12 @@ def launch_ranks(n_ranks, args):
             held["key_modes_ms"] = key_modes
         if want_c:
             left = deadline - time.perf_counter()
-            child = [sys.executable, os.path.abspath(__file__)] + base + ["--host", "c", "--steps", steps, "--warmup", "1", "--no-cpu-baseline"] + no_check
+            # on real GPUs (RCCL between the ranks) the C host runs the SAME steps over RCCL -- its line becomes the line of the
+            # bench when it comes back whole (promote_c_host); on the one-GPU test box (gloo) it stays a short extra over peer copies
+            real = args.backend == "nccl" and not args.launch_probe
+            c_steps = [str(held.get("steps", 1)), str(held.get("warmup", 1))] if real else [steps, "1"]
+            child = ([sys.executable, os.path.abspath(__file__)] + base + ["--host", "c", "--steps", c_steps[0], "--warmup", c_steps[1], "--no-cpu-baseline"]
+                     + (["--exchange", "rccl"] if real and "--exchange" not in base else []) + no_check)
             try:
                 if left <= 0:
                     raise TimeoutError
@@ -401,6 +425,7 @@ def launch_ranks(n_ranks, args):
                 if rc3 is None:
                     raise TimeoutError
                 if rc3 == 0 and j is not None:
+                    c_full = j if real else None
                     held["host_c"] = {k_: j[k_] for k_ in ("value", "unit", "ms_per_step", "steps", "warmup", "host", "exchange",
                                                           "first_build_s", "check", "config") if k_ in j}
                 else:
@@ -410,6 +435,10 @@ def launch_ranks(n_ranks, args):
             except Exception as e:                            # noqa: BLE001
                 held["host_c"] = {"error": f"{type(e).__name__}: {e}"}
             held["host"] = "python (one process per GPU, torch.distributed); host_c: the C host on the same collection"
+            if c_full is not None:
+                promoted = promote_c_host(held, c_full)
+                if promoted is not held:
+                    held.clear(); held.update(promoted)
     finally:
         for sg, h in old.items():
             signal.signal(sg, h)
@@ -758,11 +787,56 @@ def main():
         else:
             line["cpu_baseline"] = None
 
-    if rank == 0:
+    # N > 1 under an external launcher (the driver's command) on real GPUs: after the ranks' measurement, rank 0 runs the C host
+    # over RCCL on the same collection as a CHILD process -- once every rank has released its GPU (the others simply exit: the
+    # launcher waits for rank 0) -- and its line becomes the line of the bench when it comes back whole (promote_c_host).  The
+    # measured line is held back meanwhile; SIGTERM / SIGINT print it first.  --host python: no such child.
+    c_after = (rank == 0 and world > 1 and sharded and args.backend == "nccl" and args.host in (None, "both")
+               and os.environ.get("DEBWT_BENCH_NESTED") != "1" and "TORCHELASTIC_RUN_ID" in os.environ)
+    if rank == 0 and not c_after:
         emit_line(line)
     d.close()
     text.free()
+    shard_ws = None
     D.finalize()
+    if c_after:
+        import signal
+        torch.cuda.empty_cache()
+        state = {"out": False}
+
+        def flush_line(*_sig):
+            if not state["out"]:
+                state["out"] = True
+                emit_line(line)
+            if _sig:
+                if _CHILD["p"] is not None:
+                    _end_tree(_CHILD["p"], grace=5.0)
+                os._exit(0)
+
+        old = {sg: signal.signal(sg, flush_line) for sg in (signal.SIGTERM, signal.SIGINT)}
+        try:
+            env2 = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                       "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            env2["DEBWT_BENCH_NESTED"] = "1"
+            child = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--host", "c", "--exchange", "rccl",
+                     "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload, "--k", str(args.k),
+                     "--mode", args.mode if args.mode in ("auto", "exchange", "rescan") else "auto", "--no-cpu-baseline"] + (["--no-check"] if args.no_check else [])
+            sys.stderr.write("bench.py: measured line of the ranks (held back for the C host): " + json.dumps(line) + "\n")
+            sys.stderr.flush()
+            rc3, j = _run_child(child, env2, timeout=args.extras_timeout)
+            if rc3 == 0 and j is not None:
+                promoted = promote_c_host(line, j)
+                if promoted is line:
+                    line["host_c"] = {"error": "came back without a usable line", "line": {k_: j.get(k_) for k_ in ("value", "steps", "check")}}
+                line = promoted
+            else:
+                line["host_c"] = {"error": "not back within %.0f s" % args.extras_timeout if rc3 is None else "exit code %s" % rc3}
+        except Exception as e:                                # noqa: BLE001 -- the C host is extra information here
+            line["host_c"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            for sg, h in old.items():
+                signal.signal(sg, h)
+            flush_line()
 
 
 if __name__ == "__main__":

@@ -1962,12 +1962,18 @@ size_t radix_rle_ws_bytes(u64 n) { return 16 + rle_nw(n) * (8 + 12) + rle_nb(n) 
 // range offsets (uniform: scalar loads), every element then walks on from there -- ranges hold thousands of keys, so
 // that is a step or none.  (A bisection per element, 17 dependent loads in front of every 8 bytes moved, made this copy
 // run at a fifth of the rate of a radix pass.)
+// base (optional): the keys travel COMPACTED -- a stretch's keys share their leading bits up to a small difference, so in
+// the scratch array a key is (rank of its stretch) << W | (key - base[rank]) with W bits for the largest such difference:
+// the all-HBM sort of the gathered keys then takes the passes of W + bits(rank) bits instead of all 64 (distribution R at
+// 30 Gbp: 17,500 stretches per key range, W = 32: six passes instead of eight), and the way back adds the base again.
 __global__ __launch_bounds__(256) void rs_over_move(u64 *__restrict__ keys, u64 *__restrict__ scratch, const u64 *__restrict__ list,
-                                                    const u64 *__restrict__ offs, u32 nranges, u64 total, int back) {
+                                                    const u64 *__restrict__ offs, u32 nranges, u64 total, int back,
+                                                    const u64 *__restrict__ base = nullptr, int W = 0) {
     const u64 g0 = (u64)blockIdx.x * 1024u;
     if (g0 >= total) return;
     u32 lo = 0, hi = nranges;
     while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (offs[mid] <= g0) lo = mid; else hi = mid; }
+    const u64 wmask = W ? (1ull << W) - 1ull : 0ull;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const u64 g = g0 + (u64)j * 256u + threadIdx.x;
@@ -1975,8 +1981,17 @@ __global__ __launch_bounds__(256) void rs_over_move(u64 *__restrict__ keys, u64 
         u32 r = lo;
         while (r + 1 < nranges && offs[r + 1] <= g) r++;
         const u64 src = list[2 * r] + (g - offs[r]);
-        if (back) keys[src] = scratch[g]; else scratch[g] = keys[src];
+        if (!base) { if (back) keys[src] = scratch[g]; else scratch[g] = keys[src]; }
+        else if (back) keys[src] = (scratch[g] & wmask) + base[r];
+        else scratch[g] = ((u64)r << W) | (keys[src] - base[r]);
     }
+}
+// first and last key of every stretch (they are sorted by their leading bits already): what compacting them takes
+__global__ void rs_over_ends(const u64 *__restrict__ keys, const u64 *__restrict__ list, u32 nranges, u64 *__restrict__ ends) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nranges) return;
+    ends[2 * r] = keys[list[2 * r]];
+    ends[2 * r + 1] = keys[list[2 * r] + list[2 * r + 1] - 1];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2216,7 +2231,7 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
                 offs[i] = total; total += rg[i].second;
                 offs[nover + 2 * i] = rg[i].first; offs[nover + 2 * i + 1] = rg[i].second;
             }
-            if (2 * total + 3 * (u64)nover > n) whole = true;
+            if (2 * total + 6 * (u64)nover + 64 > n) whole = true;
         }
         if (getenv("DEBWT_TRACE_SORT")) {
             fprintf(stderr, "key sort of %llu keys: %u oversize stretches with %llu keys (%s)\n", (unsigned long long)n, nover,
@@ -2242,10 +2257,38 @@ u64 *radix_sort_u64(hipStream_t stream, u64 *a, u64 *b, u64 n, int key_bits, con
             (void)hipMemcpyAsync(d_offs, offs.data(), 3 * (size_t)nover * 8, hipMemcpyHostToDevice, stream);
             const u64 *d_list = d_offs + nover;
             u32 grid = (u32)((total + 1023) / 1024);
-            rs_over_move<<<grid, 256, 0, stream>>>(src, scratch, d_list, d_offs, nover, total, 0);
+            // Compacted keys (rs_over_move): the first and last key of every stretch tell how many low bits differ inside a
+            // stretch; with the stretch's rank in front, the sort of the gathered keys takes fewer passes than their 64 bits
+            u64 *d_ends = d_offs + 3 * (size_t)nover, *d_base = d_ends;              // (the ends are read back before the bases go up)
+            const u64 *cbase = nullptr;
+            int W = 0, sort_bits = key_bits;
+            static const bool plain = getenv("DEBWT_OVER_PLAIN") != nullptr;       // A/B: the 64-bit sort of rounds 2-5
+            if (!plain && nover > 1) {
+                std::vector<u64> ends(2 * (size_t)nover);
+                rs_over_ends<<<(nover + 255) / 256, 256, 0, stream>>>(src, d_list, nover, d_ends);
+                (void)hipMemcpyAsync(ends.data(), d_ends, 16 * (size_t)nover, hipMemcpyDeviceToHost, stream);
+                if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;
+                // (a stretch is in the order of its leading 64 - pshift bits only: its first key holds the smallest of those,
+                // its last the largest, the low pshift bits are anybody's)
+                u64 dmax = 0;
+                std::vector<u64> base(nover);
+                for (u32 i = 0; i < nover; i++) {
+                    base[i] = (ends[2 * i] >> pshift) << pshift;
+                    dmax = std::max(dmax, (ends[2 * i + 1] >> pshift) - (ends[2 * i] >> pshift));
+                }
+                int wb = pshift, rb = 1;
+                while (wb < 64 && (dmax >> (wb - pshift))) wb++;
+                while ((1ull << rb) < nover) rb++;
+                if (wb + rb <= key_bits - 8) {                                         // a pass less at least
+                    (void)hipMemcpyAsync(d_base, base.data(), 8 * (size_t)nover, hipMemcpyHostToDevice, stream);
+                    if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;   // base is host memory
+                    cbase = d_base; W = wb; sort_bits = wb + rb;
+                }
+            }
+            rs_over_move<<<grid, 256, 0, stream>>>(src, scratch, d_list, d_offs, nover, total, 0, cbase, W);
             // (the auxiliary kernel names: these short passes must not dilute the profile of the key-range passes)
-            u64 *r = rs_lsd(stream, scratch, tmp, total, 0, key_bits, ws, nullptr, 0, nullptr, nullptr, true);
-            rs_over_move<<<grid, 256, 0, stream>>>(src, r, d_list, d_offs, nover, total, 1);
+            u64 *r = rs_lsd(stream, scratch, tmp, total, 0, sort_bits, ws, nullptr, 0, nullptr, nullptr, true);
+            rs_over_move<<<grid, 256, 0, stream>>>(src, r, d_list, d_offs, nover, total, 1, cbase, W);
             if ((*err = hipStreamSynchronize(stream)) != hipSuccess) return src;   // offs is host memory
         }
     }

@@ -228,3 +228,22 @@ def test_bench_asked_to_leave_during_the_extras_prints_the_measured_line_first()
     assert p.returncode == 0 and len(lines) == 1, (p.returncode, out, "".join(err)[-1500:])
     j = json.loads(lines[0])
     assert j["ranks_joined"] == 2 and "key_modes_ms" not in j
+
+
+def test_bench_promotes_the_c_host_line_only_when_it_came_back_whole():
+    """N > 1 on real GPUs: the C host over RCCL (north_star's host) gives the line of the bench when its run is whole -- same
+    steps, a positive value, the inverse BWT accepted -- and the python ranks' measurement moves under `host_python`; anything
+    less leaves the python ranks' line as it is (bench.promote_c_host: pure dict logic, no GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    py = {"metric": B.METRIC, "value": 40.0, "unit": "Gbp/s", "n_gpus": 8, "steps": 5, "warmup": 1, "ms_per_step": 750.0, "host": "python",
+          "exchange": {"keys": "rescan"}, "check": {"inverse_bwt_ok": True}, "cpu_baseline": None, "vs_baseline": None}
+    c = {"metric": B.METRIC, "value": 55.0, "unit": "Gbp/s", "n_gpus": 8, "steps": 5, "warmup": 1, "ms_per_step": 545.0, "host": "c",
+         "exchange": {"backend": "RCCL"}, "check": {"inverse_bwt_ok": True}}
+    out = B.promote_c_host(py, c)
+    assert out is not py and out["value"] == 55.0 and out["ms_per_step"] == 545.0 and out["host"].startswith("c (")
+    assert out["host_python"]["value"] == 40.0 and out["host_python"]["exchange"] == {"keys": "rescan"} and "cpu_baseline" in out
+    for bad in (None, {}, dict(c, value=0.0), dict(c, steps=3), dict(c, host="python"), dict(c, check={"inverse_bwt_ok": False})):
+        assert B.promote_c_host(py, bad) is py
