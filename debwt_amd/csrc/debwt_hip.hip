@@ -112,6 +112,7 @@ struct debwt_ctx {
     u64 S_local = 0, B_slice = 0, sp_off = 0;
     int hbits = 10, pbits = 13;
     bool mzfilter = false;      // the prefilter is indexed by the nodes' minimizers (pbits = log2 of its 64-bit words)
+    int mzw = 16;               // ... of this many symbols
     bool mztable = false;       // ... and so is the node table (k_build_hash)
     bool abs32 = true;          // fill cursors hold absolute blue slots
 
@@ -1160,8 +1161,10 @@ static int sp_prepare(debwt_ctx *c) {
     // cfg.reserved & 15 = delta + 8 overrides the size (tuning).
     // The plain bitmap is kept for small node tables (below 2^20 slots: a few Mbp); from there on the minimizer filter
     // wins (250 Mbp: SP stage 3.16 ms against 3.41 ms).  cfg.reserved bit 12 forces it for any size (tests).
-    c->mzfilter = c->K >= 24 && !(c->cfg.reserved & 2048) && (hbits >= 20 || (c->cfg.reserved & 4096));
-    c->mztable = c->mzfilter && (c->cfg.reserved & 16384);        // cfg.reserved bit 14: node table addressed by minimizer (A/B, tests)
+    // (nodes of 16..23 symbols take minimizers of 12 symbols: k = 17..24 -- round 6)
+    c->mzfilter = c->K >= 16 && !(c->cfg.reserved & 2048) && (hbits >= 20 || (c->cfg.reserved & 4096));
+    c->mzw = c->K >= 24 ? MZ_W : MZ_W_SHORT;
+    c->mztable = c->mzfilter && c->K >= 24 && (c->cfg.reserved & 16384);   // cfg.reserved bit 14: node table addressed by minimizer (A/B, tests)
     int pb;
     if (c->mzfilter) {
         pb = 10;
@@ -1191,7 +1194,7 @@ static int sp_prepare(debwt_ctx *c) {
                                                                 (u32)c->Q, hbits, c->htab.as<HSlot>(), c->mzfilter ? 0 : pb,
                                                                 c->rbits.as<u32>(), c->mztable ? c->K : 0);
         if (c->mzfilter)
-            k_build_mzfilter<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->K, pb, c->rbits.as<u64>());
+            k_build_mzfilter<<<grid_for(c->R, 256), 256, 0, c->stream>>>(c->red.as<u64>(), c->R, c->K, pb, c->rbits.as<u64>(), c->mzw);
     }
     return DEBWT_OK;
 }
@@ -1228,7 +1231,7 @@ static int sp_flags(debwt_ctx *c, u64 g0, u64 g1) {
         k_sp_flags<1><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,
             c->branch.as<u64>(), c->nbranch, c->momask.as<u32>(), c->mimask.as<u32>(), g0, g1,
-            sp_block_ids(c), c->branch_bitmap ? c->brbits.as<u64>() : nullptr);
+            sp_block_ids(c), c->branch_bitmap ? c->brbits.as<u64>() : nullptr, c->mzw);
     else if (ng)
         k_sp_flags<0><<<grid_for(ng, DEBWT_BLOCK), DEBWT_BLOCK, 0, c->stream>>>(
             c->text.as<u64>(), c->sepbits.as<u64>(), c->n, c->K, c->htab.as<HSlot>(), c->hbits, c->rbits.as<u32>(), c->pbits,

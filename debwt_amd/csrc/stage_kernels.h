@@ -570,12 +570,16 @@ __device__ __forceinline__ u32 mz_bit(u64 node) { return (u32)((node * 0xC2B2AE3
 // first slot of the pair of (minimizer m at offset o of the node)
 __device__ __forceinline__ u32 mz_pair(u32 m, u32 o, int hbits) { return (((m * 0x27D4EB2Fu) >> (32 - (hbits - 5))) << 5) + 2u * o; }
 // minimizer of a node and its offset (the first 16-mer with the smallest hash)
-__device__ __forceinline__ u32 mz_of_node(u64 node, int K, u32 *off) {
+// mzw: symbols of a minimizer -- MZ_W for nodes of 24 symbols and more, MZ_W_SHORT (12) for nodes of 16..23 (k = 17..24: nine
+// to twelve candidate 12-mers per node; round 6 -- before, such k probed a bitmap once per position: k = 20 on 3.1 Gbp spent
+// 82 ms in the SP stage against 28 at k = 32)
+#define MZ_W_SHORT 12
+__device__ __forceinline__ u32 mz_of_node(u64 node, int K, u32 *off, int mzw = MZ_W) {
     const u64 win = node << (64 - 2 * K);
-    const int nw = K - MZ_W + 1;
+    const int nw = K - mzw + 1, hs = 32 - 2 * mzw;
     u32 m = 0xFFFFFFFFu, o = 0;
     for (int j = 0; j < nw; j++) {
-        const u32 h = mz_hash((u32)(win >> (32 - 2 * j)));
+        const u32 h = mz_hash((u32)(win >> (32 - 2 * j)) >> hs);
         if (h < m) { m = h; o = (u32)j; }
     }
     *off = o;
@@ -628,12 +632,12 @@ __global__ void k_build_hash(const u64 *__restrict__ red, u64 R, const u32 *__re
 // a minimizer share the word (red nodes cluster around the same loci), the words are sized for ~2 red nodes each; a
 // minimizer that very many red nodes share (a homopolymer's) saturates its word and merely sends its positions to the
 // node table, as every position went before.  Used for K >= 24 (a node then has >= 9 candidate 16-mers).
-__global__ void k_build_mzfilter(const u64 *__restrict__ red, u64 R, int K, int fbits, u64 *__restrict__ fw) {
+__global__ void k_build_mzfilter(const u64 *__restrict__ red, u64 R, int K, int fbits, u64 *__restrict__ fw, int mzw) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const u64 node = red[r] >> 2;
     u32 o;
-    atomicOr(&fw[mz_word(mz_of_node(node, K, &o), fbits)], 1ull << mz_bit(node));
+    atomicOr(&fw[mz_word(mz_of_node(node, K, &o, mzw), fbits)], 1ull << mz_bit(node));
 }
 
 // returns the slot (or 0xFFFFFFFF) and the flags of `node`; mzK > 0: the table is addressed by minimizer (k_build_hash)
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_
                                                            const u32 *__restrict__ rbits, int pb,
                                                            const u64 *__restrict__ branch, u64 nbranch,
                                                            u32 *__restrict__ momask, u32 *__restrict__ mimask,
-                                                           u64 g0, u64 g1, SpBlockIds ids, const u64 *__restrict__ brbits) {
+                                                           u64 g0, u64 g1, SpBlockIds ids, const u64 *__restrict__ brbits, int mzw = MZ_W) {
     // block ids of the lane's multi-in positions until the wave knows where they go (a lane reads only its own 32 words)
     __shared__ u32 lq[DEBWT_BLOCK * 32];
     u64 g = g0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -737,7 +741,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_
         // hashes of the 16-mers that start at symbols 0..46 of the word pair; minimizer of the node at t = the smallest
         // among those of symbols t .. t + K - 16 (pb = filter words as a power of two, rbits = the words)
         const u64 *fw = reinterpret_cast<const u64 *>(rbits);
-        const int nw = K - MZ_W + 1;
+        const int nw = K - mzw + 1, hs = 32 - 2 * mzw;      // (minimizers of mzw symbols: the leading ones of the 16-symbol window)
         u32 H[47];
 #pragma unroll
         for (int j = 0; j < 47; j++) {
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(DEBWT_BLOCK) __attribute__((amdgpu_waves_per_eu(SP_
             if (j <= 16) x = (u32)(w0 >> (32 - 2 * j));
             else if (j < 32) x = (u32)(w0 << (2 * j - 32)) | (u32)(w1 >> (96 - 2 * j));
             else x = (u32)(w1 >> (96 - 2 * j));
-            H[j] = mz_hash(x);
+            H[j] = mz_hash(x >> hs);
         }
         u32 mprev = 0;
         u64 fwv = 0;
