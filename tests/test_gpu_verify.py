@@ -118,6 +118,35 @@ def test_config2_properties(api, workload):
     assert digests[0] == digests[1]
 
 
+def test_k_over_its_range_at_config2_size(api):
+    """The reference takes any -k from 12 to 32 for any input (src/main.c:41-47).  GRCh38-sized text, k = 16 and k = 20 beside
+    k = 32 (k = 24 is in test_config2_properties): the symbol census, the device inverse BWT, and the identical BWT (k-invariance,
+    SURVEY 4.4).  k = 16 has 1.07 G branching 15-mers out of 4^15: the node table takes its 2^32 slots (64 GB) and the build
+    releases the idle range workspace when that allocation does not fit (round 5 answered DEBWT_ERANGE); k = 20 takes the
+    prefilter by minimizers of 12 symbols (round 5: a bitmap probe per position, 1.45 x the time of k = 32)."""
+    import zlib
+    from debwt_amd import synth_native as SN
+    syn = SN.Synth.named("grch38_3.1G")
+    words, census = syn.words()
+    sep = syn.sep()
+    want = census.astype(np.int64).copy()
+    want[3] += syn.nrec
+    ref = None
+    for k in (32, 20, 16):
+        d = api.DeBWT(k=k)
+        d.load_packed(words, syn.n, sep)
+        d.build()
+        assert (d.bwt_census().astype(np.int64) == want).all(), k
+        r = d.verify_device()
+        assert r["inverse_bwt_ok"] and r["inverse_bwt"]["mismatches"] == 0, (k, r)
+        w, h, dr = d.fetch()
+        d.close()
+        cur = (zlib.crc32(w.view(np.uint8)), zlib.crc32(h.view(np.uint8)), dr)
+        if ref is None:
+            ref = cur
+        assert cur == ref, k
+
+
 @pytest.mark.parametrize("workload", ["pan4x3.1G", "pan10x3G"])
 def test_config3_config4_collections_on_one_gpu(api, workload):
     """BASELINE.json configs[3] and configs[4] name 4 and 8 GPUs; their collections -- 4 x GRCh38-sized = 12.4 Gbp and
