@@ -61,7 +61,7 @@ WORKLOAD_NOTE = {
     "ecoli_4.6M": "BASELINE configs[0]: E. coli-sized single record",
     "uniform_3.1G": "distribution U: uniform 3.1 Gbp in 24 records",
     "real_3.1G": "distribution R: 3.1 Gbp in 24 records with an Alu-like family, satellite arrays, homopolymer tracts",
-    "pan10x600M": "distribution P, 10 genomes x 600 Mbp in 240 records: the largest size whose 8 shards fit next to each other on one GPU",
+    "pan10x600M": "distribution P, 10 genomes x 600 Mbp in 240 records (up to 4 shards fit next to each other on one GPU; 8 do at 10 x 400 Mbp)",
     "real10x600M": "distribution R, 10 genomes x 600 Mbp in 240 records (Alu-like family, satellites, homopolymer tracts at the 3 Gbp densities)",
     "real10x3G": "distribution R at the headline size: 10 genomes x 3.0 Gbp in 240 records, each with an Alu-like family "
                  "(10^6 copies), satellite arrays and homopolymer tracts, SNP 1e-3 between the genomes",

@@ -75,8 +75,9 @@ WORKLOADS = {
     "real_3.1G": (3_100_000_000, 1, 24, {"lowcx_fraction": 0.03, "alu_copies": 1_000_000}),
     # distribution R at the size the metric is quoted on: ten such genomes (SNPs at 1e-3 between them), 240 records
     "real10x3G": (3_000_000_000, 10, 24, {"lowcx_fraction": 0.03, "alu_copies": 1_000_000}),
-    # the two headline distributions at the largest size whose 8 shards fit next to each other in ONE GPU's HBM (~40 bytes
-    # per base over all shards): per-shard measurements of N = 2, 4, 8 on a one-GPU box (scripts/gpu_shard_balance.py);
+    # the two headline distributions at a size whose shards fit next to each other in ONE GPU's HBM (~40 bytes per base over
+    # all shards: N = 2 and 4 here; N = 8 ran out of memory and was measured at 10 x 400 Mbp): per-shard measurements on a
+    # one-GPU box (scripts/gpu_shard_balance.py);
     # the same densities of repeat families, Alu-like copies and low-complexity tracts as the 3 Gbp genomes
     "pan10x600M": (600_000_000, 10, 24, {}),
     "real10x600M": (600_000_000, 10, 24, {"lowcx_fraction": 0.03, "alu_copies": 200_000}),

@@ -137,6 +137,18 @@ int debwt_reserve(debwt_ctx *ctx, uint64_t n, uint64_t nrec, double branching, u
 int debwt_set_range_cap(debwt_ctx *ctx, uint64_t max_instances);
 
 /* ---- stage entry points, to be called in this order after a load ------------------------------ */
+/* Capacities of this build (the reference has none: uint64_t throughout, src/collect#$.h) -- each is a 32-bit index somewhere,
+ * each answers DEBWT_ERANGE with the reason in debwt_last_error, none has a slower fall-back:
+ *   debwt_kmer_sort_rle / debwt_shard_plan  one 12-mer prefix bin (the unit key ranges are cut at) holds 2^32 - 2^20 node
+ *                        instances or more: a key range indexes its keys with 32 bits.  30 Gbp of ten genomes: the fullest
+ *                        bin holds 0.1 G; a text of > 4 G copies of one 12-mer (a 4 Gbp homopolymer) would hit it.
+ *   debwt_sp_generate    more than 2^31 branching nodes (slot numbers of the node table are 32-bit: 2^32 slots = 64 GB;
+ *                        k = 16 on 3.1 Gbp has 0.7 G); a sharded build: a text slice with 2^32 multi-in positions or more
+ *                        (debwt_shard_blue_route; ten genomes with an Alu-like family at N = 1: use more shards or the
+ *                        one-GPU build, which buckets its 5.6 G entries by key range), or a routed entry whose block id
+ *                        and SP index do not fit 61 bits (debwt_shard_sp_emit).
+ *   debwt_shard_begin    world > 255 (the owner table holds bytes).
+ * DEBWT_ENOMEM is not a capacity: the stages release what the other stages left (debwt_hip.hip, reclaim) before they give up. */
 
 /* Replaces kmercounting.sh + mySort (src/main.c:70,83; src/mySort.c:26-201) and getKmer
  * (src/getKmer.c:12-49): enumerates every node instance of the text as a key
