@@ -136,6 +136,60 @@ int main() {
         free_packed_text(&want);
         remove(path);
     }
+    {   // several PLAIN gzip members (gz_parallel.cpp, inflate_gzip_members): many members (every candidate on a thread of its
+        // own) and few (one after the other, each in pieces), a damaged member, bytes behind the last member
+        std::vector<std::string> rr;
+        for (int r = 0; r < 9; r++) { std::string q(120000 + rnd() % 90000, 'A'); for (auto &c : q) c = acgt[rnd() & 3]; rr.push_back(q); }
+        const std::string whole = fasta_of(rr, 70, false, false);
+        PackedText want{};
+        CHECK(pack_fasta_buffer(whole.data(), whole.size(), 2, &want, err, sizeof err) == 0);
+        std::vector<size_t> cuts;                              // record starts
+        for (size_t i = 0; i < whole.size(); i++) if (whole[i] == '>') cuts.push_back(i);
+        cuts.push_back(whole.size());
+        const char *path = "/tmp/debwt_sanitize_members.fa.gz";
+        setenv("DEBWT_GZ_REQUIRE_PARALLEL", "1", 1);
+        setenv("DEBWT_GZ_PIECE_BYTES", "16384", 1);
+        for (size_t per : {(size_t)1, (size_t)5}) {               // 9 members, 2 members
+            remove(path);
+            std::string z;
+            for (size_t a = 0; a + 1 < cuts.size(); a += per) {
+                const size_t b = std::min(a + per, cuts.size() - 1);
+                const char *one = "/tmp/debwt_sanitize_member_one.gz";
+                gzFile g = gzopen(one, "wb6");
+                CHECK(g && gzwrite(g, whole.data() + cuts[a], (unsigned)(cuts[b] - cuts[a])) == (int)(cuts[b] - cuts[a]));
+                gzclose(g);
+                FILE *f = fopen(one, "rb");
+                char tmp[65536];
+                size_t got;
+                while ((got = fread(tmp, 1, sizeof tmp, f)) > 0) z.append(tmp, got);
+                fclose(f);
+                remove(one);
+            }
+            FILE *f = fopen(path, "wb"); CHECK(f && fwrite(z.data(), 1, z.size(), f) == z.size()); fclose(f);
+            for (int threads : {2, 8}) {
+                PackedText p{};
+                CHECK(pack_fasta_file(path, threads, &p, err, sizeof err) == 0);
+                CHECK(p.n == want.n && p.nrec == want.nrec && !memcmp(p.words, want.words, want.nwords * 8));
+                free_packed_text(&p);
+            }
+            std::string bad = z;                                    // damage: no path may hand out a wrong text
+            bad[bad.size() / 3] ^= 0x5A;
+            f = fopen(path, "wb"); fwrite(bad.data(), 1, bad.size(), f); fclose(f);
+            unsetenv("DEBWT_GZ_REQUIRE_PARALLEL");
+            PackedText p{};
+            CHECK(pack_fasta_file(path, 4, &p, err, sizeof err) != 0);
+            z.append(64, '\0');                                     // bytes behind the last member: the serial path's case
+            f = fopen(path, "wb"); fwrite(z.data(), 1, z.size(), f); fclose(f);
+            CHECK(pack_fasta_file(path, 4, &p, err, sizeof err) == 0);
+            CHECK(p.n == want.n && !memcmp(p.words, want.words, want.nwords * 8));
+            free_packed_text(&p);
+            setenv("DEBWT_GZ_REQUIRE_PARALLEL", "1", 1);
+        }
+        unsetenv("DEBWT_GZ_REQUIRE_PARALLEL");
+        unsetenv("DEBWT_GZ_PIECE_BYTES");
+        free_packed_text(&want);
+        remove(path);
+    }
     {   // block gzip (BGZF: members with the 'BC' subfield, inflated in parallel), whole and with a damaged member
         std::string fa = fasta_of(recs, 70, false, false);
         const char *path = "/tmp/debwt_sanitize_bgzf.fa.gz";
