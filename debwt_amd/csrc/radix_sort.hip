@@ -824,6 +824,9 @@ void rs_scatter_sparse_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 c
 // have to keep), and the chunk histograms it is handed count keys per chunk, whatever wave finds them.  The prefix tests
 // work on 32-bit windows (v_alignbit): a window lies in the range when (x - lo << 20) < (span << 20), and the borrow of
 // that comparison is shifted into the mask by an add-with-carry.
+#ifndef SPARSE_W32
+#define SPARSE_W32 1                   // the append loop's window by two v_alignbit_b32 instead of two 64-bit shifts (A/B: 0)
+#endif
 template <int HI, int K31>
 __global__ __launch_bounds__(SC_NT) __attribute__((amdgpu_waves_per_eu(RS_WAVES_EU, RS_WAVES_EU)))
 void rs_scatter_sparse_waves_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n, u64 chunk, RsDigit dg,
@@ -923,13 +926,25 @@ void rs_scatter_sparse_waves_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n,
             const u32 woff = incl - cnt;
             u32 take = woff >= room ? 0u : (cnt < room - woff ? cnt : room - woff);
             u32 o = w * SEG + fill + woff;
+#if SPARSE_W32
+            // W by 32-bit funnel shifts: Y = (A : B) >> 1 in four words, W = the 64 bits of Y from bit 2t + 1 on -- both halves
+            // one v_alignbit_b32 by 31 - (2t mod 32) of the word pair that 2t / 32 selects (no 64-bit shift: A/B in the header)
+            const u64 A1 = A >> 1, B2 = (A << 63) | B1;
+            const u32 Y0 = (u32)(A1 >> 32), Y1 = (u32)A1, Y2 = (u32)(B2 >> 32), Y3 = (u32)B2;
             while (take--) {
-                const u32 s2 = 2u * ((u32)__ffs(m) - 1u);
+                const u32 s2 = 2u * (u32)__builtin_ctz(m);               // (take > 0: the mask is not empty)
                 m &= m - 1u;
-                const u64 W = (A << s2) | (B1 >> (63u - s2));          // pred(t), then the 31 symbols from t on
-                if (K31) sh.skeys[o++] = (W << 2) | (W >> 62);          // node << 2 | pred: a rotation
-                else sh.skeys[o++] = (((W << 2) >> nsh) << 2) | (W >> 62);
+                const bool up = s2 > 31u;
+                const u32 ya = up ? Y1 : Y0, yb = up ? Y2 : Y1, yc = up ? Y3 : Y2, shf = s2 ^ 31u;
+                sh.skeys[o++] = ((u64)__builtin_amdgcn_alignbit(ya, yb, shf) << 32) | __builtin_amdgcn_alignbit(yb, yc, shf);
             }
+#else
+            while (take--) {
+                const u32 s2 = 2u * (u32)__builtin_ctz(m);               // (take > 0: the mask is not empty)
+                m &= m - 1u;
+                sh.skeys[o++] = (A << s2) | (B1 >> (63u - s2));          // W: pred(t), then the 31 symbols from t on; the
+            }                                                            // key is made of it where the wave takes its keys up
+#endif
             pending = tot > room;
             fill = pending ? SEG : fill + tot;
             if (fill == SEG) break;
@@ -942,7 +957,13 @@ void rs_scatter_sparse_waves_kernel(TextKeySrc ts, u64 *__restrict__ out, u64 n,
 #pragma unroll
         for (int r = 0; r < SC_ITEMS; r++) {
             const bool have = (u32)r * 64u + lane < fill;
-            key[r] = have ? sh.skeys[w * SEG + (u32)r * 64u + lane] : ~0ull;
+            const u64 W = sh.skeys[w * SEG + (u32)r * 64u + lane];
+            u64 kk;
+            if (K31) {                                                  // node << 2 | pred: W rotated left by two bits
+                const u32 hi = (u32)(W >> 32), lo = (u32)W;
+                kk = ((u64)__builtin_amdgcn_alignbit(hi, lo, 30) << 32) | __builtin_amdgcn_alignbit(lo, hi, 30);
+            } else kk = (((W << 2) >> nsh) << 2) | (W >> 62);
+            key[r] = have ? kk : ~0ull;
             vmask |= (have ? 1u : 0u) << r;
         }
         lds_barrier();                                                // every wave holds its keys: skeys becomes rank state
