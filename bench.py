@@ -791,7 +791,9 @@ def main():
     # over RCCL on the same collection as a CHILD process -- once every rank has released its GPU (the others simply exit: the
     # launcher waits for rank 0) -- and its line becomes the line of the bench when it comes back whole (promote_c_host).  The
     # measured line is held back meanwhile; SIGTERM / SIGINT print it first.  --host python: no such child.
-    c_after = (rank == 0 and world > 1 and sharded and args.backend == "nccl" and args.host in (None, "both")
+    # (DEBWT_BENCH_FORCE_C_AFTER=1: the same choreography over gloo on the one-GPU test box, the C host then over peer copies)
+    forced = os.environ.get("DEBWT_BENCH_FORCE_C_AFTER") == "1"
+    c_after = (rank == 0 and world > 1 and sharded and (args.backend == "nccl" or forced) and args.host in (None, "both")
                and os.environ.get("DEBWT_BENCH_NESTED") != "1" and "TORCHELASTIC_RUN_ID" in os.environ)
     if rank == 0 and not c_after:
         emit_line(line)
@@ -818,7 +820,8 @@ def main():
             env2 = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
                                                                        "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
             env2["DEBWT_BENCH_NESTED"] = "1"
-            child = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--host", "c", "--exchange", "rccl",
+            child = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--host", "c", "--backend", args.backend,
+                     "--exchange", "rccl" if args.backend == "nccl" else "peer",
                      "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload, "--k", str(args.k),
                      "--mode", args.mode if args.mode in ("auto", "exchange", "rescan") else "auto", "--no-cpu-baseline"] + (["--no-check"] if args.no_check else [])
             sys.stderr.write("bench.py: measured line of the ranks (held back for the C host): " + json.dumps(line) + "\n")

@@ -108,3 +108,41 @@ def test_bench_two_ranks_started_by_bench_itself_rccl():
                                "--no-cpu-baseline", "--mode", mode], env_extra={"DEBWT_BIG_MESSAGE_PROBE": "1"})
         assert j["n_gpus"] == 2 and j["check"]["census_equals_text"] and j["check"]["inverse_bwt_ok"], j
         assert j["link_probe"]["content_ok"] and j["link_probe"]["gbytes_per_s_per_peer"] > 0, j["link_probe"]
+
+
+def test_bench_under_a_launcher_hands_the_line_to_the_c_host_when_it_comes_back_whole():
+    """The driver's N > 1 command (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) on real GPUs: after the
+    ranks' measurement rank 0 runs the C host on the same collection as a child process -- the other ranks have exited and
+    released their GPU -- and its line becomes the line of the bench (`host` starts with "c", the ranks' measurement under
+    `host_python`).  Rehearsed here over gloo on the one GPU (DEBWT_BENCH_FORCE_C_AFTER: the C host then exchanges by peer
+    copies); exactly one JSON line, exit code 0, both results verified by the device inverse BWT."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DEBWT_BENCH_FORCE_C_AFTER"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "ecoli_4.6M",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["host"].startswith("c (") and j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0, j.get("host")
+    assert j["check"]["inverse_bwt_ok"] and j["host_python"]["value"] > 0 and j["host_python"]["check"]["inverse_bwt_ok"], j
+    # ... and when the C host fails, the ranks' line stays and says what happened
+    env["DEBWT_BENCH_FAIL_EXTRA"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "ecoli_4.6M",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert "host_python" not in j and j["check"]["inverse_bwt_ok"] and "exit code" in j["host_c"]["error"], j.get("host_c")
