@@ -8,6 +8,7 @@
 // Layout, alphabet and checks are the reference's: A0 C1 G2 T3 either case (src/main.c:18-23), 'T' at every
 // separator and 32 'T' behind the end (src/collect#$.c:78-90), every record longer than 32 bases (:41-45).
 #include "fasta_host.h"
+#include "fast_inflate.h"
 #include "gz_parallel.h"
 
 #include <fcntl.h>
@@ -25,6 +26,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <memory>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -404,9 +407,15 @@ int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out,
     const uint64_t nrec = reclen.size();
     const uint64_t n = sym + 1;                              // + the final '$'
     const uint64_t nwords = ((n + 63) >> 5) + 2;
-    uint64_t *words = (uint64_t *)calloc(nwords, 8);
+    // The words are not cleared as a whole (calloc's fresh pages: 4 KB faults from all threads at once; big_malloc: huge pages,
+    // which may hold anything): the packers store every word they complete, and OR only into the first word of a chunk -- the
+    // last of the chunk before -- and into the words from the final symbol on.  Those are cleared here.
+    uint64_t *words = (uint64_t *)big_malloc(nwords * 8);
     uint64_t *sep = (uint64_t *)malloc(nrec * 8);
     if (!words || !sep) { free(words); free(sep); return fail(err, errlen, "out of memory"); }
+    if (getenv("DEBWT_INGEST_POISON")) memset(words, 0xA5, nwords * 8);     // tests: nothing may rely on cleared memory
+    for (size_t t = 0; t < nch; t++) words[ch[t].sym0 >> 5] = 0;
+    for (uint64_t w = sym >> 5; w < nwords; w++) words[w] = 0;
     {
         std::vector<std::thread> th;
         for (size_t t = 1; t < nch; t++) th.emplace_back(pack, buf, std::cref(ch[t]), words, sep, opts);
@@ -445,28 +454,28 @@ static int inflate_bgzf(const unsigned char *z, size_t zlen, int threads, char *
         p += bsize;
     }
     if (off.empty()) return 1;
-    char *buf = (char *)malloc(total + 1);
+    char *buf = (char *)big_malloc(total + 1);
     if (!buf) return -1;
     const size_t nb = off.size();
     if (threads < 1) threads = 1;
     const size_t T = std::min<size_t>((size_t)threads, nb);
     std::vector<int> bad(T, 0);
     auto work = [&](size_t t) {
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) != Z_OK) { bad[t] = 1; return; }
+        // every member straight into its place of the one buffer (fast_inflate.h writes nothing behind the ISIZE bytes it is given)
+        std::unique_ptr<fastinflate::Decoder> d(new (std::nothrow) fastinflate::Decoder());
+        if (!d) { bad[t] = 1; return; }
         for (size_t b = nb * t / T; b < nb * (t + 1) / T && !bad[t]; b++) {
             const size_t want = (b + 1 < nb ? uoff[b + 1] : total) - uoff[b];
-            inflateReset(&zs);
-            zs.next_in = const_cast<Bytef *>(z + off[b]); zs.avail_in = (uInt)dlen[b];
-            zs.next_out = (Bytef *)buf + uoff[b]; zs.avail_out = (uInt)want;
-            const int r = want ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+            size_t got = 0;
+            int r = fastinflate::FI_DONE;
+            if (want) {
+                d->start(z + off[b], dlen[b], 0);
+                r = d->run((uint8_t *)buf + uoff[b], 0, &got, want, ~(size_t)0);
+            }
             const unsigned char *tr = z + off[b] + dlen[b];                              // CRC32, ISIZE
-            const uLong crc = tr[0] | ((uLong)tr[1] << 8) | ((uLong)tr[2] << 16) | ((uLong)tr[3] << 24);
-            if ((want && (r != Z_STREAM_END || zs.avail_out != 0)) || crc32(crc32(0L, Z_NULL, 0), (const Bytef *)buf + uoff[b], (uInt)want) != crc)
-                bad[t] = 1;
+            const uint32_t crc = tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+            if (r != fastinflate::FI_DONE || got != want || fastinflate::crc32_fast(0, (const uint8_t *)buf + uoff[b], want) != crc) bad[t] = 1;
         }
-        inflateEnd(&zs);
     };
     {
         std::vector<std::thread> th;

@@ -10,10 +10,10 @@
 //   2. a chunk is decoded from its block start with an UNKNOWN window: a small decoder of our own (RFC 1951, canonical
 //      codes decoded the counting way) writes 16-bit symbols, where a copy that reaches into the unknown window leaves a
 //      marker (which window byte) instead of a byte.  DNA text compresses by its Huffman codes, not by long copies, so
-//      after a few blocks the last 32 KB of output hold no marker: from the next block boundary on zlib's own inflate
-//      continues (raw deflate, that 32 KB as dictionary, inflatePrime for the bits before the first whole byte -- the
-//      random-access recipe of zlib's examples/zran.c) up to the bit where the next chunk starts, which must be one of
-//      the block boundaries it stops at (Z_BLOCK);
+//      after a few blocks the last 32 KB of output hold no marker: from the next block boundary on the byte decoder of
+//      fast_inflate.h continues (it starts at any bit with that 32 KB in front of its output; until round 6 this was
+//      zlib's inflate by the recipe of its examples/zran.c, at under half the rate) up to the bit where the next chunk
+//      starts, which must be one of the block boundaries it passes;
 //   3. the chunks' marker prefixes are resolved in order with the 32 KB before them (a few hundred KB per chunk), the
 //      pieces are copied into one buffer by all threads, and the CRC32 and length of the whole (crc32_combine of the
 //      chunks') must equal the gzip trailer.
@@ -21,6 +21,7 @@
 // where the next begins, a CRC that differs -- makes the function return 1 and the caller inflates serially with gzread,
 // as before.  Nothing here is trusted without the trailer check.
 #include "gz_parallel.h"
+#include "fast_inflate.h"
 
 #include <zlib.h>
 
@@ -30,6 +31,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -43,21 +46,23 @@ constexpr size_t WIN = 32768;
 // the slack behind every deflate block: O(n) per block)
 struct SymVec {
     sym_t *p = nullptr; size_t n = 0, cap = 0;
+    size_t lead = 0;                           // symbols kept in front of p[0] in the same allocation (a piece's window of markers)
     SymVec() = default;
     SymVec(const SymVec &) = delete;
     SymVec &operator=(const SymVec &) = delete;
-    SymVec(SymVec &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
-    ~SymVec() { free(p); }
+    SymVec(SymVec &&o) noexcept : p(o.p), n(o.n), cap(o.cap), lead(o.lead) { o.p = nullptr; o.n = o.cap = 0; }
+    ~SymVec() { release(); }
     size_t size() const { return n; }
     sym_t &operator[](size_t i) { return p[i]; }
     const sym_t &operator[](size_t i) const { return p[i]; }
     void clear() { n = 0; }
-    void release() { free(p); p = nullptr; n = cap = 0; }
+    void release() { if (p) free(p - lead); p = nullptr; n = cap = 0; }
     bool reserve(size_t want) {                // false: out of memory (the old array stays)
-        if (want <= cap) return true;
-        sym_t *q = (sym_t *)realloc(p, want * sizeof(sym_t));
+        if (want <= cap && p) return true;
+        sym_t *q = (sym_t *)big_malloc((want + lead) * sizeof(sym_t));
         if (!q) return false;
-        p = q; cap = want;
+        if (p) { memcpy(q, p - lead, (n + lead) * sizeof(sym_t)); free(p - lead); }
+        p = q + lead; cap = want;
         return true;
     }
     bool push_back(sym_t v) { if (n == cap && !reserve(cap + cap / 2 + ((size_t)1 << 16))) return false; p[n++] = v; return true; }
@@ -280,86 +285,87 @@ size_t find_block(const unsigned char *z, size_t nbits, size_t from, size_t to) 
 struct Piece {
     size_t start_bit = 0, end_bit = 0;       // decoded from / up to (the next piece's start_bit, or the end of the final block)
     SymVec head;                              // symbols decoded with the unknown window (may hold markers)
-    char *body = nullptr; size_t body_len = 0, body_cap = 0;   // what zlib decoded behind them (final bytes)
+    char *alloc = nullptr;                    // WIN bytes (the window the body starts from) and the body behind them
+    char *body = nullptr; size_t body_len = 0, body_cap = 0;   // what the fast decoder decoded behind the head (final bytes)
     std::vector<char> head_bytes;             // head, resolved
     bool final_block = false;
     int status = 0;                           // 0 ok, 1 does not fit (serial fallback), -1 damaged / out of memory
 };
 
-bool grow(Piece &p, size_t need) {
+// room for `need` more body bytes.  `first`: the capacity to start with (fast_part sizes it from the piece's compressed bytes, so
+// that the body is allocated once -- reserved, not touched -- and never moved)
+bool grow(Piece &p, size_t need, size_t first = (size_t)8 << 20) {
     if (p.body_len + need <= p.body_cap) return true;
-    size_t cap = p.body_cap ? p.body_cap : ((size_t)8 << 20);
+    size_t cap = p.body_cap ? p.body_cap : first;
     while (cap < p.body_len + need) cap *= 2;
-    char *nb = (char *)realloc(p.body, cap);
+    char *nb = (char *)big_malloc(WIN + cap);
     if (!nb) return false;
-    p.body = nb; p.body_cap = cap;
+    if (p.alloc) { memcpy(nb, p.alloc, WIN + p.body_len); free(p.alloc); }
+    p.alloc = nb; p.body = nb + WIN; p.body_cap = cap;
     return true;
 }
 
-// zlib continues at a block boundary `bit` with the 32 KB `dict` before it, until it reaches `stop_bit` (a boundary) or
-// the end of the final block
-void zlib_part(const unsigned char *z, size_t zlen, size_t bit, size_t stop_bit, const unsigned char *dict, size_t dictlen, Piece &p) {
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) { p.status = -1; return; }
-    if (dictlen && inflateSetDictionary(&zs, dict, (uInt)dictlen) != Z_OK) { inflateEnd(&zs); p.status = 1; return; }
-    size_t byte = bit >> 3;
-    if (bit & 7) {
-        if (inflatePrime(&zs, 8 - (int)(bit & 7), z[byte] >> (bit & 7)) != Z_OK) { inflateEnd(&zs); p.status = 1; return; }
-        byte++;
-    }
-    size_t in_done = byte;                                    // bytes of z handed to zlib and consumed
+// the fast decoder (fast_inflate.h) continues at a block boundary `bit` with the 32 KB `dict` before it, until it reaches
+// `stop_bit` (a boundary) or the end of the final block
+void fast_part(const unsigned char *z, size_t zlen, size_t bit, size_t stop_bit, const unsigned char *dict, size_t dictlen, Piece &p) {
+    std::unique_ptr<fastinflate::Decoder> d(new (std::nothrow) fastinflate::Decoder());
+    // DNA text deflates to 1/3.2 .. 1/4.5: five times the piece's compressed bytes hold it
+    const size_t comp = ((stop_bit == ~(size_t)0 ? 8 * zlen : stop_bit) - bit) / 8;
+    if (!d || !grow(p, (size_t)1 << 20, comp * 5 + ((size_t)1 << 20))) { p.status = -1; return; }
+    if (dictlen) memcpy(p.body - dictlen, dict, dictlen);      // (dictlen <= WIN: the bytes in front of the body)
+    d->start(z, zlen, bit);
     for (;;) {
-        if (!grow(p, (size_t)1 << 20)) { p.status = -1; break; }
-        const size_t chunk_in = zlen - in_done < ((size_t)1 << 30) ? zlen - in_done : ((size_t)1 << 30);
-        zs.next_in = const_cast<Bytef *>(z + in_done); zs.avail_in = (uInt)chunk_in;
-        const size_t room = p.body_cap - p.body_len < ((size_t)1 << 30) ? p.body_cap - p.body_len : ((size_t)1 << 30);
-        zs.next_out = (Bytef *)p.body + p.body_len; zs.avail_out = (uInt)room;
-        const int r = inflate(&zs, Z_BLOCK);
-        in_done += chunk_in - zs.avail_in;
-        p.body_len += room - zs.avail_out;
-        if (r == Z_STREAM_END) { p.final_block = true; p.end_bit = 8 * in_done - (size_t)(zs.data_type & 63); break; }
-        if (r != Z_OK && r != Z_BUF_ERROR) { p.status = 1; break; }       // not deflate from here: the start was wrong
-        if (zs.data_type & 128) {                             // at a block boundary
-            const size_t here = 8 * in_done - (size_t)(zs.data_type & 63);
-            if (here == stop_bit) { p.end_bit = here; break; }
-            if (here > stop_bit) { p.status = 1; break; }     // the next piece does not start on a boundary of this one
-        }
-        if (r == Z_BUF_ERROR && zs.avail_in == 0 && in_done >= zlen) { p.status = 1; break; }   // input ends inside a block
+        if (!grow(p, (size_t)1 << 20)) { p.status = -1; return; }
+        size_t pos = p.body_len;
+        const int r = d->run((uint8_t *)p.body, dictlen, &pos, p.body_cap, stop_bit);
+        p.body_len = pos;
+        if (r == fastinflate::FI_NEED_OUTPUT) continue;
+        if (r == fastinflate::FI_DONE) { p.final_block = true; p.end_bit = d->bitpos; }
+        else if (r == fastinflate::FI_STOPPED) p.end_bit = d->bitpos;
+        else p.status = 1;                                      // not deflate from here, the next piece does not start on a boundary of this one, or the input ends inside a block
+        return;
     }
-    inflateEnd(&zs);
 }
 
 void decode_piece(const unsigned char *z, size_t zlen, size_t stop_bit, bool first, Piece &p) {
-    const size_t nbits = 8 * zlen;
-    if (first) { zlib_part(z, zlen, p.start_bit, stop_bit, nullptr, 0, p); return; }
-    Bits b{z, nbits, p.start_bit};
-    size_t clean = 0;                                         // symbols at the end of head that hold no marker
+    if (first) { fast_part(z, zlen, p.start_bit, stop_bit, nullptr, 0, p); return; }
+    // with an unknown window: 16-bit symbols behind WIN markers (marker i = byte i of the 32 KB before the piece), block by
+    // block until the last WIN symbols hold no marker
+    std::unique_ptr<fastinflate::Decoder> d(new (std::nothrow) fastinflate::Decoder());
+    p.head.lead = WIN;
+    // (room for the whole piece -- five symbols per compressed byte -- is reserved, not touched: the head of gzip -6 text ends
+    // after 0.5 - 1 M symbols, that of gzip -1 text never does, and neither is moved while it grows)
+    const size_t comp = ((stop_bit == ~(size_t)0 ? 8 * zlen : stop_bit) - p.start_bit) / 8;
+    if (!d || !p.head.reserve(std::min(comp * 5 + ((size_t)1 << 20), (size_t)1 << 26))) { p.status = -1; return; }
+    for (size_t i = 0; i < WIN; i++) p.head.p[(ptrdiff_t)i - (ptrdiff_t)WIN] = (sym_t)(MARK + i);
+    d->start(z, zlen, p.start_bit);
     for (;;) {
-        if (b.pos == stop_bit) { p.end_bit = b.pos; return; }
-        if (b.pos > stop_bit) { p.status = 1; return; }
-        if (clean >= WIN) break;                              // a known window: zlib from here
-        const size_t before = p.head.size();
-        int last = 0;
-        // (a text whose copies keep reaching back -- tandem repeats -- never sheds its markers: beyond 2^26 symbols of head
-        // the file is left to the serial path rather than decoded at this decoder's pace)
-        const int r = block(b, p.head, false, &last, (size_t)1 << 26);
-        if (r != 0) { p.status = r == -2 ? -1 : 1; return; }
-        (void)before;
-        clean = 0;                                            // marker-free symbols at the end, as far as it matters
-        for (size_t i = p.head.size(); i > 0 && clean < WIN && p.head[i - 1] < MARK; i--) clean++;
-        if (last) { p.final_block = true; p.end_bit = b.pos; return; }
+        const int r = d->run<sym_t>(p.head.p, WIN, &p.head.n, p.head.cap, stop_bit, true);
+        if (r == fastinflate::FI_NEED_OUTPUT) {
+            // (a text whose copies keep reaching back -- tandem repeats, gzip -1 -- never sheds its markers: a piece is at most
+            // 16 MB of the file and stays below 2^26 symbols; beyond that the file is left to the serial path)
+            if (p.head.cap >= ((size_t)1 << 26)) { p.status = 1; return; }
+            if (!p.head.reserve(std::min(p.head.cap * 2, (size_t)1 << 26))) { p.status = -1; return; }
+            continue;
+        }
+        if (r == fastinflate::FI_DONE) { p.final_block = true; p.end_bit = d->bitpos; return; }
+        if (r != fastinflate::FI_STOPPED) { p.status = 1; return; }
+        if (d->bitpos == stop_bit) { p.end_bit = d->bitpos; return; }
+        size_t clean = 0;                                         // marker-free symbols at the end, as far as it matters
+        for (size_t i = p.head.n; i > 0 && clean < WIN && p.head.p[i - 1] < MARK; i--) clean++;
+        if (clean >= WIN) break;                                  // a known window: the byte decoder from here
     }
     unsigned char dict[WIN];
     for (size_t i = 0; i < WIN; i++) dict[i] = (unsigned char)p.head[p.head.size() - WIN + i];
-    zlib_part(z, zlen, b.pos, stop_bit, dict, WIN, p);
+    fast_part(z, zlen, d->bitpos, stop_bit, dict, WIN, p);
 }
 
 }  // namespace
 
 #define GZ_TRACE(...) do { if (trace) fprintf(stderr, "gz_parallel: " __VA_ARGS__); } while (0)
 
-int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char **out_buf, size_t *out_len) {
+// dst: where the text goes when the caller knows its length (dst_len; a member of a file of several) -- else a new buffer
+static int gzip_parallel(const unsigned char *z, size_t zlen, int threads, char *dst, size_t dst_len, char **out_buf, size_t *out_len) {
     const bool trace = getenv("DEBWT_TRACE_GZ") != nullptr;
     if (threads < 2 || zlen < 18 + ((size_t)1 << 16)) return 1;
     // the member header (RFC 1952)
@@ -419,7 +425,7 @@ int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char
         for (auto &x : th) x.join();
     }
     GZ_TRACE("pieces decoded after %.3f s\n", since());
-    auto cleanup = [&] { for (Piece &p : pc) free(p.body); };
+    auto cleanup = [&] { for (Piece &p : pc) { free(p.alloc); p.alloc = p.body = nullptr; } };
     int st = 0;
     for (size_t i = 0; i < pc.size(); i++) {
         const Piece &p = pc[i];
@@ -438,8 +444,10 @@ int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char
     const size_t total = off.back();
     const size_t want_len = z[zlen - 4] | ((size_t)z[zlen - 3] << 8) | ((size_t)z[zlen - 2] << 16) | ((size_t)z[zlen - 1] << 24);
     if ((total & 0xFFFFFFFFull) != want_len) { GZ_TRACE("length %zu differs from the trailer's %zu\n", total, want_len); cleanup(); return 1; }
-    char *buf = (char *)malloc(total + 1);
+    if (dst && total != dst_len) { cleanup(); return 1; }
+    char *buf = dst ? dst : (char *)big_malloc(total + 1);
     if (!buf) { cleanup(); return -1; }
+    auto drop_buf = [&] { if (!dst) free(buf); };
     // the window of every piece, in order: only the last WIN bytes of a piece are needed for the next one's
     std::vector<std::vector<unsigned char>> window(pc.size() + 1);   // window[i]: the (up to) WIN bytes before piece i
     auto resolve = [&](const std::vector<unsigned char> &win, sym_t s, unsigned char *byte) {
@@ -465,7 +473,7 @@ int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char
             nw.insert(nw.end(), (unsigned char *)p.body, (unsigned char *)p.body + bl);
         }
     }
-    if (st) { free(buf); cleanup(); return st; }
+    if (st) { drop_buf(); cleanup(); return st; }
     GZ_TRACE("windows known after %.3f s\n", since());
     // heads resolved, bodies into place and the CRC of every piece, in parallel
     std::vector<uLong> crc(pc.size(), 0);
@@ -486,14 +494,9 @@ int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char
                 }
                 p.head.release();
                 if (p.body_len) memcpy(dst + (off[i + 1] - off[i] - p.body_len), p.body, p.body_len);
-                free(p.body); p.body = nullptr;
-                uLong c = crc32(0L, Z_NULL, 0);
-                for (size_t a = 0, n = off[i + 1] - off[i]; a < n;) {
-                    const size_t m = std::min<size_t>(n - a, (size_t)1 << 30);
-                    c = crc32(c, dst + a, (uInt)m);
-                    a += m;
-                }
-                crc[i] = c;
+                // (the body is released behind the threads' join: an munmap takes the address space's lock for writing and waits
+                // for -- and holds up -- every page fault of the threads that are filling `buf`)
+                crc[i] = fastinflate::crc32_fast(0, dst, off[i + 1] - off[i]);
             }
         };
         std::vector<std::thread> th;
@@ -501,21 +504,27 @@ int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char
         work();
         for (auto &x : th) x.join();
     }
-    if (bad) { free(buf); cleanup(); return 1; }
     GZ_TRACE("resolved, copied and summed after %.3f s\n", since());
+    cleanup();
+    if (bad) { drop_buf(); return 1; }
     uLong all = crc32(0L, Z_NULL, 0);
     for (size_t i = 0; i < pc.size(); i++) all = crc32_combine(all, crc[i], (z_off_t)(off[i + 1] - off[i]));
     const uLong want_crc = z[zlen - 8] | ((uLong)z[zlen - 7] << 8) | ((uLong)z[zlen - 6] << 16) | ((uLong)z[zlen - 5] << 24);
-    if (all != want_crc) { GZ_TRACE("CRC differs from the trailer's\n"); free(buf); return 1; }             // (the serial path will say whether the file is damaged)
-    *out_buf = buf; *out_len = total;
+    if (all != want_crc) { GZ_TRACE("CRC differs from the trailer's\n"); drop_buf(); return 1; }             // (the serial path will say whether the file is damaged)
+    if (out_buf) *out_buf = buf;
+    if (out_len) *out_len = total;
     return 0;
+}
+
+int inflate_gzip_parallel(const unsigned char *z, size_t zlen, int threads, char **out_buf, size_t *out_len) {
+    return gzip_parallel(z, zlen, threads, nullptr, 0, out_buf, out_len);
 }
 
 // ---- several plain members ---------------------------------------------------------------------------------------------
 // `cat a.fa.gz b.fa.gz`, one member per chromosome or per genome: members are independent deflate streams, but nothing says
 // where the next one starts except the end of the one before.  Member HEADERS are found by their fixed bytes (ID1 ID2 CM = 1f
 // 8b 08, reserved flag bits zero, XFL 0 / 2 / 4, a known OS byte -- ~10^-11 false positives per byte), every candidate is
-// inflated on its own -- many members: by as many threads, each with zlib; few and large ones: one after the other, each cut
+// inflated on its own -- many members: by as many threads; few and large ones: one after the other, each cut
 // into pieces by inflate_gzip_parallel -- and checked against the CRC32 and ISIZE that follow its final block; then the
 // chain is walked from byte 0: every member must start exactly where the one before ended and the last must end the file.
 // A candidate that does not inflate to a checked member (a false positive) is on no chain.  Returns 1 (inflate serially) for
@@ -537,46 +546,50 @@ size_t member_data(const unsigned char *z, size_t zlen, size_t p) {
 
 struct Member { size_t start = 0, end = 0; char *out = nullptr; size_t len = 0; int status = 1; };   // status 0: inflated and checked
 
-// one member with zlib from its header at m.start; `hint`: compressed bytes up to the next candidate (sizes the first buffer)
+// one member from its header at m.start; `hint`: compressed bytes up to the next candidate (sizes the first buffer)
 void inflate_member(const unsigned char *z, size_t zlen, size_t hint, Member &m) {
     const size_t q = member_data(z, zlen, m.start);
     if (!q) return;
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) { m.status = -1; return; }
-    size_t cap = std::max<size_t>(hint * 4, (size_t)1 << 20), in_done = q;
-    char *out = (char *)malloc(cap);
-    uLong crc = crc32(0L, Z_NULL, 0);
-    size_t len = 0;
+    std::unique_ptr<fastinflate::Decoder> d(new (std::nothrow) fastinflate::Decoder());
+    if (!d) { m.status = -1; return; }
+    size_t cap = std::max<size_t>(hint * 5, (size_t)1 << 20), len = 0;      // (reserved, touched only as far as the text goes)
+    char *out = (char *)big_malloc(cap);
     int st = out ? 1 : -1;
+    d->start(z + q, zlen - q, 0);
     while (out) {
-        if (cap - len < ((size_t)1 << 16)) {
-            char *nb = (char *)realloc(out, cap * 2);
+        const int r = d->run((uint8_t *)out, 0, &len, cap, ~(size_t)0);
+        if (r == fastinflate::FI_NEED_OUTPUT) {
+            char *nb = (char *)big_malloc(cap * 2);
             if (!nb) { st = -1; break; }
+            memcpy(nb, out, len);
+            free(out);
             out = nb; cap *= 2;
+            continue;
         }
-        const size_t chunk_in = std::min(zlen - in_done, (size_t)1 << 30), room = std::min(cap - len, (size_t)1 << 30);
-        zs.next_in = const_cast<Bytef *>(z + in_done); zs.avail_in = (uInt)chunk_in;
-        zs.next_out = (Bytef *)out + len; zs.avail_out = (uInt)room;
-        const int r = inflate(&zs, Z_NO_FLUSH);
-        const size_t got = room - zs.avail_out;
-        crc = crc32(crc, (const Bytef *)out + len, (uInt)got);
-        in_done += chunk_in - zs.avail_in;
-        len += got;
-        if (r == Z_STREAM_END) {
+        if (r == fastinflate::FI_DONE) {
+            const size_t in_done = q + ((d->bitpos + 7) >> 3);
             if (in_done + 8 > zlen) break;
             const unsigned char *t = z + in_done;
-            const uLong want_crc = t[0] | ((uLong)t[1] << 8) | ((uLong)t[2] << 16) | ((uLong)t[3] << 24);
+            const uint32_t want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
             const size_t want_len = t[4] | ((size_t)t[5] << 8) | ((size_t)t[6] << 16) | ((size_t)t[7] << 24);
-            if (want_crc == crc && want_len == (len & 0xFFFFFFFFull)) { st = 0; m.end = in_done + 8; }
-            break;
+            if (want_len == (len & 0xFFFFFFFFull) && want_crc == fastinflate::crc32_fast(0, (const uint8_t *)out, len)) { st = 0; m.end = in_done + 8; }
         }
-        if (r != Z_OK && r != Z_BUF_ERROR) break;              // not a deflate stream: a false candidate (or a damaged file)
-        if (r == Z_BUF_ERROR && got == 0 && chunk_in == zs.avail_in) break;   // no progress: the input ends inside the stream
+        break;                                                  // done, or not a deflate stream: a false candidate (or a damaged file)
     }
-    inflateEnd(&zs);
     if (st == 0) { m.out = out; m.len = len; } else free(out);
     m.status = st;
+}
+
+// the member whose header starts at `start` and whose trailer ends at `end`, straight into dst[0 .. size): 0 when all of it holds
+int member_into(const unsigned char *z, size_t zlen, size_t start, size_t end, char *dst, size_t size, fastinflate::Decoder &d) {
+    const size_t q = member_data(z, zlen, start);
+    if (!q || q + 8 > end) return 1;
+    size_t len = 0;
+    d.start(z + q, end - 8 - q, 0);
+    if (d.run((uint8_t *)dst, 0, &len, size, ~(size_t)0) != fastinflate::FI_DONE || len != size || q + ((d.bitpos + 7) >> 3) != end - 8) return 1;
+    const unsigned char *t = z + end - 8;
+    const uint32_t want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    return want_crc == fastinflate::crc32_fast(0, (const uint8_t *)dst, size) ? 0 : 1;
 }
 
 }  // namespace
@@ -609,6 +622,53 @@ int inflate_gzip_members(const unsigned char *z, size_t zlen, int threads, char 
     for (auto &f : found) cand.insert(cand.end(), f.begin(), f.end());
     GZ_TRACE("%zu candidate member headers after %.3f s\n", cand.size(), since());
     if (cand.size() < 2) return 1;                            // one member: inflate_gzip_parallel's case
+    // 1b. The straight case first: EVERY candidate is a member.  Then each member ends where the next candidate begins, its
+    // ISIZE are the four bytes in front of that, and the place of every member's text in the one buffer is known before anything
+    // is inflated: no buffer per member, no copy.  Any member that does not come out at exactly its length, end and CRC-32
+    // (a false candidate, a member of 4 GB or more, damage) sends the file to the general way below.
+    if (cand[0] == 0 && !getenv("DEBWT_GZ_MEMBERS_GENERAL")) {
+        const size_t nm = cand.size();
+        std::vector<size_t> off(nm + 1, 0);
+        for (size_t i = 0; i < nm; i++) {
+            const size_t end = i + 1 < nm ? cand[i + 1] : zlen;
+            off[i + 1] = off[i] + (z[end - 4] | ((size_t)z[end - 3] << 8) | ((size_t)z[end - 2] << 16) | ((size_t)z[end - 1] << 24));
+        }
+        char *buf = off[nm] / 1100 <= zlen ? (char *)big_malloc(off[nm] + 1) : nullptr;      // (deflate cannot expand more than 1032 times)
+        std::atomic<int> bad{buf ? 0 : 1};
+        if (buf && nm * 2 > (size_t)threads) {
+            std::vector<size_t> order(nm);                        // the largest first: the last member to finish is a small one
+            for (size_t i = 0; i < nm; i++) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+            std::atomic<size_t> next{0};
+            auto work = [&] {
+                std::unique_ptr<fastinflate::Decoder> d(new (std::nothrow) fastinflate::Decoder());
+                if (!d) { bad = 1; return; }
+                for (size_t k; !bad && (k = next.fetch_add(1)) < nm;) {
+                    const size_t i = order[k];
+                    if (member_into(z, zlen, cand[i], i + 1 < nm ? cand[i + 1] : zlen, buf + off[i], off[i + 1] - off[i], *d)) bad = 1;
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < threads; t++) th.emplace_back(work);
+            work();
+            for (auto &x : th) x.join();
+        } else if (buf) {
+            std::unique_ptr<fastinflate::Decoder> d(new (std::nothrow) fastinflate::Decoder());
+            for (size_t i = 0; d && i < nm && !bad; i++) {
+                const size_t end = i + 1 < nm ? cand[i + 1] : zlen;
+                if (gzip_parallel(z + cand[i], end - cand[i], threads, buf + off[i], off[i + 1] - off[i], nullptr, nullptr) != 0 &&
+                    member_into(z, zlen, cand[i], end, buf + off[i], off[i + 1] - off[i], *d)) bad = 1;
+            }
+            if (!d) bad = 1;
+        }
+        if (!bad) {
+            GZ_TRACE("%zu members, %zu bytes, each inflated into its place, after %.3f s\n", nm, off[nm], since());
+            *out_buf = buf; *out_len = off[nm];
+            return 0;
+        }
+        free(buf);
+        GZ_TRACE("not every candidate is a member that ends at the next: the general way (after %.3f s)\n", since());
+    }
     std::vector<Member> chain;
     auto cleanup = [&](std::vector<Member> &v) { for (Member &m : v) { free(m.out); m.out = nullptr; } };
     if (cand.size() * 2 > (size_t)threads) {
@@ -646,7 +706,7 @@ int inflate_gzip_members(const unsigned char *z, size_t zlen, int threads, char 
             Member m;
             m.start = cur;
             if (inflate_gzip_parallel(z + cur, nxt - cur, threads, &m.out, &m.len) == 0) { m.end = nxt; m.status = 0; }
-            else inflate_member(z, zlen, nxt - cur, m);         // small, not text, or a false candidate cut it short: zlib finds its end
+            else inflate_member(z, zlen, nxt - cur, m);         // small, not text, or a false candidate cut it short: decoding finds its end
             if (m.status < 0) { cleanup(chain); return -1; }
             if (m.status) { GZ_TRACE("no member at byte %zu: left to the serial path\n", cur); cleanup(chain); return 1; }
             chain.push_back(m);
@@ -657,7 +717,7 @@ int inflate_gzip_members(const unsigned char *z, size_t zlen, int threads, char 
     // 2. one buffer
     std::vector<size_t> off(chain.size() + 1, 0);
     for (size_t j = 0; j < chain.size(); j++) off[j + 1] = off[j] + chain[j].len;
-    char *buf = (char *)malloc(off.back() + 1);
+    char *buf = (char *)big_malloc(off.back() + 1);
     if (!buf) { cleanup(chain); return -1; }
     {
         std::atomic<size_t> next{0};

@@ -3,15 +3,18 @@
 // ("build runs ASan/UBSan on its CPU restatement"; the reference's own hazards it must not repeat are
 // listed at /root/reference/src/getKmer.c:51-52 and src/generateSP.c:351-369).  CPU only -- never run on the GPU box.
 // Build + run: make -C tests/sanitize   (log -> profiles/r03_sanitizers.txt)
+#include "../../debwt_amd/csrc/fast_inflate.h"
 #include "../../debwt_amd/csrc/fasta_host.h"
 #include "../../debwt_amd/csrc/special_host.h"
 #include "../../include/debwt_synth.h"
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -224,6 +227,137 @@ int main() {
         PackedText p{};
         CHECK(pack_fasta_file(path, 3, &p, err, sizeof err) != 0);
         remove(path);
+    }
+    {   // the ingest's own DEFLATE decoder and CRC (fast_inflate.h) against zlib: every kind of block (stored, fixed, dynamic,
+        // codes longer than the root tables), output handed out in steps (resumed after "need output"), 16-bit symbols behind a
+        // window of markers from a block boundary in the middle, stops at block boundaries, damaged and cut-short streams
+        using namespace fastinflate;
+        auto gen = [&](int kind, size_t len) {
+            std::string t(len, 'A');
+            switch (kind) {
+                case 0: for (auto &c : t) c = "ACGT"[rnd() & 3]; for (size_t i = 60; i < len; i += 61) t[i] = '\n'; break;
+                case 1: for (auto &c : t) c = (char)rnd(); break;
+                case 2: break;
+                case 3: for (size_t i = 0; i < len; i++) t[i] = (char)('a' + (rnd() % 3 ? (i % 7) : (rnd() % 26))); break;
+                case 4: {
+                    std::string unit(200 + rnd() % 3000, 'A');
+                    for (auto &c : unit) c = "ACGT"[rnd() & 3];
+                    for (size_t i = 0; i < len; i++) t[i] = rnd() % 50 ? unit[i % unit.size()] : "ACGT"[rnd() & 3];
+                    break;
+                }
+                case 5: for (size_t i = 0; i < len; i++) t[i] = (char)(rnd() % 5 ? 'x' : rnd()); break;
+            }
+            return t;
+        };
+        auto deflate_raw = [&](const std::string &t, int level, int strategy, std::vector<size_t> *bounds) {
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            CHECK(deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy) == Z_OK);
+            std::vector<unsigned char> out(deflateBound(&zs, (uLong)t.size()) + 64);
+            zs.next_in = (Bytef *)t.data(); zs.avail_in = (uInt)t.size(); zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
+            CHECK(deflate(&zs, Z_FINISH) == Z_STREAM_END);
+            out.resize(out.size() - zs.avail_out);
+            deflateEnd(&zs);
+            if (bounds) {                                            // block boundaries (bit, bytes of text before it) as zlib sees them
+                z_stream is; memset(&is, 0, sizeof is);
+                CHECK(inflateInit2(&is, -15) == Z_OK);
+                std::vector<unsigned char> txt(t.size() + 1);
+                is.next_in = out.data(); is.avail_in = (uInt)out.size(); is.next_out = txt.data(); is.avail_out = (uInt)txt.size();
+                for (;;) {
+                    const int r = inflate(&is, Z_BLOCK);
+                    if (r != Z_OK) break;
+                    if ((is.data_type & 128) && !(is.data_type & 64)) { bounds->push_back(8 * (size_t)is.total_in - (size_t)(is.data_type & 63)); bounds->push_back((size_t)is.total_out); }
+                }
+                inflateEnd(&is);
+            }
+            for (int i = 0; i < 8; i++) out.push_back(0xAB);        // (a trailer's worth of bytes behind the data, as in a gzip file)
+            return out;
+        };
+        std::unique_ptr<Decoder> d(new Decoder());
+        int cases = 0;
+        for (int kind = 0; kind < 6; kind++)
+            for (size_t len : {(size_t)0, (size_t)1, (size_t)100, (size_t)4097, (size_t)70000, (size_t)400001})
+                for (int level : {0, 1, 6, 9})
+                    for (int strategy : {Z_DEFAULT_STRATEGY, Z_FIXED, Z_HUFFMAN_ONLY}) {
+                        const std::string t = gen(kind, len);
+                        const auto z = deflate_raw(t, level, strategy, nullptr);
+                        for (size_t step : {(size_t)0, (size_t)1, (size_t)333, (size_t)65536}) {
+                            if (step == 1 && len > 5000) continue;
+                            std::vector<unsigned char> out((step ? step : t.size()) + 1);     // (+ 1: a vector of no bytes has no address)
+                            size_t pos = 0, cap = out.size() - 1;
+                            int rc;
+                            d->start(z.data(), z.size() - 8, 0);
+                            while ((rc = d->run(out.data(), 0, &pos, cap, ~(size_t)0)) == FI_NEED_OUTPUT && cap < t.size() + 1000) { cap += step ? step : 1; out.resize(cap + 1); }
+                            CHECK(rc == FI_DONE && pos == t.size() && !memcmp(out.data(), t.data(), pos) && (d->bitpos + 7) / 8 == z.size() - 8);
+                            cases++;
+                        }
+                    }
+        printf("fast_inflate: %d streams equal to zlib's text\n", cases);
+        {   // from a block boundary in the middle: bytes with the true window in front, 16-bit symbols behind markers, a stop bit
+            int starts = 0;
+            for (int level : {1, 6}) {
+                const std::string t = gen(level == 1 ? 4 : 0, 3000000);
+                std::vector<size_t> bounds;
+                const auto z = deflate_raw(t, level, Z_DEFAULT_STRATEGY, &bounds);
+                CHECK(bounds.size() >= 8);
+                for (size_t b = 2; b + 3 < bounds.size(); b += 2 * (1 + bounds.size() / 24)) {
+                    const size_t bit = bounds[b], at = bounds[b + 1], stop = bounds[bounds.size() - 2], stop_at = bounds[bounds.size() - 1];
+                    const size_t hist = std::min<size_t>(at, 32768);
+                    std::vector<unsigned char> out(hist + (t.size() - at) + 1);
+                    memcpy(out.data(), t.data() + at - hist, hist);
+                    size_t pos = 0;
+                    d->start(z.data(), z.size() - 8, bit);
+                    int rc = d->run(out.data() + hist, hist, &pos, t.size() - at, stop);
+                    CHECK(rc == FI_STOPPED && d->bitpos == stop && pos == stop_at - at && !memcmp(out.data() + hist, t.data() + at, pos));
+                    rc = d->run(out.data() + hist, hist, &pos, t.size() - at, ~(size_t)0);
+                    CHECK(rc == FI_DONE && pos == t.size() - at && !memcmp(out.data() + hist, t.data() + at, pos));
+                    // unknown window: markers, block by block, resolved afterwards
+                    std::vector<uint16_t> sym(32768 + (t.size() - at) + 1);
+                    for (size_t i = 0; i < 32768; i++) sym[i] = (uint16_t)(0x8000 + i);
+                    size_t n = 0, blocks = 0;
+                    d->start(z.data(), z.size() - 8, bit);
+                    while ((rc = d->run<uint16_t>(sym.data() + 32768, 32768, &n, t.size() - at, ~(size_t)0, true)) == FI_STOPPED) blocks++;
+                    CHECK(rc == FI_DONE && n == t.size() - at && blocks >= 1);
+                    bool same = true;
+                    for (size_t i = 0; i < n && same; i++) {
+                        const uint16_t v = sym[32768 + i];
+                        const size_t w = (size_t)(v - 0x8000);       // byte w of the 32 KB that end at `at`
+                        same = v < 256 ? (unsigned char)t[at + i] == v : (v >= 0x8000 && at + w >= 32768 && t[at + w - 32768] == t[at + i]);
+                    }
+                    CHECK(same);
+                    starts++;
+                }
+            }
+            printf("fast_inflate: %d starts in the middle (bytes with a window, 16-bit symbols behind markers, stop bits)\n", starts);
+        }
+        {   // damaged and cut-short streams: an error or another text, never a fault; the output bound holds
+            const std::string t = gen(0, 300000);
+            const auto z = deflate_raw(t, 6, Z_DEFAULT_STRATEGY, nullptr);
+            int refused = 0;
+            for (int k = 0; k < 1500; k++) {
+                auto zz = z;
+                if (k % 3 == 0) zz.resize(8 + rnd() % (zz.size() - 8)); else zz[rnd() % (zz.size() - 8)] ^= (unsigned char)(1 + rnd() % 255);
+                std::vector<unsigned char> out(t.size() + 1000);
+                size_t pos = 0;
+                d->start(zz.data(), zz.size() - 8, 0);
+                const int rc = d->run(out.data(), 0, &pos, out.size(), ~(size_t)0);
+                CHECK(pos <= out.size());
+                if (!(rc == FI_DONE && pos == t.size() && !memcmp(out.data(), t.data(), pos))) refused++;
+            }
+            printf("fast_inflate: %d of 1500 damaged streams refused or decoded to another text\n", refused);
+            CHECK(refused >= 1400);
+        }
+        {   // CRC-32 by carry-less multiplication against zlib's, any length and start value
+            int bad = 0;
+            for (int k = 0; k < 600; k++) {
+                size_t len = rnd() % 5000;
+                if (k % 50 == 0) len = 1000000 + rnd() % 1000;
+                std::string t(len, 0);
+                for (auto &c : t) c = (char)rnd();
+                const uint32_t c0 = (uint32_t)(k % 3 ? rnd() : 0);
+                if (crc32_fast(c0, (const uint8_t *)t.data(), len) != (uint32_t)crc32(c0, (const Bytef *)t.data(), (uInt)len)) bad++;
+            }
+            CHECK(bad == 0);
+        }
     }
     {   // IUPAC letters: refused by default, replaced deterministically (independent of threads) with the option
         std::vector<std::string> r2 = recs;

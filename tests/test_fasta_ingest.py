@@ -46,7 +46,9 @@ def recs():
 
 @pytest.mark.parametrize("threads", [1, 2, 3, 8, 64])
 @pytest.mark.parametrize("shape", ["plain", "lower", "crlf", "blank", "spaces", "wide", "narrow", "gz"])
-def test_pack_fasta_matches_numpy_packer(tmp_path, recs, threads, shape):
+def test_pack_fasta_matches_numpy_packer(tmp_path, recs, threads, shape, monkeypatch):
+    # the packed words are not cleared as a whole (fasta_host.cpp: only the words the packers OR into): start from 0xA5 bytes
+    monkeypatch.setenv("DEBWT_INGEST_POISON", "1")
     p = str(tmp_path / ("t.fa.gz" if shape == "gz" else "t.fa"))
     kw = {"plain": {}, "lower": {"lower": True}, "crlf": {"crlf": True}, "blank": {"blank_lines": True},
           "spaces": {"spaces": True}, "wide": {"width": 100000}, "narrow": {"width": 1}, "gz": {"gz": True}}[shape]
@@ -401,14 +403,20 @@ def test_pack_gzip_shapes_the_parallel_path_declines(tmp_path, monkeypatch):
         api.pack_fasta(bad, 4)
 
 
+@pytest.mark.parametrize("way", ["into_place", "general"])
 @pytest.mark.parametrize("members,threads", [(2, 8), (3, 2), (7, 3), (40, 4)])
-def test_pack_several_plain_gzip_members_in_parallel(tmp_path, monkeypatch, members, threads):
+def test_pack_several_plain_gzip_members_in_parallel(tmp_path, monkeypatch, members, threads, way):
     """`cat a.fa.gz b.fa.gz ...` (one member per chromosome or genome; the reference reads it through gzread,
     src/collect#$.c:26,34-90): the member headers are found by their fixed bytes, every member is inflated on its own -- many
     members by as many threads, few large ones one after the other in pieces -- checked against its CRC32 and ISIZE, and the
     members must chain from byte 0 to the end.  Same packed text as from the plain file, no serial fall-back
     (DEBWT_GZ_REQUIRE_PARALLEL).  One member holds the bytes of a gzip header in its data (a false candidate): it is on no
-    chain.  Bytes behind the last member: left to the serial path, which reads what gzread reads."""
+    chain.  Bytes behind the last member: left to the serial path, which reads what gzread reads.
+    way: when every candidate is a member, each member's ISIZE stands in front of the next candidate and the members are
+    inflated straight into their places of one buffer ("into_place"; the file with the false candidate falls through to the
+    general way by itself); DEBWT_GZ_MEMBERS_GENERAL forces the general way (a buffer per candidate, chained, copied)."""
+    if way == "general":
+        monkeypatch.setenv("DEBWT_GZ_MEMBERS_GENERAL", "1")
     rng = np.random.default_rng(500 + members)
     recs = [rng.integers(0, 4, size=int(rng.integers(60_000, 300_000))).astype(np.uint8) for _ in range(max(members, 6))]
     plain = str(tmp_path / "m.fa")
