@@ -503,6 +503,7 @@ int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, s
             if (zm != MAP_FAILED) {
                 char *buf = nullptr;
                 size_t len = 0;
+                struct Hold { Hold() { release_hold(1); } ~Hold() { release_hold(0); } } hold;   // (buffers given up are released behind the parse)
                 int br = inflate_bgzf((const unsigned char *)zm, (size_t)st.st_size, threads, &buf, &len);
                 if (br == 1 && !getenv("DEBWT_GZ_SERIAL")) {
                     // several plain members (their headers are found first: a file of one member is told apart at once), else
@@ -522,7 +523,8 @@ int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, s
                     auto t1 = std::chrono::steady_clock::now();
                     rc = pack_fasta_buffer(buf, len, threads, out, err, errlen, opts);
                     out->seconds_pack = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-                    free(buf);
+                    void *gone = buf;
+                    release_later(&gone, 1);                            // (the inflated text: 50 ms per GB that nobody has to wait for)
                     return rc;
                 }
             }

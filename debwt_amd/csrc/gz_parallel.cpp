@@ -31,7 +31,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -362,6 +365,59 @@ void decode_piece(const unsigned char *z, size_t zlen, size_t stop_bit, bool fir
 
 }  // namespace
 
+namespace {
+struct Releaser {                             // one thread, started at the first hand-over, that free()s what is queued
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<void *> q;
+    std::thread th;
+    bool started = false, stop = false;
+    int held = 0;                             // > 0: nothing is released for now (the caller's threads are faulting pages in)
+    void loop() {
+        for (;;) {
+            std::unique_lock<std::mutex> g(m);
+            cv.wait(g, [&] { return stop || (!q.empty() && held <= 0); });
+            if (q.empty()) return;                            // (stop: what was queued has been released first)
+            void *p = q.front();
+            q.pop_front();
+            g.unlock();
+            free(p);
+        }
+    }
+    bool give(const std::vector<void *> &v) {                 // false: no thread to be had
+        std::lock_guard<std::mutex> g(m);
+        if (!started) {
+            try { th = std::thread([this] { loop(); }); } catch (...) { return false; }
+            started = true;
+        }
+        q.insert(q.end(), v.begin(), v.end());
+        cv.notify_one();
+        return true;
+    }
+    ~Releaser() {
+        { std::lock_guard<std::mutex> g(m); stop = true; }
+        cv.notify_one();
+        if (started) th.join();
+    }
+};
+}  // namespace
+
+static Releaser &releaser() { static Releaser r; return r; }
+
+void release_hold(int on) {
+    Releaser &r = releaser();
+    { std::lock_guard<std::mutex> g(r.m); r.held += on ? 1 : -1; }
+    r.cv.notify_one();
+}
+
+void release_later(void *const *ptrs, size_t n) {
+    Releaser &r = releaser();
+    std::vector<void *> v;
+    for (size_t i = 0; i < n; i++) if (ptrs[i]) v.push_back(ptrs[i]);
+    if (v.empty()) return;
+    if (getenv("DEBWT_RELEASE_INLINE") || !r.give(v)) for (void *p : v) free(p);
+}
+
 #define GZ_TRACE(...) do { if (trace) fprintf(stderr, "gz_parallel: " __VA_ARGS__); } while (0)
 
 // dst: where the text goes when the caller knows its length (dst_len; a member of a file of several) -- else a new buffer
@@ -486,13 +542,24 @@ static int gzip_parallel(const unsigned char *z, size_t zlen, int threads, char 
                 unsigned char *dst = (unsigned char *)buf + off[i];
                 const std::vector<unsigned char> &win = window[i];
                 const size_t wbase = WIN - win.size();
-                for (size_t j = 0, hl = p.head.size(); j < hl; j++) {
-                    const sym_t s = p.head[j];
-                    if (s < 256) dst[j] = (unsigned char)s;
-                    else if ((size_t)(s - MARK) >= wbase) dst[j] = win[(size_t)(s - MARK) - wbase];
-                    else { bad = 1; break; }
+                const size_t hl = p.head.size();
+                if (wbase == 0 && hl >= 4 * WIN) {
+                    // a whole window in front (every piece but those at the very start of the text): every marker is good, and a
+                    // table by symbol value -- 64 KB: bytes as they are, markers by the window -- turns the head into bytes
+                    // without a branch (the head of gzip -1 text is the whole piece)
+                    std::vector<unsigned char> lut((size_t)1 << 16, 0);
+                    for (size_t v = 0; v < 256; v++) lut[v] = (unsigned char)v;
+                    memcpy(lut.data() + MARK, win.data(), WIN);
+                    const sym_t *h = p.head.p;
+                    for (size_t j = 0; j < hl; j++) dst[j] = lut[h[j]];
+                } else {
+                    for (size_t j = 0; j < hl; j++) {
+                        const sym_t s = p.head[j];
+                        if (s < 256) dst[j] = (unsigned char)s;
+                        else if ((size_t)(s - MARK) >= wbase) dst[j] = win[(size_t)(s - MARK) - wbase];
+                        else { bad = 1; break; }
+                    }
                 }
-                p.head.release();
                 if (p.body_len) memcpy(dst + (off[i + 1] - off[i] - p.body_len), p.body, p.body_len);
                 // (the body is released behind the threads' join: an munmap takes the address space's lock for writing and waits
                 // for -- and holds up -- every page fault of the threads that are filling `buf`)
@@ -505,7 +572,17 @@ static int gzip_parallel(const unsigned char *z, size_t zlen, int threads, char 
         for (auto &x : th) x.join();
     }
     GZ_TRACE("resolved, copied and summed after %.3f s\n", since());
-    cleanup();
+    {   // heads and bodies: released behind the caller's back (release_later; by all threads at once it took as long as one after
+        // the other, and as long as inflating the text)
+        std::vector<void *> gone;
+        for (Piece &p : pc) {
+            if (p.head.p) gone.push_back(p.head.p - p.head.lead);
+            p.head.p = nullptr; p.head.n = p.head.cap = 0;
+            gone.push_back(p.alloc);
+            p.alloc = p.body = nullptr;
+        }
+        release_later(gone.data(), gone.size());
+    }
     if (bad) { drop_buf(); return 1; }
     uLong all = crc32(0L, Z_NULL, 0);
     for (size_t i = 0; i < pc.size(); i++) all = crc32_combine(all, crc[i], (z_off_t)(off[i + 1] - off[i]));
@@ -724,13 +801,17 @@ int inflate_gzip_members(const unsigned char *z, size_t zlen, int threads, char 
         auto work = [&] {
             for (size_t j; (j = next.fetch_add(1)) < chain.size();) {
                 if (chain[j].len) memcpy(buf + off[j], chain[j].out, chain[j].len);
-                free(chain[j].out); chain[j].out = nullptr;
             }
         };
         std::vector<std::thread> th;
         for (int t = 1; t < threads && (size_t)t < chain.size(); t++) th.emplace_back(work);
         work();
         for (auto &x : th) x.join();
+    }
+    {
+        std::vector<void *> gone;
+        for (Member &m : chain) { gone.push_back(m.out); m.out = nullptr; }
+        release_later(gone.data(), gone.size());
     }
     GZ_TRACE("%zu members, %zu bytes after %.3f s\n", chain.size(), off.back(), since());
     *out_buf = buf; *out_len = off.back();

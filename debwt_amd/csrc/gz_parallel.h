@@ -16,6 +16,15 @@ static inline void *big_malloc(size_t n) {
     return p;
 }
 
+// Buffers handed over to be free()d by a thread of their own while the caller goes on (the parse of the text, the upload):
+// returning 1 GB of touched memory to this host's kernel takes 50 ms whether huge pages or not, one thread or sixteen
+// (scripts/micro/page_cost.cpp) -- as long as inflating it.  One thread, started at the first call, works the queue off; it is
+// joined, the queue empty, when the library is unloaded or the process ends.  DEBWT_RELEASE_INLINE=1: free() here and now.
+void release_later(void *const *ptrs, size_t n);
+// release_hold(1) ... release_hold(0): nothing is released in between (an munmap takes the address space's lock for writing: the
+// page faults of threads that are filling fresh buffers wait for it -- measured: the parse ran at half its rate beside it)
+void release_hold(int on);
+
 // z[0 .. zlen): the whole .gz file.  0: *out_buf (malloc'ed, caller frees) holds the *out_len inflated bytes, CRC32 and
 // length checked against the gzip trailer; 1: not done (several members, not text, too small, a block start that could not
 // be found or verified ...) -- inflate it serially; -1: out of memory.
