@@ -78,8 +78,11 @@ inline uint8_t iupac_pick(unsigned char ch, uint64_t pos, uint64_t seed) {
 struct Chunk {
     size_t beg = 0, end = 0;
     bool starts_in_header = false;
+    bool starts_a_line = false;           // the chunk is a piece of its own (a FASTQ rewrite's): what lies before beg is not text
     uint64_t head_bases = 0;              // bases before the chunk's first header start (they belong to an earlier record)
     std::vector<uint64_t> rec_bases;      // per header start in the chunk: bases from there to the next start / chunk end
+    uint64_t sum_bases = 0;               // of rec_bases
+    uint64_t min_complete = ~0ull;        // the shortest of rec_bases but the last (which later chunks may continue)
     // filled by the serial combine
     uint64_t sym0 = 0;                    // text position of the chunk's first symbol
     uint64_t rec0 = 0;                    // records started before the chunk
@@ -236,7 +239,7 @@ void scan_chunk(const char *buf, const Chunk &c, RunFn run, Packer *pk, uint64_t
         if (!nl) return;
         i = (size_t)((const char *)nl - buf) + 1;
     }
-    bool bol = i == 0 || buf[i - 1] == '\n';
+    bool bol = c.starts_a_line || i == 0 || buf[i - 1] == '\n';
     while (i < c.end) {
         if (bol && buf[i] == '>') {
             on_header();
@@ -269,6 +272,10 @@ void census(const char *buf, Chunk &c, IngestOpts opts) {
             else if (c.bad_at < 0) c.bad_at = (long)(p - buf);
         });
     if (any) c.rec_bases.push_back(cur); else c.head_bases = cur;
+    for (size_t j = 0; j < c.rec_bases.size(); j++) {
+        c.sum_bases += c.rec_bases[j];
+        if (j + 1 < c.rec_bases.size() && c.rec_bases[j] < c.min_complete) c.min_complete = c.rec_bases[j];
+    }
 }
 
 // pass 2: symbols of the chunk at their text positions; a header start closes the record before it with a 'T'
@@ -294,49 +301,64 @@ int fail(char *err, size_t errlen, const std::string &msg) {
 
 // FASTQ, which the reference's reader accepts as well (klib kseq_read, src/kseq.h:177-201: '@' or '>' header, sequence
 // lines up to a line that starts with '+', '@' or '>'; after '+' quality characters until there are as many as bases,
-// quality of another length = error; a record that ends at the next header has no qualities): the records are rewritten as header-less FASTA (">\n" + the sequence lines) into `out`, which the chunked
-// FASTA parser then takes.  One serial walk over the lines (memchr speed): a quality line may start with '@' or '>', so
-// record starts cannot be recognised from the middle of the file.  Returns the FASTA length, or -1 with a message.
-long fastq_to_fasta(const char *buf, size_t len, char *out, char *err, size_t errlen) {
-    size_t i = 0, o = 0;
-    uint64_t rec = 0;
-    auto line_end = [&](size_t from) {                       // index of the newline that ends the line at `from`, or len
-        const void *nl = memchr(buf + from, '\n', len - from);
-        return nl ? (size_t)((const char *)nl - buf) : len;
-    };
-    auto payload = [&](size_t from, size_t to) {             // characters of [from, to) that are not white space
-        size_t c = 0;
-        for (size_t j = from; j < to; j++) c += !(buf[j] == '\r' || buf[j] == ' ' || buf[j] == '\t');
-        return c;
-    };
-    while (i < len) {
+// quality of another length = error; a record that ends at the next header has no qualities): the records are rewritten as
+// header-less FASTA (">\n" + the sequence lines) into `out`, which the chunked FASTA parser then takes.
+//
+// fastq_records walks the records that START in [*pi, stop) (the last one is finished wherever it ends) and leaves *pi behind
+// them; out == nullptr: nothing is written, *po only counts.  0, or -1 with a message (err may be null).
+inline size_t fq_line_end(const char *buf, size_t len, size_t from) {      // index of the newline that ends the line at `from`, or len
+    const void *nl = memchr(buf + from, '\n', len - from);
+    return nl ? (size_t)((const char *)nl - buf) : len;
+}
+inline size_t fq_payload(const char *buf, size_t from, size_t to) {        // characters of [from, to) that are not white space
+    // eight at a time: a line of a read set holds no byte below 0x21 (blank, tab and CR all are) -- then all of it counts
+    size_t j = from;
+    uint64_t low = 0;
+    for (; j + 8 <= to; j += 8) {
+        uint64_t x;
+        memcpy(&x, buf + j, 8);
+        low |= (x - 0x2121212121212121ull) & ~x & 0x8080808080808080ull;     // a byte < 0x21 sets its top bit (a borrow from a lower byte only adds false alarms)
+    }
+    for (; j < to; j++) low |= (unsigned char)buf[j] < 0x21 ? 1u : 0u;
+    if (!low) return to - from;
+    size_t c = 0;
+    for (j = from; j < to; j++) c += !(buf[j] == '\r' || buf[j] == ' ' || buf[j] == '\t');
+    return c;
+}
+int fastq_records(const char *buf, size_t len, size_t *pi, size_t stop, char *out, size_t *po, uint64_t *prec, char *err, size_t errlen) {
+    size_t i = *pi, o = *po;
+    uint64_t rec = *prec;
+    int rc = 0;
+    while (i < len && i < stop) {
         if (buf[i] == '\n' || buf[i] == '\r') { i++; continue; }               // blank lines between records
         if (buf[i] != '@' && buf[i] != '>') {
             char m[120];
             snprintf(m, sizeof m, "FASTQ record %llu does not start with '@' or '>' (byte %zu)", (unsigned long long)rec + 1, i);
             fail(err, errlen, m);
-            return -1;
+            rc = -1;
+            break;
         }
-        i = std::min(len, line_end(i) + 1);                                     // header line: the name is not used
-        out[o++] = '>'; out[o++] = '\n';
+        i = std::min(len, fq_line_end(buf, len, i) + 1);                        // header line: the name is not used
+        if (out) { out[o] = '>'; out[o + 1] = '\n'; }
+        o += 2;
         size_t bases = 0;
         // sequence lines, up to a line that starts with '+' (qualities follow) or with '@' / '>' (the next record: this one
         // has no quality section -- kseq_read ends a sequence at any of the three, src/kseq.h:188) or the end of the input
         while (i < len && buf[i] != '+' && buf[i] != '@' && buf[i] != '>') {
-            const size_t e = line_end(i);
-            bases += payload(i, e);
-            memcpy(out + o, buf + i, e - i); o += e - i;
-            out[o++] = '\n';
+            const size_t e = fq_line_end(buf, len, i);
+            bases += fq_payload(buf, i, e);
+            if (out) { memcpy(out + o, buf + i, e - i); out[o + (e - i)] = '\n'; }
+            o += e - i + 1;
             i = std::min(len, e + 1);
         }
         rec++;
         if (i >= len || buf[i] != '+') continue;                                // a record without qualities
         rec--;
-        i = std::min(len, line_end(i) + 1);                                     // the '+' line
+        i = std::min(len, fq_line_end(buf, len, i) + 1);                        // the '+' line
         size_t qual = 0;
         while (i < len && qual < bases) {                                       // quality lines
-            const size_t e = line_end(i);
-            qual += payload(i, e);
+            const size_t e = fq_line_end(buf, len, i);
+            qual += fq_payload(buf, i, e);
             i = std::min(len, e + 1);
         }
         if (qual != bases) {
@@ -344,25 +366,132 @@ long fastq_to_fasta(const char *buf, size_t len, char *out, char *err, size_t er
             snprintf(m, sizeof m, "FASTQ record %llu: %zu quality characters for %zu bases (truncated file?)",
                      (unsigned long long)rec + 1, qual, bases);
             fail(err, errlen, m);
-            return -1;
+            rc = -1;
+            break;
         }
         rec++;
     }
-    return (long)o;
+    *pi = i; *po = o; *prec = rec;
+    return rc;
+}
+
+// One serial walk over the lines (memchr speed).  Returns the FASTA length, or -1 with a message.
+long fastq_to_fasta(const char *buf, size_t len, char *out, char *err, size_t errlen) {
+    size_t i = 0, o = 0;
+    uint64_t rec = 0;
+    return fastq_records(buf, len, &i, len, out, &o, &rec, err, errlen) ? -1 : (long)o;
+}
+
+// The same rewrite by all threads.  A quality line may start with '@' or '>', so a record start cannot be RECOGNISED from the
+// middle of the file -- but it can be guessed and the guess proved: every thread but the first looks, from its cut of the file
+// on, for a line that starts with '@' and begins two records in a row of the full form (header, at least one sequence line of
+// letters, a '+' line, as many quality characters as bases, then '@' or the end); thread 0 starts at byte 0, which is a record
+// start; every thread walks (as the serial walk does) the records that start before the next thread's guess, and the walk
+// must END exactly on that guess.  By induction from byte 0 every guess is then a record start of the one serial walk, and the
+// pieces of FASTA, one behind the other, are what it would have written.
+// Anything else (a walk that does not end on the next guess, any malformed record) returns -1 and the serial walk runs, with
+// its messages.  Chunks without a guess (no full-form record starts there: records without qualities, FASTA records mixed
+// in) are walked by the thread before them.
+bool fq_probe(const char *buf, size_t len, size_t p, size_t *next) {         // a full-form record at p?  *next: where the one behind it starts
+    if (p >= len || buf[p] != '@') return false;
+    size_t i = std::min(len, fq_line_end(buf, len, p) + 1), bases = 0;
+    while (i < len && buf[i] != '+' && buf[i] != '@' && buf[i] != '>') {
+        const size_t e = fq_line_end(buf, len, i);
+        for (size_t j = i; j < e; j++) {
+            const unsigned char c = (unsigned char)buf[j];
+            if (c == '\r' || c == ' ' || c == '\t') continue;
+            if (!((c | 0x20) >= 'a' && (c | 0x20) <= 'z') && c != '*' && c != '-' && c != '.') return false;
+            bases++;
+        }
+        i = std::min(len, e + 1);
+    }
+    if (!bases || i >= len || buf[i] != '+') return false;
+    i = std::min(len, fq_line_end(buf, len, i) + 1);
+    size_t qual = 0;
+    while (i < len && qual < bases) {
+        const size_t e = fq_line_end(buf, len, i);
+        qual += fq_payload(buf, i, e);
+        i = std::min(len, e + 1);
+    }
+    if (qual != bases) return false;
+    while (i < len && (buf[i] == '\n' || buf[i] == '\r')) i++;
+    if (i < len && buf[i] != '@') return false;
+    *next = i;
+    return true;
+}
+// pieces: (begin, end) in `out` of every thread's FASTA.  A thread's piece is written at the offset at which its records
+// begin in the input -- the rewrite never grows (a header line of >= 2 bytes becomes 2, a sequence line stays as long; only a
+// last line without its newline gains one: `out` has two bytes of slack), so the pieces cannot meet -- and the parser takes the
+// pieces as its chunks: one walk, nothing is moved.
+bool fastq_to_fasta_parallel(const char *buf, size_t len, char *out, int threads, std::vector<std::pair<size_t, size_t>> *pieces) {
+    size_t per = (size_t)1 << 20;                                              // at least 1 MB per thread (tests: DEBWT_FASTQ_CHUNK_MIN)
+    if (const char *e = getenv("DEBWT_FASTQ_CHUNK_MIN")) { const long long v = atoll(e); if (v >= 16) per = (size_t)v; }
+    const size_t T = std::min<size_t>((size_t)threads, len / per);
+    if (T < 2 || getenv("DEBWT_FASTQ_SERIAL")) return false;
+    if (getenv("DEBWT_FASTQ_REQUIRE_PARALLEL")) fprintf(stderr, "fastq: %zu threads\n", T);
+    std::vector<size_t> start(T + 1, len), stop(T, len), bytes(T, 0);
+    std::vector<int> bad(T, 0);
+    start[0] = 0;
+    auto all = [&](auto work) {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < T; t++) th.emplace_back(work, t);
+        work((size_t)0);
+        for (auto &x : th) x.join();
+    };
+    all([&](size_t t) {                                                        // the guesses
+        if (t == 0) return;
+        const size_t from = len / T * t, to = t + 1 == T ? len : len / T * (t + 1);
+        size_t p = from;
+        if (p && buf[p - 1] != '\n') p = std::min(len, fq_line_end(buf, len, p) + 1);     // to the next line start
+        for (int tries = 0; p < to && tries < 64; tries++) {                   // (a chunk of records of another form: leave it to the thread before)
+            size_t n1, n2;
+            if (buf[p] == '@' && fq_probe(buf, len, p, &n1) && (n1 >= len || fq_probe(buf, len, n1, &n2))) { start[t] = p; return; }
+            p = std::min(len, fq_line_end(buf, len, p) + 1);
+        }
+    });
+    for (size_t t = T; t-- > 0;) stop[t] = t + 1 < T ? (start[t + 1] < len ? start[t + 1] : stop[t + 1]) : len;
+    all([&](size_t t) {                                                        // the walk, and the proof
+        if (start[t] >= len && t) return;
+        size_t i = start[t], o = start[t];
+        uint64_t rec = 0;
+        if (fastq_records(buf, len, &i, stop[t], out, &o, &rec, nullptr, 0) || i != stop[t]) bad[t] = 1;
+        bytes[t] = o - start[t];
+    });
+    for (size_t t = 0; t < T; t++) if (bad[t]) return false;
+    pieces->clear();
+    for (size_t t = 0; t < T; t++)
+        if (bytes[t]) pieces->emplace_back(start[t], start[t] + bytes[t]);
+    return true;
 }
 
 }  // namespace
+
+// census, combine and pack over the chunks given (equal cuts of a FASTA text, or the pieces of a FASTQ rewrite)
+static int pack_chunks(const char *buf, size_t len, std::vector<Chunk> &ch, PackedText *out, char *err, size_t errlen, IngestOpts opts);
 
 int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out, char *err, size_t errlen, IngestOpts opts) {
     if (threads < 1) threads = 1;
     if (len == 0) return fail(err, errlen, "empty input");
     if (buf[0] == '@') {
+        const bool trace = getenv("DEBWT_TRACE_INGEST") != nullptr;
+        const auto t_begin = std::chrono::steady_clock::now();
         // header, sequence and '+' lines never grow: 2 bytes for every header of >= 2 (">\n" for "@\n")
-        char *fa = (char *)malloc(len + 2);
+        char *fa = (char *)big_malloc(len + 2);
         if (!fa) return fail(err, errlen, "out of memory");
-        const long fl = fastq_to_fasta(buf, len, fa, err, errlen);
-        const int rc = fl < 0 ? -1 : (fl == 0 ? fail(err, errlen, "no FASTQ record") : pack_fasta_buffer(fa, (size_t)fl, threads, out, err, errlen, opts));
-        free(fa);
+        std::vector<std::pair<size_t, size_t>> pieces;
+        int rc;
+        if (fastq_to_fasta_parallel(buf, len, fa, threads, &pieces)) {
+            if (trace) fprintf(stderr, "ingest: FASTQ rewritten as %zu pieces of FASTA after %.3f s\n", pieces.size(),
+                               std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+            std::vector<Chunk> ch(pieces.size());
+            for (size_t t = 0; t < pieces.size(); t++) { ch[t].beg = pieces[t].first; ch[t].end = pieces[t].second; ch[t].starts_a_line = true; }
+            rc = ch.empty() ? fail(err, errlen, "no FASTQ record") : pack_chunks(fa, len + 2, ch, out, err, errlen, opts);
+        } else {
+            const long fl = fastq_to_fasta(buf, len, fa, err, errlen);            // one thread, a small file, or the messages
+            rc = fl < 0 ? -1 : (fl == 0 ? fail(err, errlen, "no FASTQ record") : pack_fasta_buffer(fa, (size_t)fl, threads, out, err, errlen, opts));
+        }
+        void *gone = fa;
+        release_later(&gone, 1);
         return rc;
     }
     size_t nch = std::min<size_t>((size_t)threads, std::max<size_t>(1, len >> 16));
@@ -372,15 +501,24 @@ int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out,
         ch[t].end = t + 1 == nch ? len : len / nch * (t + 1);
         ch[t].starts_in_header = ch[t].beg > 0 && in_header_at(buf, ch[t].beg);
     }
+    return pack_chunks(buf, len, ch, out, err, errlen, opts);
+}
+
+static int pack_chunks(const char *buf, size_t len, std::vector<Chunk> &ch, PackedText *out, char *err, size_t errlen, IngestOpts opts) {
+    const size_t nch = ch.size();
+    const bool trace = getenv("DEBWT_TRACE_INGEST") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
     {
         std::vector<std::thread> th;
         for (size_t t = 1; t < nch; t++) th.emplace_back(census, buf, std::ref(ch[t]), opts);
         census(buf, ch[0], opts);
         for (auto &x : th) x.join();
     }
-    // serial combine: record lengths, chunk offsets
-    std::vector<uint64_t> reclen;
-    uint64_t sym = 0;
+    if (trace) fprintf(stderr, "ingest: census of %zu bytes by %zu threads after %.3f s\n", len, nch, since());
+    // serial combine: chunk offsets, and the record that is open across chunk ends (10^7 reads: no walk over the records here)
+    uint64_t sym = 0, nrec_all = 0, open_len = 0;
+    bool short_rec = false;
     for (size_t t = 0; t < nch; t++) {
         Chunk &c = ch[t];
         if (c.bad_at >= 0) {
@@ -389,22 +527,24 @@ int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out,
                      (unsigned)(unsigned char)buf[c.bad_at], c.bad_at);
             return fail(err, errlen, m);
         }
-        c.sym0 = sym; c.rec0 = reclen.size();
+        c.sym0 = sym; c.rec0 = nrec_all;
         if (c.head_bases) {
-            if (reclen.empty()) return fail(err, errlen, "sequence before the first header");
-            reclen.back() += c.head_bases;
+            if (!nrec_all) return fail(err, errlen, "sequence before the first header");
+            open_len += c.head_bases;
         }
         sym += c.head_bases;
-        for (uint64_t b : c.rec_bases) {
-            if (!reclen.empty()) sym++;                     // separator of the record that ends at this header
-            reclen.push_back(b);
-            sym += b;
+        if (!c.rec_bases.empty()) {
+            if (nrec_all && open_len <= 32) short_rec = true;                        // the open record ends at this chunk's first header
+            if (c.min_complete <= 32) short_rec = true;
+            sym += c.sum_bases + c.rec_bases.size() - (nrec_all ? 0 : 1);            // a separator for every record that ends at a header
+            nrec_all += c.rec_bases.size();
+            open_len = c.rec_bases.back();
         }
     }
-    if (reclen.empty()) return fail(err, errlen, "no FASTA record");
-    for (uint64_t b : reclen)
-        if (b <= 32) return fail(err, errlen, "Length <= 32!");                      // src/collect#$.c:41-45
-    const uint64_t nrec = reclen.size();
+    if (!nrec_all) return fail(err, errlen, "no FASTA record");
+    if (short_rec || open_len <= 32) return fail(err, errlen, "Length <= 32!");      // src/collect#$.c:41-45
+    if (trace) fprintf(stderr, "ingest: %llu records combined after %.3f s\n", (unsigned long long)nrec_all, since());
+    const uint64_t nrec = nrec_all;
     const uint64_t n = sym + 1;                              // + the final '$'
     const uint64_t nwords = ((n + 63) >> 5) + 2;
     // The words are not cleared as a whole (calloc's fresh pages: 4 KB faults from all threads at once; big_malloc: huge pages,
@@ -425,6 +565,7 @@ int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out,
     sep[nrec - 1] = n - 1;                                   // '$': 'T' there and 32 'T' behind (src/collect#$.c:85-90)
     for (uint64_t j = n - 1; j < n + 32; j++) words[j >> 5] |= 3ull << ((31 - (j & 31)) << 1);
     out->words = words; out->nwords = nwords; out->n = n; out->sep = sep; out->nrec = nrec;
+    if (trace) fprintf(stderr, "ingest: packed after %.3f s\n", since());
     return 0;
 }
 

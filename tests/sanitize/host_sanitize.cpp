@@ -387,12 +387,24 @@ int main() {
             CHECK(p.n == ref.n && p.nrec == ref.nrec && !memcmp(p.words, ref.words, ref.nwords * 8));
             free_packed_text(&p);
         }
+        // the rewrite by all threads (fastq_to_fasta_parallel): cuts every 64 .. 4096 bytes, guessed record starts proved by
+        // the walks; the cut-short file below fails in a walk and gets the serial walk's message
+        for (const char *chunk_min : {"64", "300", "4096"}) {
+            setenv("DEBWT_FASTQ_CHUNK_MIN", chunk_min, 1);
+            for (int threads : {2, 5, 16}) {
+                PackedText p{};
+                CHECK(pack_fasta_buffer(fq.data(), fq.size(), threads, &p, err, sizeof err) == 0);
+                CHECK(p.n == ref.n && p.nrec == ref.nrec && !memcmp(p.words, ref.words, ref.nwords * 8));
+                free_packed_text(&p);
+            }
+        }
         PackedText p{};
         std::string cut = fq.substr(0, fq.size() - 5);                                     // quality string cut short
         CHECK(pack_fasta_buffer(cut.data(), cut.size(), 2, &p, err, sizeof err) != 0);
         cut = fq.substr(0, fq.find('+'));                                  // no '+' line: a record without qualities (kseq)
         CHECK(pack_fasta_buffer(cut.data(), cut.size(), 2, &p, err, sizeof err) == 0 && p.nrec == 1);
         free_packed_text(&p);
+        unsetenv("DEBWT_FASTQ_CHUNK_MIN");
     }
     for (const char *bad : {"ACGT\n", ">a\nACGTACGT\n", ">a\nACGTXACGTACGTACGTACGTACGTACGTACGTACGTACGT\n", "@r\nACGT\n+\nIIII\n", "@\n", "@r\nACGT", "", ">only header\n"}) {
         PackedText p{};

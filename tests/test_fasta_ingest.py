@@ -95,6 +95,31 @@ def test_pack_fasta_errors(tmp_path, content, msg):
     assert msg in str(ei.value)
 
 
+@pytest.mark.parametrize("where", ["first", "middle", "last", "at_a_cut"])
+def test_pack_fasta_short_record_among_many_chunks(tmp_path, where):
+    """src/collect#$.c:41-45: a record of 32 bases or fewer is an error wherever it lies -- the chunks' censuses report their
+    shortest complete record, and the one record that is open across a chunk end is followed by the serial combine."""
+    rng = np.random.default_rng(77)
+    recs = [rng.integers(0, 4, size=int(rng.integers(2000, 9000))).astype(np.uint8) for _ in range(200)]   # ~1.1 MB: 8 chunks and more
+    p = str(tmp_path / "short.fa")
+    _write(p, recs, width=60)
+    size = os.path.getsize(p)
+    _check(p, recs, 8)
+    k = {"first": 0, "middle": 100, "last": 199}.get(where)
+    if k is None:                                          # the record that lies across the cut between chunks 3 and 4 of 8
+        data = open(p, "rb").read()
+        k = data[:size // 8 * 4].count(b"\n>")             # (headers before the cut, less the first, which no newline precedes)
+    recs2 = list(recs)
+    recs2[k] = recs[k][:32]
+    _write(p, recs2, width=60)
+    for threads in (1, 8):
+        with pytest.raises(api.DebwtError, match="Length <= 32!"):
+            api.pack_fasta(p, threads)
+    recs2[k] = recs[k][:33]
+    _write(p, recs2, width=60)
+    _check(p, recs2, 8)
+
+
 def test_pack_fasta_missing_file():
     with pytest.raises(api.DebwtError):
         api.pack_fasta("/nonexistent/x.fa", 2)
@@ -240,6 +265,53 @@ def test_pack_fastq_matches_numpy_packer(tmp_path, threads, shape):
           "lower": {"lower": True}, "blank": {"blank": True}}[shape]
     _write_fastq(p, recs, **kw)
     _check(p, recs, threads)
+
+
+@pytest.mark.parametrize("shape", ["plain", "multiline", "crlf", "blank", "mixed"])
+@pytest.mark.parametrize("threads,chunk_min", [(2, 64), (5, 500), (16, 4096)])
+def test_pack_fastq_by_all_threads(tmp_path, monkeypatch, capfd, shape, threads, chunk_min):
+    """The FASTQ rewrite by all threads (fasta_host.cpp, fastq_to_fasta_parallel): every thread but the first GUESSES a record
+    start behind its cut of the file (a quality line may start with '@': it cannot be recognised), walks like the serial walk,
+    and must end exactly on the next thread's guess -- by induction from byte 0 the guesses are then record starts of the one
+    serial walk.  Chunks down to 64 bytes (DEBWT_FASTQ_CHUNK_MIN: cuts inside headers, qualities that start with '@', '>'
+    and '+', '+' lines that repeat the name), records without qualities and FASTA records mixed in (no guess in their
+    chunks): same packed text as the serial walk and as the numpy packer; a malformed record gives the serial walk's message."""
+    rng = np.random.default_rng(40 + threads)
+    recs = [rng.integers(0, 4, size=int(rng.integers(33, 400))).astype(np.uint8) for _ in range(700)]
+    p = str(tmp_path / "par.fq")
+    if shape == "mixed":
+        with open(p, "wb") as f:
+            for i, r in enumerate(recs):
+                s = bytes(ASC[c] for c in r)
+                kind = i % 4 if i + 1 < len(recs) else 1
+                f.write((b">" if kind == 2 else b"@") + b"rec%d\n" % i)
+                for a in range(0, len(s), 61):
+                    f.write(s[a:a + 61] + b"\n")
+                if kind in (0, 3):
+                    f.write(b"+\n" + (b"@" if kind == 0 else b">") + b"I" * (len(s) - 1) + b"\n")
+    else:
+        kw = {"plain": {}, "multiline": {"width": 37}, "crlf": {"crlf": True, "width": 50}, "blank": {"blank": True}}[shape]
+        _write_fastq(p, recs, **kw)
+    monkeypatch.setenv("DEBWT_FASTQ_CHUNK_MIN", str(chunk_min))
+    monkeypatch.setenv("DEBWT_FASTQ_REQUIRE_PARALLEL", "1")          # (says on stderr how many threads took part)
+    capfd.readouterr()
+    _check(p, recs, threads)
+    assert "fastq: %d threads" % threads in capfd.readouterr().err
+    w, n, sep, _, _ = api.pack_fasta(p, threads)
+    monkeypatch.setenv("DEBWT_FASTQ_SERIAL", "1")
+    w1, n1, sep1, _, _ = api.pack_fasta(p, threads)
+    assert n == n1 and np.array_equal(sep, sep1) and np.array_equal(w, w1)
+    monkeypatch.delenv("DEBWT_FASTQ_SERIAL")
+    # one quality character short in the middle: the message of the serial walk, with its record number
+    data = open(p, "rb").read()
+    if shape == "plain":
+        lines = data.split(b"\n")
+        k = 4 * 350 + 3                                              # quality line of record 351
+        lines[k] = lines[k][:-1]
+        bad = str(tmp_path / "bad.fq")
+        open(bad, "wb").write(b"\n".join(lines))
+        with pytest.raises(api.DebwtError, match="FASTQ record 351: "):
+            api.pack_fasta(bad, threads)
 
 
 def test_pack_fastq_records_without_qualities_and_fasta_records_mixed_in(tmp_path):
