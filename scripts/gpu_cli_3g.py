@@ -1,6 +1,6 @@
 """cli/deBWT -- the drop-in program -- end to end on a GRCh38-sized FASTA (3.1 Gbp, 24 records): wall time of the whole
 process (context, FASTA ingest on the host threads, cold build, fetch, write of OUT / OUT.# / OUT.$) and its own
-breakdown; the output is compared with a build of the same text through the API.  python scripts/gpu_cli_3g.py [workload]"""
+breakdown; the output is compared with a build of the same text through the API.  python scripts/gpu_cli_3g.py [workload] [gz [gz6]]"""
 import hashlib, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,6 +31,44 @@ for rep in range(2):                      # second run: the file is in the page 
     print(r.stdout.strip(), flush=True)
     if r.returncode: print(r.stderr[-2000:]); sys.exit(1)
 sha_cli = hashlib.sha256(open("/tmp/cli_OUT", "rb").read()).hexdigest()
+# the same text block-gzipped (BGZF, written by 16 threads) and, with "gz6" as second argument, as ONE gzip -6 member (zlib on
+# one thread: ~75 s per GB): the program inflates them on the host threads (fast_inflate.h); same output files
+extra = []
+if len(sys.argv) > 2:
+    import struct, zlib
+    from concurrent.futures import ThreadPoolExecutor
+    data = open(fa, "rb").read()
+    def bgzf_block(a, B=65280):
+        chunk = data[a:a + B] if a < len(data) else b""
+        co = zlib.compressobj(6, zlib.DEFLATED, -15); body = co.compress(chunk) + co.flush()
+        return (b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1)
+                + body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    t0 = time.time()
+    with open("/tmp/cli_in.bgzf.fa.gz", "wb") as f, ThreadPoolExecutor(16) as pool:
+        for blk in pool.map(bgzf_block, list(range(0, len(data), 65280)) + [len(data)], chunksize=64): f.write(blk)
+    extra.append("/tmp/cli_in.bgzf.fa.gz")
+    print(f"wrote BGZF (level 6) {os.path.getsize(extra[-1]) / 1e9:.2f} GB in {time.time() - t0:.1f} s", flush=True)
+    if "gz6" in sys.argv[2:]:
+        t0 = time.time()
+        with open("/tmp/cli_in.gzip6.fa.gz", "wb") as f:
+            co = zlib.compressobj(6, zlib.DEFLATED, 31)
+            for o in range(0, len(data), 1 << 24): f.write(co.compress(data[o:o + (1 << 24)]))
+            f.write(co.flush())
+        extra.append("/tmp/cli_in.gzip6.fa.gz")
+        print(f"wrote one gzip -6 member {os.path.getsize(extra[-1]) / 1e9:.2f} GB in {time.time() - t0:.1f} s", flush=True)
+    del data
+    for z in extra:
+        for rep in range(2):
+            t0 = time.time()
+            r = subprocess.run([os.path.join(ROOT, "cli", "deBWT"), "-o", "/tmp/cli_OUT_gz", "-t", "16", z], capture_output=True, text=True)
+            dt = time.time() - t0
+            print(f"{os.path.basename(z)} run {rep}: exit {r.returncode}, wall {dt:.2f} s = {syn.n / dt / 1e9:.2f} Gbp/s end to end", flush=True)
+            print(r.stdout.strip().split("\n")[-1], flush=True)
+            if r.returncode: print(r.stderr[-2000:]); sys.exit(1)
+        same = hashlib.sha256(open("/tmp/cli_OUT_gz", "rb").read()).hexdigest() == sha_cli
+        print(f"{os.path.basename(z)}: same OUT as from the plain file: {same}", flush=True)
+        if not same: sys.exit(1)
+    for p in extra + ["/tmp/cli_OUT_gz", "/tmp/cli_OUT_gz.#", "/tmp/cli_OUT_gz.$"]: os.remove(p)
 import torch
 from debwt_amd import api
 text = SN.PinnedArray(syn.nwords)
