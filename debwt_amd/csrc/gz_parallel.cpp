@@ -24,6 +24,8 @@
 #include "fast_inflate.h"
 
 #include <zlib.h>
+#include <pthread.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -368,15 +370,16 @@ void decode_piece(const unsigned char *z, size_t zlen, size_t stop_bit, bool fir
 namespace {
 struct Releaser {                             // one thread, started at the first hand-over, that free()s what is queued
     std::mutex m;
-    std::condition_variable cv;
-    std::deque<void *> q;
-    std::thread th;
-    bool started = false, stop = false;
+    std::condition_variable *cv = new std::condition_variable();   // (on the heap for the same reason: the child leaves the one
+    std::deque<void *> q;                                          //  the parent's thread waits in alone -- destroying it would wait for that thread)
+    std::thread *th = nullptr;                // (on the heap: a process forked off this one must not destroy -- join -- a thread it has not got)
+    pid_t owner = 0;                          // the process the thread runs in
+    bool stop = false;
     int held = 0;                             // > 0: nothing is released for now (the caller's threads are faulting pages in)
     void loop() {
         for (;;) {
             std::unique_lock<std::mutex> g(m);
-            cv.wait(g, [&] { return stop || (!q.empty() && held <= 0); });
+            cv->wait(g, [&] { return stop || (!q.empty() && held <= 0); });
             if (q.empty()) return;                            // (stop: what was queued has been released first)
             void *p = q.front();
             q.pop_front();
@@ -386,28 +389,46 @@ struct Releaser {                             // one thread, started at the firs
     }
     bool give(const std::vector<void *> &v) {                 // false: no thread to be had
         std::lock_guard<std::mutex> g(m);
-        if (!started) {
-            try { th = std::thread([this] { loop(); }); } catch (...) { return false; }
-            started = true;
+        if (!th) {
+            try { th = new std::thread([this] { loop(); }); } catch (...) { th = nullptr; return false; }
+            owner = getpid();
         }
         q.insert(q.end(), v.begin(), v.end());
-        cv.notify_one();
+        cv->notify_one();
         return true;
     }
     ~Releaser() {
         { std::lock_guard<std::mutex> g(m); stop = true; }
-        cv.notify_one();
-        if (started) th.join();
+        cv->notify_one();
+        if (th && owner == getpid()) { th->join(); delete th; }
+        delete cv;
     }
 };
 }  // namespace
 
-static Releaser &releaser() { static Releaser r; return r; }
+static Releaser &releaser();
+// fork(): the child has the queue and the lock as they were but not the thread.  The lock is taken around the fork so that the
+// child does not inherit it held by a thread it has not got; the child forgets the thread (and what was queued: those buffers
+// are the parent's to release) and starts one of its own at its first hand-over.
+static void releaser_prepare() { releaser().m.lock(); }
+static void releaser_parent() { releaser().m.unlock(); }
+static void releaser_child() {
+    Releaser &r = releaser();
+    if (r.th) r.cv = new std::condition_variable();            // (the old one, and the thread object, are left where they are)
+    r.th = nullptr; r.q.clear(); r.held = 0;
+    r.m.unlock();
+}
+static Releaser &releaser() {
+    static Releaser r;
+    static const int once = pthread_atfork(releaser_prepare, releaser_parent, releaser_child);
+    (void)once;
+    return r;
+}
 
 void release_hold(int on) {
     Releaser &r = releaser();
     { std::lock_guard<std::mutex> g(r.m); r.held += on ? 1 : -1; }
-    r.cv.notify_one();
+    r.cv->notify_one();
 }
 
 void release_later(void *const *ptrs, size_t n) {

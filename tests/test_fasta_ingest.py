@@ -520,3 +520,36 @@ def test_pack_several_plain_gzip_members_in_parallel(tmp_path, monkeypatch, memb
         api.pack_fasta(p3, threads)
     monkeypatch.delenv("DEBWT_GZ_REQUIRE_PARALLEL")
     _check(p3, recs, threads)
+
+
+def test_ingest_in_a_forked_child_of_a_process_that_has_ingested(tmp_path):
+    """The library releases the buffers the gzip ingest gives up on a thread of its own (gz_parallel.cpp, release_later).  A
+    process forked off one that has started that thread has the queue, the lock and the condition variable but not the thread:
+    it must start its own, and must neither wait for nor join the parent's at its exit.  (Run in a process of its own, with a
+    time limit: the failure is a child that never exits.)"""
+    import subprocess, sys, textwrap
+    rng = np.random.default_rng(8)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 400_000)].tobytes()
+    rec = b"".join(seq[a:a + 80] + b"\n" for a in range(0, len(seq), 80))
+    p = str(tmp_path / "members.fa.gz")
+    with open(p, "wb") as f:
+        for i in range(4):
+            f.write(gzip.compress(b">r%d\n" % i + rec, mtime=0))
+    code = textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        import numpy as np
+        from debwt_amd import api
+        os.environ["DEBWT_GZ_REQUIRE_PARALLEL"] = "1"
+        r = api.pack_fasta({p!r}, 4)
+        pid = os.fork()
+        if pid == 0:
+            r2 = api.pack_fasta({p!r}, 4)
+            sys.exit(0 if r2[1] == r[1] and np.array_equal(r2[0], r[0]) else 3)
+        _, st = os.waitpid(pid, 0)
+        r3 = api.pack_fasta({p!r}, 4)
+        sys.exit(0 if os.WIFEXITED(st) and os.WEXITSTATUS(st) == 0 and r3[1] == r[1] else 4)
+    """)
+    done = subprocess.run([sys.executable, "-c", code], timeout=120, capture_output=True, text=True)
+    assert done.returncode == 0, done.stderr[-2000:]
+
