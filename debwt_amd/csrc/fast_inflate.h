@@ -1,15 +1,18 @@
 // fast_inflate.h -- a raw DEFLATE (RFC 1951) decoder and a CRC-32 for the gzip ingest (FASTA / gz -> packed text at
 // >= 10 GB/s; the reference reads gzip through zlib's gzread on one thread, src/collect#$.c:26,34-37 / src/kseq.h).
 //
-// zlib's inflate decodes ~0.3-0.45 GB/s of FASTA text per host thread and its crc32 ~1 GB/s: sixteen threads cannot reach the
-// row's rate through it.  This decoder is built for the ingest's three callers (BGZF members, several plain members, the pieces
-// of one member): a 64-bit bit buffer refilled without a branch, an 11-bit litlen table and an 8-bit distance table whose entries
-// hold symbol, extra-bit count and code length in one word (longer codes through sub-tables), up to two literals per refill,
-// matches copied eight bytes at a time.  It starts at any BIT of the stream with up to 32 KB of history in front of the output,
-// stops at the end of the final block or at a given block boundary, and can be resumed when the output buffer is full (the
-// symbol that did not fit is not consumed).  Near the end of the output it writes byte-exact: members decoded side by side into
-// one buffer never touch each other's bytes.  Anything malformed is an error, never a wrong byte; every caller still checks the
-// member's CRC-32 and ISIZE.
+// zlib's inflate decodes 0.5-0.65 GB/s of FASTA text per host thread of the MI355X box (EPYC 9575F) and its crc32 2 GB/s:
+// sixteen threads cannot reach the row's rate through it.  This decoder is built for the ingest's callers (BGZF members, several
+// plain members, the pieces of one member) and for what gzip makes of DNA text -- matches of 4..9 bytes, 95 % of the bytes at
+// level 6, all of them at level 1; literals where the text is qualities: a 64-bit bit buffer refilled without a branch, an
+// 11-bit litlen table whose entries hold up to four literals or a whole match (length and distance in one look-up), the next
+// entry loaded before the refill, an 8-bit distance table, longer codes through sub-tables, copies by two unconditional 8-byte
+// steps.  1.3-1.5 GB/s per thread on the same host.  Output is bytes, or 16-bit symbols for a start whose window is unknown
+// (markers, see run).  It starts at any BIT of the stream with up to 32 KB of history in front of the output, stops at the end
+// of the final block, at a given block boundary or at every boundary, and can be resumed when the output buffer is full (the
+// symbol that did not fit is not consumed).  It writes nothing at or behind the bound it is given: members decoded side by side
+// into one buffer never touch each other's bytes.  Anything malformed is an error, never a wrong byte; every caller still
+// checks the member's CRC-32 and ISIZE.
 // crc32_fast: the gzip polynomial by carry-less multiplication (PCLMULQDQ folding, the constants of Intel's "Fast CRC Computation
 // for Generic Polynomials Using PCLMULQDQ"), zlib's crc32 for the tail and where the instruction is missing.
 #pragma once
@@ -28,7 +31,7 @@ enum { FI_DONE = 0, FI_STOPPED = 1, FI_NEED_OUTPUT = 2, FI_ERROR = -1 };
 
 constexpr int LROOT = 11, DROOT = 8;
 // A table entry (64 bits):  bits 0..7 the input bits it consumes (0: not a code); bits 8..10 how many literals it holds (root
-// entries of the litlen table hold up to FOUR: DNA text is Huffman-coded literals of 2-3 bits, and one look-up per literal is a
+// entries of the litlen table hold up to FOUR -- as many as their codes fit into the root index: one look-up per literal is a
 // chain of load -> shift -> load, ~7 cycles); bit 11 end of block; bit 12 pointer to a sub-table (bits 32.. its offset, bits
 // 16..20 its index bits); a length / distance: bits 32.. its base, bits 16..20 the number of extra bits, bits 24..28 the length
 // of the code alone (bits 0..7 count both, so one shift consumes the symbol and the extra bits are cut out of the buffer as it
