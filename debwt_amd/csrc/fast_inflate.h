@@ -58,7 +58,7 @@ struct Decoder {
 
     void start(const uint8_t *z, size_t zlen, size_t bit) { in = z; in_len = zlen; bitpos = bit; in_block = false; last = false; }
 
-    // canonical Huffman table from code lengths; false: over-subscribed, or incomplete with more than one code
+    // canonical Huffman table from code lengths; false: over-subscribed, or incomplete (but for one code of one bit, or no code)
     static bool build(uint64_t *tab, int root, const uint8_t *len, int n, bool litlen, const uint64_t *dtab = nullptr) {
         static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
         static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -69,7 +69,7 @@ struct Decoder {
         const int used = n - count[0];
         long left = 1;
         for (int l = 1; l <= 15; l++) { left = left * 2 - count[l]; if (left < 0) return false; }
-        if (left > 0 && used > 1) return false;                  // incomplete: only a code of one symbol may be (zlib allows the same)
+        if (used && left > 0 && (used > 1 || !count[1])) return false;   // incomplete: only ONE code of ONE bit may be (as zlib: inftrees.c "max != 1"); none at all may
         const size_t rootsz = (size_t)1 << root;
         if (left > 0 || !used) memset(tab, 0, rootsz * sizeof(uint64_t));      // 0 = no code here: an error when it is looked up (a complete code fills the root)
         if (!used) return true;
@@ -276,7 +276,7 @@ struct Decoder {
                         long left = 1;
                         bool bad = false;
                         for (int l = 1; l <= 7; l++) { left = left * 2 - count[l]; if (left < 0) { bad = true; break; } }
-                        if (bad || (left > 0 && 19 - count[0] != 1)) break;
+                        if (bad || left > 0) break;               // the code-length code must be complete (zlib: "invalid code lengths set")
                         memset(ctab, 0, sizeof ctab);
                         uint32_t code = 0;
                         for (int l = 1; l <= 7; l++) {

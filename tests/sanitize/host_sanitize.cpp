@@ -346,6 +346,58 @@ int main() {
             printf("fast_inflate: %d of 1500 damaged streams refused or decoded to another text\n", refused);
             CHECK(refused >= 1400);
         }
+        {   // differential: random texts deflated with random level, strategy, memLevel and window, three in four then damaged
+            // (a bit flipped, a byte replaced, cut short, a byte inserted) -- zlib's inflate and this decoder must agree on
+            // whether the stream is good, and when it is on every byte and on where it ends (150,000 such streams agreed when the
+            // decoder was written; zlib is stricter than RFC 1951 about incomplete codes and the decoder follows it)
+            long same = 0, refused = 0, differ = 0;
+            for (long it = 0; it < 8000; it++) {
+                const int kind = (int)(rnd() % 5);
+                const size_t len = rnd() % 3 == 0 ? rnd() % 300 : rnd() % 40000;
+                std::string t(len, 'A');
+                switch (kind) {
+                    case 0: for (auto &c : t) c = "ACGT"[rnd() & 3]; break;
+                    case 1: for (auto &c : t) c = (char)rnd(); break;
+                    case 2: break;
+                    case 3: for (size_t i = 0; i < len; i++) t[i] = (char)(33 + rnd() % 41); break;
+                    case 4: for (size_t i = 0; i < len; i++) t[i] = (char)('a' + (rnd() % 3 ? (i % 7) : (rnd() % 26))); break;
+                }
+                const int strategy = (int)(rnd() % 4);
+                z_stream zs; memset(&zs, 0, sizeof zs);
+                if (deflateInit2(&zs, (int)(rnd() % 10), Z_DEFLATED, -(9 + (int)(rnd() % 7)), 1 + (int)(rnd() % 9), strategy == 3 ? Z_FIXED : strategy) != Z_OK) continue;
+                std::vector<unsigned char> z(deflateBound(&zs, (uLong)len) + 64);
+                zs.next_in = (Bytef *)t.data(); zs.avail_in = (uInt)len; zs.next_out = z.data(); zs.avail_out = (uInt)z.size();
+                deflate(&zs, Z_FINISH); z.resize(z.size() - zs.avail_out); deflateEnd(&zs);
+                for (int m = it % 4 == 0 ? 0 : 1 + (int)(rnd() % 3); m > 0 && !z.empty(); m--) {
+                    const int how = (int)(rnd() % 4);
+                    if (how == 0) z[rnd() % z.size()] ^= (unsigned char)(1u << (rnd() % 8));
+                    else if (how == 1) z[rnd() % z.size()] = (unsigned char)rnd();
+                    else if (how == 2) z.resize(rnd() % (z.size() + 1));
+                    else z.insert(z.begin() + (long)(rnd() % z.size()), (unsigned char)rnd());
+                }
+                const size_t cap = len + 70000;
+                std::vector<unsigned char> o1(cap + 1), o2(cap + 1);
+                z_stream is; memset(&is, 0, sizeof is);
+                CHECK(inflateInit2(&is, -15) == Z_OK);
+                is.next_in = z.data(); is.avail_in = (uInt)z.size(); is.next_out = o1.data(); is.avail_out = (uInt)cap;
+                const int zr = inflate(&is, Z_FINISH);
+                const size_t zn = is.total_out, zin = is.total_in;
+                const bool zfull = zr == Z_BUF_ERROR && is.avail_out == 0;
+                inflateEnd(&is);
+                const size_t zlen_data = z.size();
+                for (int i = 0; i < 8; i++) z.push_back(0);              // (a trailer's worth behind the data, not part of it)
+                d->start(z.data(), zlen_data, 0);
+                size_t pos = 0, lim = rnd() % 2 ? cap : std::min<size_t>(cap, 1 + rnd() % 500);
+                int rc;
+                while ((rc = d->run(o2.data(), 0, &pos, lim, ~(size_t)0)) == FI_NEED_OUTPUT && lim < cap) lim = std::min(cap, lim + 1 + rnd() % 5000);
+                if (zr == Z_STREAM_END && rc == FI_DONE) { if (zn == pos && !memcmp(o1.data(), o2.data(), pos) && (d->bitpos + 7) / 8 == zin) same++; else differ++; }
+                else if (zr != Z_STREAM_END && (rc != FI_DONE || zfull)) refused++;
+                else differ++;
+            }
+            printf("fast_inflate: %ld random streams, three in four damaged: zlib and the decoder both decode %ld to the same bytes, both refuse %ld, differ on %ld\n",
+                   same + refused + differ, same, refused, differ);
+            CHECK(differ == 0 && same >= 2000);
+        }
         {   // CRC-32 by carry-less multiplication against zlib's, any length and start value
             int bad = 0;
             for (int k = 0; k < 600; k++) {
