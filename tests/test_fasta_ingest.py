@@ -553,3 +553,54 @@ def test_ingest_in_a_forked_child_of_a_process_that_has_ingested(tmp_path):
     done = subprocess.run([sys.executable, "-c", code], timeout=120, capture_output=True, text=True)
     assert done.returncode == 0, done.stderr[-2000:]
 
+
+def test_gzip_files_damaged_at_random_are_taken_or_refused_as_the_serial_reader_does(tmp_path, monkeypatch):
+    """Differential: gzip files of every shape the parallel paths take (BGZF, several plain members, one member in pieces) with a
+    byte changed, a stretch cut out, the end cut off or bytes appended, at random: the threads' paths (fast_inflate.h,
+    gz_parallel.cpp) and the serial reader (zlib's gzread, DEBWT_GZ_SERIAL) must both give the same packed text or both refuse
+    the file.  (A change in a header's time stamp or OS byte is no damage; one in the deflate data or a trailer is.)"""
+    rng = np.random.default_rng(2024)
+    recs = [rng.integers(0, 4, size=int(rng.integers(20_000, 60_000))).astype(np.uint8) for _ in range(12)]
+    plain = str(tmp_path / "d.fa")
+    _write(plain, recs, width=70)
+    data = open(plain, "rb").read()
+    cuts = [0] + sorted({data.index(b">", len(data) * i // 5) for i in range(1, 5)}) + [len(data)]
+    shapes = {
+        "bgzf": None,
+        "members": _gz_members([data[a:b] for a, b in zip(cuts[:-1], cuts[1:])], level=6),
+        "one6": gzip.compress(data, compresslevel=6, mtime=0),
+        "one1": gzip.compress(data, compresslevel=1, mtime=0),
+    }
+    pb = str(tmp_path / "b.gz")
+    _write_bgzf(pb, data, block=3000)
+    shapes["bgzf"] = open(pb, "rb").read()
+    monkeypatch.setenv("DEBWT_GZ_PIECE_BYTES", "40000")
+    outcomes = {"same": 0, "both refuse": 0}
+    p = str(tmp_path / "x.fa.gz")
+    for name, blob in shapes.items():
+        for trial in range(24):
+            z = bytearray(blob)
+            how = trial % 6
+            if how == 1: z[int(rng.integers(0, len(z)))] ^= 1 << int(rng.integers(0, 8))
+            elif how == 2: a = int(rng.integers(0, len(z) - 200)); del z[a:a + int(rng.integers(1, 200))]
+            elif how == 3: del z[int(rng.integers(len(z) // 2, len(z))):]
+            elif how == 4: z += bytes(rng.integers(0, 256, size=int(rng.integers(1, 50))).astype(np.uint8))
+            elif how == 5: z[int(rng.integers(len(z) - 40, len(z)))] ^= 0x10          # in the last member's data or trailer
+            open(p, "wb").write(bytes(z))
+            res = []
+            for serial in (False, True):
+                if serial: monkeypatch.setenv("DEBWT_GZ_SERIAL", "1")
+                else: monkeypatch.delenv("DEBWT_GZ_SERIAL", raising=False)
+                try:
+                    w, n, sep, _, _ = api.pack_fasta(p, 5)
+                    res.append((n, w.tobytes(), sep.tobytes()))
+                except api.DebwtError:
+                    res.append(None)
+            assert (res[0] is None) == (res[1] is None), (name, trial, how)
+            if res[0] is not None:
+                assert res[0] == res[1], (name, trial, how)
+                outcomes["same"] += 1
+            else:
+                outcomes["both refuse"] += 1
+    assert outcomes["same"] >= 16 and outcomes["both refuse"] >= 30, outcomes
+
