@@ -29,7 +29,10 @@ namespace fastinflate {
 
 enum { FI_DONE = 0, FI_STOPPED = 1, FI_NEED_OUTPUT = 2, FI_ERROR = -1 };
 
-constexpr int LROOT = 11, DROOT = 8;
+#ifndef FI_LROOT
+#define FI_LROOT 11                    // (12, a 32 KB table: 8 % slower on DNA text, the same on FASTQ -- scripts/micro/inflate_rate.cpp on the box)
+#endif
+constexpr int LROOT = FI_LROOT, DROOT = 8;
 // A table entry (64 bits):  bits 0..7 the input bits it consumes (0: not a code); bits 8..10 how many literals it holds (root
 // entries of the litlen table hold up to FOUR -- as many as their codes fit into the root index: one look-up per literal is a
 // chain of load -> shift -> load, ~7 cycles); bit 11 end of block; bit 12 pointer to a sub-table (bits 32.. its offset, bits

@@ -1,6 +1,6 @@
 // inflate_rate.cpp -- the ingest's DEFLATE decoder and CRC-32 (debwt_amd/csrc/fast_inflate.h) against zlib's on FASTA-like text,
 // one thread and T threads side by side (host only).  g++ -O3 -std=c++17 -o inflate_rate scripts/micro/inflate_rate.cpp -lz -lpthread
-// usage: inflate_rate [Mbp per thread = 100] [threads = 16]
+// usage: inflate_rate [Mbp per thread = 100] [threads = 16] [fastq]      (-DFI_LROOT=12: the litlen root table of 12 bits)
 #include "../../debwt_amd/csrc/fast_inflate.h"
 #include <chrono>
 #include <cstdio>
@@ -17,6 +17,18 @@ int main(int argc, char **argv) {
     std::string s(len, 'A');
     for (auto &c : s) c = "ACGT"[rng() & 3];
     for (size_t i = 60; i < len; i += 61) s[i] = '\n';
+    const bool fastq = argc > 3 && !strcmp(argv[3], "fastq");       // reads of 100 b with 41 quality values: literals, not matches
+    if (fastq) {
+        size_t o = 0;
+        for (size_t r = 0; o + 220 < len; r++) {
+            o += (size_t)snprintf(&s[o], 16, "@r%010zu\n", r);
+            for (int i = 0; i < 100; i++) s[o++] = "ACGT"[rng() & 3];
+            s[o++] = '\n'; s[o++] = '+'; s[o++] = '\n';
+            for (int i = 0; i < 100; i++) s[o++] = (char)(33 + rng() % 41);
+            s[o++] = '\n';
+        }
+        for (; o < len; o++) s[o] = '\n';
+    }
     for (int level : {1, 6}) {
         z_stream zs; memset(&zs, 0, sizeof zs);
         deflateInit2(&zs, level, Z_DEFLATED, -15, 8, 0);
