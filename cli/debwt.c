@@ -111,12 +111,12 @@ static int write_outputs(const char *obj, const uint64_t *bwt, uint64_t n, const
 /* A one-shot program pays for its device memory (the driver clears what another process released, ~33 GiB/s): the helper
  * thread allocates the workspace (debwt_reserve) and the page-locked output buffers while the main thread still reads and
  * packs the FASTA file -- the file size bounds the text length. */
-struct reserve_job { debwt_ctx *ctx; uint64_t n_bound; uint64_t *bwt; int rc; double seconds; };
+struct reserve_job { debwt_ctx *ctx; uint64_t n_bound; uint64_t *bwt; int rc; double seconds; unsigned flags; };
 double now(void);
 static void *reserve_main(void *arg) {
     struct reserve_job *j = arg;
     double t0 = now();
-    j->rc = debwt_reserve(j->ctx, j->n_bound, 1, 0.0, DEBWT_RESERVE_ONE_SHOT);
+    j->rc = debwt_reserve(j->ctx, j->n_bound, 1, 0.0, j->flags);
     void *p = NULL;
     if (debwt_pinned_alloc((size_t)((j->n_bound + 31) >> 5) * 8 + 64, &p) == DEBWT_OK) j->bwt = p;
     j->seconds = now() - t0;
@@ -268,7 +268,8 @@ int main(int argc, char **argv) {
     if (rc) { fprintf(stderr, "debwt_create: %s\n", debwt_strerror(rc)); return 1; }
     double t1 = now();
     /* workspace and output buffer on a helper thread while the file is read (plain FASTA: a base takes a byte of the file) */
-    struct reserve_job job = {ctx, 0, NULL, 0, 0.0};
+    /* (--dump wants the text sorted in one key range: no compact plan then; DEBWT_CLI_NO_COMPACT: A/B) */
+    struct reserve_job job = {ctx, 0, NULL, 0, 0.0, DEBWT_RESERVE_ONE_SHOT | (dump || getenv("DEBWT_CLI_NO_COMPACT") ? 0u : DEBWT_RESERVE_COMPACT)};
     pthread_t helper;
     int have_helper = 0;
     {
@@ -288,6 +289,9 @@ int main(int argc, char **argv) {
     double t1b = now();
     if (have_helper) pthread_join(helper, NULL);
     double t1c = now();
+    /* gzip input: the text's length was not known beside the parse; the same compact plan now (a few key ranges more, a third
+     * of the device memory: a process right behind another waits for the driver to clear what that one released) */
+    if (!rc && !have_helper && !dump && !getenv("DEBWT_CLI_NO_COMPACT")) (void)debwt_reserve(ctx, pt.n, pt.nrec, 0.0, DEBWT_RESERVE_ONE_SHOT | DEBWT_RESERVE_COMPACT);
     if (!rc) { rc = debwt_load_text(ctx, pt.words, pt.n, pt.sep, pt.nrec); if (rc) snprintf(msg, sizeof msg, "%s", debwt_last_error(ctx)); }
     if (rc) {
         fprintf(stderr, "%s (sequence must be ACGT only unless --iupac is given, records > 32 bases)\n", msg);

@@ -110,10 +110,10 @@ class DeBWT:
         st = self.stats()
         self.n, self.nrec = st["n"], st["nrec"]
 
-    def reserve(self, n, nrec, branching=0.0, one_shot=False):
+    def reserve(self, n, nrec, branching=0.0, one_shot=False, compact=False):
         """Allocate the workspace of a text of up to n symbols in nrec records ahead of the load (debwt_reserve): call it
         on a thread of its own while the input is still being read -- ctypes releases the GIL for the call."""
-        self._chk(self._L.debwt_reserve(self._h, int(n), int(nrec), float(branching), 1 if one_shot else 0))
+        self._chk(self._L.debwt_reserve(self._h, int(n), int(nrec), float(branching), (1 if one_shot else 0) | (2 if compact else 0)))
 
     def set_range_cap(self, max_instances):
         """Largest number of node instances sorted in one go; larger texts are built in k-mer-prefix ranges."""

@@ -1783,7 +1783,7 @@ extern "C" int debwt_bwt_assemble(debwt_ctx *c) {
 // (blue entries, SP code, sub-block tables) for `branching` of the positions being branching nodes (<= 0: 0.12; a text that
 // needs more grows them when it gets there).  Not to be called while another call on the context is running.
 extern "C" int debwt_reserve(debwt_ctx *c, uint64_t n, uint64_t nrec, double branching, unsigned flags) {
-    if (!c || n < 34 || nrec == 0 || n <= nrec * (uint64_t)c->K || (flags & ~DEBWT_RESERVE_ONE_SHOT)) return DEBWT_EINVAL;
+    if (!c || n < 34 || nrec == 0 || n <= nrec * (uint64_t)c->K || (flags & ~(DEBWT_RESERVE_ONE_SHOT | DEBWT_RESERVE_COMPACT))) return DEBWT_EINVAL;
     // before the text is there, and only then: the buffers below are re-allocated WITHOUT their contents, so a context that
     // holds a loaded text (or a result) would go on with a stale census over uninitialised memory
     if (c->stage >= ST_LOADED) { c->err = "debwt_reserve: the context already holds a text (reserve comes before the load)"; return DEBWT_ESTATE; }
@@ -1821,7 +1821,18 @@ extern "C" int debwt_reserve(debwt_ctx *c, uint64_t n, uint64_t nrec, double bra
         // with the context (debwt_set_range_cap).
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         const double gib = (double)(tw * 8 + bw * 8 + ngroups * 20 + (n - NS)) / (double)(1ull << 30);
-        if ((flags & DEBWT_RESERVE_ONE_SHOT) && gib > 4.0 && secs > 0.010 * gib) {
+        if ((flags & DEBWT_RESERVE_COMPACT) && (n - NS) <= 20000000000ull) {
+            // (Beyond ~20 Gbp the buffers that grow with the text alone -- 3-4 bytes per base -- are half of the device's memory:
+            // a run behind another of the same size waits whatever the ranges are, 30 Gbp: 10.3-10.9 s of wall time with 16 ranges,
+            // 11.5 with 7, profiles/r06_cli_compact_plan.txt; the rule below stays in charge there.)
+            // Key ranges of 2^29 instances whatever the allocations cost so far: the driver clears memory when it is RELEASED
+            // and an allocation that is handed a block not yet cleared waits for the whole job (profiles/r06_malloc_cost.txt: 96 GB
+            // right behind another process: 72 GB at once, then 2.7 s) -- the first buffers say nothing about the large ones.
+            // 3.1 Gbp in 6 ranges: 28 GiB instead of 102, 158 ms per build instead of 146 (scripts/gpu_range_footprint.py).
+            const u64 P = std::min<u64>(RS_MAX_RANGES, ((n - NS) + (1ull << 29) - 1) >> 29);
+            const u64 want = (u64)((double)(n - NS) / (double)std::max<u64>(1, P) * 1.02) + 1;
+            if (P > 1 && want < cap) { cap = std::max<u64>(want, 1ull << 26); c->range_cap = cap; c->plan_valid = false; }
+        } else if ((flags & DEBWT_RESERVE_ONE_SHOT) && gib > 4.0 && secs > 0.010 * gib) {
             const double per_range_s = 0.034 * (double)n / 30e9 + 0.004;
             const double P = std::min<double>(RS_MAX_RANGES, std::sqrt(30.0 * (double)(n - NS) / 35e9 / per_range_s));
             const u64 want = (u64)((double)(n - NS) / std::max(1.0, P) * 1.02) + 1;   // (cuts fall on prefix bins: a little slack)

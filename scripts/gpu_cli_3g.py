@@ -31,6 +31,21 @@ for rep in range(2):                      # second run: the file is in the page 
     print(r.stdout.strip(), flush=True)
     if r.returncode: print(r.stderr[-2000:]); sys.exit(1)
 sha_cli = hashlib.sha256(open("/tmp/cli_OUT", "rb").read()).hexdigest()
+# A/B of the compact plan the program asks for (DEBWT_RESERVE_COMPACT: key ranges of 2^29 instances, a third of the device memory):
+# two runs right behind each other without it
+for rep in range(2):
+    t0 = time.time()
+    r = subprocess.run([os.path.join(ROOT, "cli", "deBWT"), "-o", "/tmp/cli_OUT", "-t", "16", fa], capture_output=True, text=True,
+                       env=dict(os.environ, DEBWT_CLI_NO_COMPACT="1"))
+    dt = time.time() - t0
+    print(f"without the compact plan, run {rep}: exit {r.returncode}, wall {dt:.2f} s = {syn.n / dt / 1e9:.2f} Gbp/s end to end", flush=True)
+    print(r.stdout.strip().split("\n")[-1], flush=True)
+for rep in range(2, 4):
+    t0 = time.time()
+    r = subprocess.run([os.path.join(ROOT, "cli", "deBWT"), "-o", "/tmp/cli_OUT", "-t", "16", fa], capture_output=True, text=True)
+    dt = time.time() - t0
+    print(f"run {rep} (compact again): exit {r.returncode}, wall {dt:.2f} s = {syn.n / dt / 1e9:.2f} Gbp/s end to end", flush=True)
+    print(r.stdout.strip().split("\n")[-1], flush=True)
 # the same text block-gzipped (BGZF, written by 16 threads) and, with "gz6" as second argument, as ONE gzip -6 member (zlib on
 # one thread: ~75 s per GB): the program inflates them on the host threads (fast_inflate.h); same output files
 extra = []

@@ -132,13 +132,19 @@ def test_k_over_its_range_at_config2_size(api):
     want = census.astype(np.int64).copy()
     want[3] += syn.nrec
     ref = None
-    for k in (32, 20, 16):
-        d = api.DeBWT(k=k)
+    for k in (32, "compact", 20, 16):
+        # "compact": k = 32 behind debwt_reserve(..., ONE_SHOT | COMPACT), the plan cli/deBWT asks for -- key ranges of 2^29
+        # instances (six here instead of one, a third of the device memory): the same rows
+        d = api.DeBWT(k=32 if k == "compact" else k)
+        if k == "compact":
+            d.reserve(syn.n, syn.nrec, one_shot=True, compact=True)
         d.load_packed(words, syn.n, sep)
         d.build()
         assert (d.bwt_census().astype(np.int64) == want).all(), k
         r = d.verify_device()
         assert r["inverse_bwt_ok"] and r["inverse_bwt"]["mismatches"] == 0, (k, r)
+        if k == "compact":                                   # (radix_pass_keys: the keys of the first key range)
+            assert 0 < d.stats()["radix_pass_keys"] < syn.n // 2, d.stats()["radix_pass_keys"]
         w, h, dr = d.fetch()
         d.close()
         cur = (zlib.crc32(w.view(np.uint8)), zlib.crc32(h.view(np.uint8)), dr)
