@@ -73,7 +73,7 @@ SYMBOLS = [
     "debwt_shard_facts_export", "debwt_shard_classify_global", "debwt_shard_info", "debwt_shard_fetch",
     "debwt_shard_partition_keys", "debwt_shard_plan", "debwt_shard_ranges", "debwt_shard_sort_begin",
     "debwt_shard_sort_range", "debwt_shard_sort_end", "debwt_concat_rows", "debwt_shard_export", "debwt_census_words", "debwt_shard_sp_flags", "debwt_shard_sp_emit",
-    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_verify_device", "debwt_multi_create", "debwt_multi_destroy", "debwt_multi_last_error",
+    "debwt_shard_sp_import", "debwt_shard_blue_route", "debwt_shard_blue_place", "debwt_set_range_cap", "debwt_pack_fasta", "debwt_free_packed", "debwt_load_fasta", "debwt_pack_fasta_opts", "debwt_load_fasta_opts", "debwt_fasta_text_bound", "debwt_host_release_hold", "debwt_special_digest", "debwt_bwt_census", "debwt_fetch_rows", "debwt_verify_device", "debwt_multi_create", "debwt_multi_destroy", "debwt_multi_last_error",
     "debwt_multi_load_text", "debwt_multi_load_fasta", "debwt_multi_build", "debwt_multi_fetch_bwt", "debwt_multi_get_stats",
     "debwt_multi_verify", "debwt_multi_shard", "debwt_pinned_alloc", "debwt_pinned_free", "debwt_shard_key_mode",
     "debwt_multi_set_key_mode", "debwt_special_compare", "debwt_build_to_host", "debwt_multi_set_exchange", "debwt_reserve",
@@ -201,6 +201,10 @@ def lib():
     L.debwt_free_packed.argtypes = [ctypes.POINTER(DebwtPackedText)]
     L.debwt_load_fasta.restype = ctypes.c_int
     L.debwt_load_fasta.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
+    L.debwt_host_release_hold.restype = None
+    L.debwt_host_release_hold.argtypes = [ctypes.c_int]
+    L.debwt_fasta_text_bound.restype = ctypes.c_uint64
+    L.debwt_fasta_text_bound.argtypes = [ctypes.c_char_p]
     L.debwt_pack_fasta_opts.restype = ctypes.c_int
     L.debwt_pack_fasta_opts.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64,
                                         ctypes.POINTER(DebwtPackedText), ctypes.c_char_p, ctypes.c_size_t]

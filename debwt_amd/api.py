@@ -343,6 +343,11 @@ def write_outputs(path, words, hash_rows, dollar_row):
 FASTA_IUPAC_RANDOM = 1
 
 
+def fasta_text_bound(path):
+    """Upper bound of the text length the file can hold, from its size and framing alone (0: not known); debwt_fasta_text_bound."""
+    return int(_lib.lib().debwt_fasta_text_bound(str(path).encode()))
+
+
 def pack_fasta(path, threads=8, iupac_seed=None):
     """Host-only: (words, n, sep, seconds_read, seconds_pack) of a FASTA file in the reference's 2-bit layout."""
     L = _lib.lib()

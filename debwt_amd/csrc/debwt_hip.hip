@@ -21,6 +21,7 @@
 #include "radix_sort.h"
 #include "special_host.h"
 #include "fasta_host.h"
+#include "gz_parallel.h"
 #include "stage_kernels.h"
 #include "special_kernels.h"
 #include "verify_kernels.h"
@@ -480,11 +481,14 @@ extern "C" int debwt_pack_fasta(const char *path, int threads, debwt_packed_text
     return debwt_pack_fasta_opts(path, threads, 0, 0, out, errbuf, errlen);
 }
 extern "C" void debwt_free_packed(debwt_packed_text *p) { free_packed_text(reinterpret_cast<PackedText *>(p)); }
+extern "C" uint64_t debwt_fasta_text_bound(const char *path) { return path ? fasta_text_bound(path) : 0; }
+extern "C" void debwt_host_release_hold(int on) { release_hold(on); }
 
 extern "C" int debwt_load_fasta_opts(debwt_ctx *c, const char *path, int threads, unsigned flags, uint64_t seed) {
     if (!c || !path || (flags & ~DEBWT_FASTA_IUPAC_RANDOM)) return DEBWT_EINVAL;
     PackedText pt{};
     char msg[256] = "";
+    struct Hold { Hold() { release_hold(1); } ~Hold() { release_hold(0); } } hold;      // (the ingest's buffers are released behind the load)
     if (pack_fasta_file(path, threads, &pt, msg, sizeof msg, IngestOpts{flags, seed})) { c->err = msg; return DEBWT_EINVAL; }
     c->own_text.assign(pt.words, pt.words + pt.nwords);
     std::vector<uint64_t> sep(pt.sep, pt.sep + pt.nrec);

@@ -716,6 +716,51 @@ int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, s
     return rc;
 }
 
+uint64_t fasta_text_bound(const char *path) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return 0;
+    struct stat st;
+    if (fstat(fd, &st) || st.st_size < 2) { close(fd); return 0; }
+    const size_t zlen = (size_t)st.st_size;
+    unsigned char h[18] = {0};
+    if (pread(fd, h, zlen < 18 ? zlen : 18, 0) < 2) { close(fd); return 0; }
+    if (!(h[0] == 0x1f && h[1] == 0x8b)) { close(fd); return (uint64_t)zlen + 1; }          // plain: a symbol takes a byte
+    uint64_t bound = 0;
+    if (zlen >= 28 && h[2] == 8 && h[3] == 4) {
+        // BGZF: the walk of inflate_bgzf over the members' BSIZE, their ISIZE added up
+        const unsigned char *z = (const unsigned char *)mmap(nullptr, zlen, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (z != MAP_FAILED) {
+            size_t p = 0;
+            bool ok = true;
+            while (ok && p < zlen) {
+                if (zlen - p < 28 || z[p] != 0x1f || z[p + 1] != 0x8b || z[p + 2] != 8 || z[p + 3] != 4) { ok = false; break; }
+                const size_t xlen = z[p + 10] | ((size_t)z[p + 11] << 8), xend = p + 12 + xlen;
+                size_t q = p + 12, bsize = 0;
+                if (xend + 8 > zlen) { ok = false; break; }
+                while (q + 4 <= xend) {
+                    const size_t slen = z[q + 2] | ((size_t)z[q + 3] << 8);
+                    if (z[q] == 'B' && z[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = (z[q + 4] | ((size_t)z[q + 5] << 8)) + 1;
+                    q += 4 + slen;
+                }
+                if (!bsize || p + bsize > zlen || bsize < 12 + xlen + 8) { ok = false; break; }
+                bound += z[p + bsize - 4] | ((uint64_t)z[p + bsize - 3] << 8) | ((uint64_t)z[p + bsize - 2] << 16) | ((uint64_t)z[p + bsize - 1] << 24);
+                p += bsize;
+            }
+            munmap((void *)z, zlen);
+            if (!ok) bound = 0;
+        }
+    }
+    if (!bound && zlen >= 18 && zlen < ((size_t)1 << 30)) {
+        // one member (as far as its last four bytes can say: a file of several members gives the last one's length -- the
+        // caller's buffers grow when the text turns out longer)
+        unsigned char t[4];
+        if (pread(fd, t, 4, (off_t)zlen - 4) == 4) bound = t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+        if (bound < zlen) bound = 0;                                                         // (not a text that deflated)
+    }
+    close(fd);
+    return bound ? bound + 1 : 0;
+}
+
 void free_packed_text(PackedText *p) {
     if (!p) return;
     free(p->words); free(p->sep);

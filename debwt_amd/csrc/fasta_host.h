@@ -25,3 +25,9 @@ int pack_fasta_buffer(const char *buf, size_t len, int threads, PackedText *out,
 int pack_fasta_file(const char *path, int threads, PackedText *out, char *err, size_t errlen,
                     IngestOpts opts = IngestOpts{0, 0});
 void free_packed_text(PackedText *p);
+
+// An upper bound of the number of text symbols the file can hold, from the file's size and framing alone (no inflate): a plain
+// file: its bytes; block gzip (BGZF): the ISIZE of its members added up; one gzip member of less than 1 GB: its ISIZE (a text of
+// 4 GB and more wraps there, and no DNA text deflates to less than a quarter).  0: not known (several plain members, a large
+// member, not readable).  For a host that reserves device memory beside the parse (debwt_reserve).
+uint64_t fasta_text_bound(const char *path);

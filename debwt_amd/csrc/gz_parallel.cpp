@@ -24,6 +24,7 @@
 #include "fast_inflate.h"
 
 #include <zlib.h>
+#include <malloc.h>
 #include <pthread.h>
 #include <unistd.h>
 
@@ -368,6 +369,21 @@ void decode_piece(const unsigned char *z, size_t zlen, size_t stop_bit, bool fir
 }  // namespace
 
 namespace {
+// A large block goes back to the kernel in slices of 64 MB by madvise(MADV_DONTNEED) first -- that takes the address space's
+// lock for READING, as a page fault does, and does the work (this host clears what it takes back: 50 ms per GB) -- and the
+// munmap inside free() then finds nothing left to do under the lock it takes for WRITING.  One munmap of the 3 GB text stopped
+// every page fault and every copy to the device of the process for 0.16 s (cli/deBWT: the build behind a gzip parse took 0.38 s
+// instead of 0.17 s).
+static void give_back(void *p) {
+    const size_t sz = malloc_usable_size(p);
+    if (sz >= ((size_t)16 << 20) && !getenv("DEBWT_RELEASE_WHOLE")) {
+        const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + sz) & ~(uintptr_t)4095;
+        for (uintptr_t x = a; x < e; x += (uintptr_t)64 << 20)
+            (void)madvise((void *)x, (size_t)std::min<uintptr_t>((uintptr_t)64 << 20, e - x), MADV_DONTNEED);
+    }
+    free(p);
+}
+
 struct Releaser {                             // one thread, started at the first hand-over, that free()s what is queued
     std::mutex m;
     std::condition_variable *cv = new std::condition_variable();   // (on the heap for the same reason: the child leaves the one
@@ -384,7 +400,7 @@ struct Releaser {                             // one thread, started at the firs
             void *p = q.front();
             q.pop_front();
             g.unlock();
-            free(p);
+            give_back(p);
         }
     }
     bool give(const std::vector<void *> &v) {                 // false: no thread to be had

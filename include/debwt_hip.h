@@ -114,6 +114,17 @@ int debwt_load_fasta(debwt_ctx *ctx, const char *path, int threads);
 int debwt_pack_fasta_opts(const char *path, int threads, unsigned flags, uint64_t seed, debwt_packed_text *out,
                           char *errbuf, size_t errlen);
 int debwt_load_fasta_opts(debwt_ctx *ctx, const char *path, int threads, unsigned flags, uint64_t seed);
+/* An upper bound of the text length (symbols incl. separators) the file can hold, from its size and framing alone -- a plain
+ * file: its bytes; block gzip: the members' ISIZE added up; one gzip member below 1 GB: its ISIZE -- or 0 when that cannot be
+ * told (several plain members, a large member).  For the n of a debwt_reserve that runs beside the parse; a text that turns out
+ * longer only makes the buffers grow at the load.  (The reference knows its text's length only after reading it,
+ * src/collect#$.c:52-59.) */
+uint64_t debwt_fasta_text_bound(const char *path);
+/* The ingest of a gzip file gives up buffers as large as the text (inflated text, pieces); the library releases them on a thread
+ * of its own once the text is packed -- returning memory costs this host's kernel 50 ms per GB, and it holds the address space's
+ * lock meanwhile.  Between debwt_host_release_hold(1) and (0) nothing is released: a host that copies the packed text to the
+ * device right behind the parse (debwt_load_text from pageable memory) brackets both.  Calls nest. */
+void debwt_host_release_hold(int on);
 
 /* Device memory for a text of up to n symbols in nrec records, allocated before the text is there: a one-shot host (the
  * reference is one: src/main.c:16-173) calls this on a helper thread while it still reads and packs its input, so that the

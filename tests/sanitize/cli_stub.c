@@ -23,6 +23,8 @@ int debwt_load_fasta_opts(debwt_ctx *c, const char *path, int threads, unsigned 
 int debwt_reserve(debwt_ctx *c, uint64_t n, uint64_t nrec, double branching, unsigned flags) { (void)c; (void)nrec; (void)branching; (void)flags; return n ? 0 : DEBWT_EINVAL; }
 int debwt_pinned_alloc(size_t bytes, void **out) { *out = malloc(bytes); return *out ? 0 : DEBWT_ENOMEM; }
 void debwt_pinned_free(void *p) { free(p); }
+uint64_t debwt_fasta_text_bound(const char *path) { (void)path; return 0; }
+void debwt_host_release_hold(int on) { (void)on; }
 int debwt_pack_fasta_opts(const char *path, int threads, unsigned flags, uint64_t seed, debwt_packed_text *out, char *errbuf,
                           size_t errlen) {
     (void)threads; (void)flags; (void)seed;

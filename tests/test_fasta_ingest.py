@@ -604,3 +604,23 @@ def test_gzip_files_damaged_at_random_are_taken_or_refused_as_the_serial_reader_
                 outcomes["both refuse"] += 1
     assert outcomes["same"] >= 16 and outcomes["both refuse"] >= 30, outcomes
 
+
+def test_text_bound_from_the_file_alone(tmp_path):
+    """debwt_fasta_text_bound: what a host reserves device memory for while the file is still being parsed -- the file's bytes
+    (plain), the members' ISIZE added up (block gzip), the ISIZE of a one-member gzip file; 0 where the framing cannot say
+    (here: a file that is not there).  Never below the text's length for these shapes."""
+    rng = np.random.default_rng(31)
+    recs = [rng.integers(0, 4, size=int(rng.integers(5000, 50000))).astype(np.uint8) for _ in range(9)]
+    plain = str(tmp_path / "b.fa")
+    _write(plain, recs, width=61)
+    data = open(plain, "rb").read()
+    n = sum(len(r) for r in recs) + len(recs)
+    assert api.fasta_text_bound(plain) == len(data) + 1 >= n
+    one = str(tmp_path / "b1.fa.gz")
+    open(one, "wb").write(gzip.compress(data, mtime=0))
+    assert api.fasta_text_bound(one) == len(data) + 1
+    bg = str(tmp_path / "b2.fa.gz")
+    _write_bgzf(bg, data, block=3000)
+    assert api.fasta_text_bound(bg) == len(data) + 1
+    assert api.fasta_text_bound(str(tmp_path / "none.fa")) == 0
+
